@@ -1,0 +1,153 @@
+// oracle/ref/ref_driver.cpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// Driver that runs the *unmodified* reference renderer (compiled from
+// /root/reference by oracle/ref/Makefile into oracle/_ref/) on a pbrt-v1 scene
+// file.  The reference's own front end needs flex/bison (core/pbrtlex.l,
+// core/pbrtparse.y) and its image writer needs OpenEXR (core/exrio.cpp); neither
+// exists here, so this driver
+//   * feeds the reference through its public C++ API (core/api.h:29-85) exactly
+//     as the grammar actions do (core/pbrtparse.y:294-468), using the repo's own
+//     scene parser (pbrt-v1_amd/csrc/host/scene_parser.h) as the tokenizer;
+//   * defines the symbols the un-buildable files would have provided:
+//     line_num / current_file (pbrtparse.y:31-32), ParseFile (parser.cpp:27),
+//     ReadImage / WriteRGBAImage (exrio.cpp:29-96, signatures pbrt.h:234-238).
+//     WriteRGBAImage is the float tap: it dumps the pre-quantisation film.
+// Nothing from /root/reference is copied; the reference is only #included and
+// linked where it lies.
+//
+// usage: pbrt_ref [--out film.bin] [--quiet] scene.pbrt
+// film.bin layout (little endian): char magic[8]="PBRTFILM"; int32 xRes,yRes,
+//   totalX,totalY,xOff,yOff; float rgb[3*xRes*yRes]; float alpha[xRes*yRes].
+#include "pbrt.h"
+#include "api.h"
+#include "paramset.h"
+#include "color.h"
+#include <sys/time.h>
+#include <unistd.h>
+#include <fcntl.h>
+
+#include "../../pbrt-v1_amd/csrc/host/scene_parser.h"
+
+int line_num = 0;
+string current_file;
+
+// ---- shared counters, filled in by the helper plugins (count_accel / keyed_sampler)
+extern "C" {
+unsigned long long g_ref_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // [0]=Intersect calls [1]=IntersectP calls [2]=Intersect hits [3]=IntersectP hits
+double g_ref_times[4] = {0, 0, 0, 0};                             // [0]=accel build s  [1]=t(build done)  [2]=t(film written)
+double ref_now() { timeval tv; gettimeofday(&tv, NULL); return tv.tv_sec + 1e-6 * tv.tv_usec; }
+}
+
+static string g_outPath;
+
+COREDLL bool ParseFile(const char *) { return false; }
+COREDLL Spectrum *ReadImage(const string &, int *, int *) { return NULL; }
+COREDLL void WriteRGBAImage(const string &name, float *pixels, float *alpha, int XRes, int YRes,
+                            int totalXRes, int totalYRes, int xOffset, int yOffset) {
+    g_ref_times[2] = ref_now();
+    string path = g_outPath.empty() ? name + ".film" : g_outPath;
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) { Error("ref_driver: cannot write %s", path.c_str()); return; }
+    int hdr[6] = {XRes, YRes, totalXRes, totalYRes, xOffset, yOffset};
+    fwrite("PBRTFILM", 1, 8, f);
+    fwrite(hdr, sizeof(int), 6, f);
+    fwrite(pixels, sizeof(float), size_t(3) * XRes * YRes, f);
+    fwrite(alpha, sizeof(float), size_t(XRes) * YRes, f);
+    fclose(f);
+}
+
+namespace {
+using pbrthip::ParamList;
+using pbrthip::ParamType;
+
+// ParamList -> reference ParamSet, the job of InitParamSet (pbrtparse.y:470-546)
+void Fill(ParamSet &ps, const ParamList &pl) {
+    for (size_t k = 0; k < pl.size(); ++k) {
+        const pbrthip::Param &p = pl[k];
+        int n = int(p.nums.size());
+        switch (p.type) {
+        case ParamType::Float: ps.AddFloat(p.name, p.nums.data(), n); break;
+        case ParamType::Int: {
+            vector<int> iv(n); for (int i = 0; i < n; ++i) iv[i] = int(p.nums[i]);
+            ps.AddInt(p.name, iv.data(), n); break; }
+        case ParamType::Bool: {
+            int m = int(p.strs.size()); bool *bv = new bool[m ? m : 1];
+            for (int i = 0; i < m; ++i) bv[i] = (p.strs[0] == "true");
+            ps.AddBool(p.name, bv, m); delete[] bv; break; }
+        case ParamType::Point: ps.AddPoint(p.name, (const Point *)p.nums.data(), n / 3); break;
+        case ParamType::Vector: ps.AddVector(p.name, (const Vector *)p.nums.data(), n / 3); break;
+        case ParamType::Normal: ps.AddNormal(p.name, (const Normal *)p.nums.data(), n / 3); break;
+        case ParamType::Color: {
+            vector<Spectrum> sv;
+            for (int i = 0; i + 2 < n; i += 3) { float c[3] = {p.nums[i], p.nums[i + 1], p.nums[i + 2]}; sv.push_back(Spectrum(c)); }
+            ps.AddSpectrum(p.name, sv.data(), int(sv.size())); break; }
+        case ParamType::String: ps.AddString(p.name, p.strs.data(), int(p.strs.size())); break;
+        case ParamType::Texture: if (p.strs.size() == 1) ps.AddTexture(p.name, p.strs[0]); break;
+        }
+    }
+}
+
+struct RefSink : pbrthip::DirectiveSink {
+    void Identity() { pbrtIdentity(); }
+    void Translate(float x, float y, float z) { pbrtTranslate(x, y, z); }
+    void Rotate(float a, float x, float y, float z) { pbrtRotate(a, x, y, z); }
+    void Scale(float x, float y, float z) { pbrtScale(x, y, z); }
+    void LookAt(const float v[9]) { pbrtLookAt(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8]); }
+    void ConcatTransform(const float m[16]) { float t[16]; memcpy(t, m, sizeof t); pbrtConcatTransform(t); }
+    void Transform(const float m[16]) { float t[16]; memcpy(t, m, sizeof t); pbrtTransform(t); }
+    void CoordinateSystem(const std::string &n) { pbrtCoordinateSystem(n); }
+    void CoordSysTransform(const std::string &n) { pbrtCoordSysTransform(n); }
+#define FWD(NAME, CALL) void NAME(const std::string &n, const ParamList &p) { ParamSet ps; Fill(ps, p); CALL(n, ps); }
+    FWD(PixelFilter, pbrtPixelFilter) FWD(Film, pbrtFilm) FWD(Sampler, pbrtSampler)
+    FWD(Accelerator, pbrtAccelerator) FWD(SurfaceIntegrator, pbrtSurfaceIntegrator)
+    FWD(VolumeIntegrator, pbrtVolumeIntegrator) FWD(Camera, pbrtCamera) FWD(Material, pbrtMaterial)
+    FWD(LightSource, pbrtLightSource) FWD(AreaLightSource, pbrtAreaLightSource) FWD(Shape, pbrtShape)
+    FWD(Volume, pbrtVolume)
+#undef FWD
+    void SearchPath(const std::string &n) { pbrtSearchPath(n); }
+    void WorldBegin() { pbrtWorldBegin(); }
+    void AttributeBegin() { pbrtAttributeBegin(); }
+    void AttributeEnd() { pbrtAttributeEnd(); }
+    void TransformBegin() { pbrtTransformBegin(); }
+    void TransformEnd() { pbrtTransformEnd(); }
+    void Texture(const std::string &name, const std::string &type, const std::string &cls, const ParamList &p) {
+        ParamSet ps; Fill(ps, p); pbrtTexture(name, type, cls, ps);
+    }
+    void ReverseOrientation() { pbrtReverseOrientation(); }
+    void ObjectBegin(const std::string &n) { pbrtObjectBegin(n); }
+    void ObjectEnd() { pbrtObjectEnd(); }
+    void ObjectInstance(const std::string &n) { pbrtObjectInstance(n); }
+    void WorldEnd() { pbrtWorldEnd(); }
+};
+}  // namespace
+
+int main(int argc, char **argv) {
+    bool quiet = false; string scene;
+    for (int i = 1; i < argc; ++i) {
+        string a = argv[i];
+        if (a == "--out" && i + 1 < argc) g_outPath = argv[++i];
+        else if (a == "--quiet") quiet = true;
+        else scene = a;
+    }
+    if (scene.empty()) { fprintf(stderr, "usage: %s [--out film.bin] [--quiet] scene.pbrt\n", argv[0]); return 2; }
+    int savedOut = -1;
+    if (quiet) {  // progress bar + StatsPrint go to stdout (util.cpp:396-448, api.cpp:479)
+        fflush(stdout); savedOut = dup(1);
+        int nul = open("/dev/null", O_WRONLY); dup2(nul, 1); close(nul);
+    }
+    double t0 = ref_now();
+    pbrtInit();
+    RefSink sink;
+    pbrthip::SceneParser parser(sink);
+    current_file = scene;
+    bool ok = parser.ParseFile(scene);
+    pbrtCleanup();
+    double t1 = ref_now();
+    if (quiet) { fflush(stdout); dup2(savedOut, 1); close(savedOut); }
+    double render_s = (g_ref_times[1] > 0 && g_ref_times[2] > 0) ? g_ref_times[2] - g_ref_times[1] : -1.;
+    printf("{\"ok\": %s, \"total_s\": %.6f, \"accel_build_s\": %.6f, \"render_s\": %.6f, "
+           "\"closest_rays\": %llu, \"any_rays\": %llu, \"closest_hits\": %llu, \"any_hits\": %llu}\n",
+           ok ? "true" : "false", t1 - t0, g_ref_times[0], render_s,
+           g_ref_counters[0], g_ref_counters[1], g_ref_counters[2], g_ref_counters[3]);
+    return ok ? 0 : 1;
+}
