@@ -1,0 +1,199 @@
+/* pbrt_hip.h -- C ABI of the MI355X (gfx950) implementation of pbrt-v1's
+ * Scene::Render hot path.  Plain C: pointers, sizes and PODs only.
+ *
+ * The reference has NO foreign-function interface for this path: Scene::Render
+ * (core/scene.cpp:32-88) is a non-virtual C++ loop that calls C++ plugin objects
+ * created by extern "C" factories taking C++ types (core/dynload.cpp:112-260).  The
+ * boundary below is therefore the one a maintainer would introduce between
+ * RenderOptions::MakeScene (core/api.cpp:484-529) and Scene::Render
+ * (core/api.cpp:475): everything MakeScene has produced is handed over as flat
+ * arrays, the frame is rendered on the GPU, and the film comes back in the layout
+ * ImageFilm keeps (film/image.cpp:57-65).  INTEGRATION.md shows the reference-side
+ * stub.  Each entry point cites the reference interface it replaces.
+ *
+ * Conventions: every function returns 0 on success, a negative RT_E* code on
+ * failure (no exceptions cross the boundary, like the reference);
+ * rt_last_error() gives the message.  The caller owns all host buffers; the
+ * library owns device memory.  One hipStream_t per handle; a handle may be used
+ * from one thread at a time.  All arithmetic is IEEE float32 compiled without
+ * FMA contraction so that results track the reference's SSE build.
+ */
+#ifndef PBRT_HIP_H
+#define PBRT_HIP_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK 0
+#define RT_EINVAL (-1)   /* bad argument / inconsistent description          */
+#define RT_EDEVICE (-2)  /* HIP runtime error (no device, OOM, launch failed) */
+#define RT_ESTATE (-3)   /* call out of order (e.g. render before film bind)  */
+
+typedef struct RtScene RtScene; /* opaque */
+
+/* ---- materials: materials/matte.cpp:46-64, glass.cpp:46-63, mirror.cpp:42-55 ---- */
+enum { RT_MAT_MATTE = 0, RT_MAT_MIRROR = 1, RT_MAT_GLASS = 2 };
+typedef struct RtMaterial {
+    int32_t type;
+    float kd[3];   /* matte Kd  | mirror/glass Kr  (already .Clamp()'ed >= 0)   */
+    float kt[3];   /* glass Kt                                                   */
+    float sigma;   /* matte: Oren-Nayar sigma in degrees, clamped [0,90]; 0 = Lambertian */
+    float ior;     /* glass "index"                                              */
+} RtMaterial;
+
+/* ---- lights: lights/point.cpp:49-69, lights/area.cpp:28-105 ---- */
+enum { RT_LIGHT_POINT = 0, RT_LIGHT_AREA = 1 };
+typedef struct RtLight {
+    int32_t type;
+    float color[3];      /* point: I      area: Lemit                                */
+    float pos[3];        /* point light position (world)                            */
+    int32_t n_samples;   /* Light::nSamples (light.h:39)                            */
+    uint32_t first_tri;  /* area: range in light_tris (ShapeSet order, shape.h:112) */
+    uint32_t n_tris;
+    int32_t reverse_orientation; /* Triangle::Sample flips Ns by this only (trianglemesh.cpp:346) */
+    int32_t flip_normal;         /* reverseOrientation ^ transformSwapsHandedness (shape.cpp:49)   */
+} RtLight;
+
+/* ---- camera: core/camera.cpp:50-70, cameras/perspective.cpp:51-82 ---- */
+typedef struct RtCamera {
+    float raster_to_camera[16]; /* row-major 4x4, as Matrix4x4::m (core/transform.h) */
+    float camera_to_world[16];
+    float lens_radius, focal_distance, hither, yon;
+    float shutter_open, shutter_close;
+} RtCamera;
+
+/* ---- homogeneous medium: volumes/homogeneous.cpp:27-74 ---- */
+typedef struct RtVolume {
+    int32_t present;
+    float world_to_volume[16];
+    float p0[3], p1[3];
+    float sigma_a[3], sigma_s[3], le[3];
+    float g;
+} RtVolume;
+
+/* ---- accelerator parameters: accelerators/kdtree.cpp:489-498, grid.cpp:431-434 ---- */
+enum { RT_ACCEL_KDTREE = 0, RT_ACCEL_GRID = 1 };
+typedef struct RtAccelParams {
+    int32_t kind;
+    int32_t isect_cost, trav_cost, max_prims, max_depth; /* kd defaults 80, 1, 1, -1 */
+    float empty_bonus;                                    /* kd default 0.5           */
+    int32_t build_threads;                                /* 0 = auto                  */
+} RtAccelParams;
+
+/* Scene description = what MakeScene hands to Scene::Scene (core/scene.cpp:100-119),
+ * flattened.  Triangles are in the order KdTreeAccel's FullyRefine produces
+ * (kdtree.cpp:146-148: per mesh, last triangle first). Vertices are world space
+ * (trianglemesh.cpp:166-168). */
+typedef struct RtSceneDesc {
+    uint32_t n_tris;
+    const float *tri_verts;       /* [n_tris][9]  p1 p2 p3                                   */
+    const uint16_t *tri_material; /* [n_tris] index into materials                             */
+    const int32_t *tri_light;     /* [n_tris] area-light index (GetAreaLight) or -1           */
+    const uint8_t *tri_flags;     /* [n_tris] bit0 = flip geometric normal (shape.cpp:49-50)   */
+    uint32_t n_materials;
+    const RtMaterial *materials;
+    uint32_t n_lights;
+    const RtLight *lights;
+    uint32_t n_light_tris;
+    const float *light_tris;      /* [n_light_tris][9] emitter triangles, ShapeSet order       */
+    RtCamera camera;
+    RtVolume volume;
+    RtAccelParams accel;
+} RtSceneDesc;
+
+/* ---- per-frame description ---- */
+enum { RT_INTEGRATOR_WHITTED = 0, RT_INTEGRATOR_DIRECT = 1, RT_INTEGRATOR_PATH = 2 };
+enum { RT_STRATEGY_ALL = 0, RT_STRATEGY_ONE = 1 };
+enum { RT_VOLUME_NONE = 0, RT_VOLUME_EMISSION = 1, RT_VOLUME_SINGLE = 2 };
+enum { RT_SAMPLER_STRATIFIED = 0, RT_SAMPLER_LOWDISCREPANCY = 1, RT_SAMPLER_RANDOM = 2 };
+
+typedef struct RtRenderDesc {
+    /* SurfaceIntegrator: integrators/{whitted,directlighting,path}.cpp factories */
+    int32_t integrator, max_depth, strategy;
+    /* VolumeIntegrator: integrators/{emission,single}.cpp */
+    int32_t volume_integrator;
+    float step_size;
+    /* Sampler: samplers/{stratified,lowdiscrepancy,random}.cpp */
+    int32_t sampler, x_samples, y_samples, jitter, pixel_samples;
+    uint32_t seed;            /* counter-RNG seed (see oracle/ref/keyed_rng.cpp)         */
+    /* Film: film/image.cpp:69-101,148-156 */
+    int32_t x_res, y_res;
+    int32_t x_pixel_start, y_pixel_start, x_pixel_count, y_pixel_count; /* crop window in pixels */
+    int32_t x_start, x_end, y_start, y_end;  /* sample extent (GetSampleExtent)               */
+    float filter_x_width, filter_y_width;
+    float filter_table[256];  /* 16x16, image.cpp:89-101                                   */
+    /* Work partition (reference: cropwindow processes, image.cpp:220-228): pixels of the
+     * sample extent, in scanline order, are grouped into tiles of tile_pixels consecutive
+     * pixels; this call renders tiles t with t % shard_count == shard_index. */
+    int32_t shard_index, shard_count, tile_pixels;
+} RtRenderDesc;
+
+/* per-frame counters (reference: StatsCounters, core/util.cpp:186-285) */
+typedef struct RtCounters {
+    uint64_t camera_rays;     /* "Camera Rays Traced" scene.cpp:80            */
+    uint64_t closest_rays;    /* every Scene::Intersect  (camera+bounce+MIS)  */
+    uint64_t any_rays;        /* every Scene::IntersectP ("shadow rays", light.cpp:32) */
+    uint64_t nodes_visited;   /* kd nodes / grid voxels touched               */
+    uint64_t leaf_refs;       /* leaf primitive references read               */
+    uint64_t tri_tests;       /* Triangle::Intersect(P) calls, trianglemesh.cpp:217 */
+    uint64_t bad_samples;     /* NaN/negative/inf radiance, scene.cpp:60-74   */
+    uint64_t stack_overflows; /* traversal stack entries spilled beyond LDS   */
+} RtCounters;
+
+typedef struct RtRay { float o[3], d[3], mint, maxt; } RtRay;             /* geometry.h:204-217 */
+typedef struct RtHit { int32_t prim; float t, b1, b2; } RtHit;            /* prim < 0 : miss      */
+typedef struct RtAccelInfo {
+    uint32_t n_nodes, n_leaf_refs, max_depth, n_tris;
+    float bounds[6];
+    double build_seconds;
+} RtAccelInfo;
+
+const char *rt_last_error(void);
+int rt_device_count(int *count);
+
+/* Build accelerator (KdTreeAccel ctor kdtree.cpp:141-190 / GridAccel ctor grid.cpp:122-210),
+ * upload everything.  device < 0 = current device. */
+int rt_scene_create(const RtSceneDesc *desc, int device, RtScene **out);
+int rt_scene_destroy(RtScene *s);
+int rt_scene_set_stream(RtScene *s, void *hip_stream);
+int rt_scene_accel_info(const RtScene *s, RtAccelInfo *info);
+/* copy the flattened kd-tree back (tests / oracle traverse the same tree):
+ * nodes = [n_nodes][2] u32, leaf_refs = [n_leaf_refs] u32 */
+int rt_scene_accel_copy(const RtScene *s, uint32_t *nodes, uint32_t *leaf_refs);
+
+/* Unit entry points (parity of one stage in isolation) */
+/* Camera::GenerateRay for `count` samples starting at camera-sample index `first`
+ * (perspective.cpp:51-82 + the sampler's image/lens positions) */
+int rt_camera_rays(RtScene *s, const RtRenderDesc *rd, uint64_t first, uint32_t count, RtRay *rays_out);
+/* Scene::Intersect (kdtree.cpp:313-403 + trianglemesh.cpp:213-278) */
+int rt_trace_closest(RtScene *s, const RtRay *rays, uint32_t n, RtHit *hits_out);
+/* Scene::IntersectP (kdtree.cpp:404-488 + trianglemesh.cpp:279-314); occluded_out[i] in {0,1} */
+int rt_trace_any(RtScene *s, const RtRay *rays, uint32_t n, uint8_t *occluded_out);
+
+/* Film accumulators, ImageFilm::Pixel (image.cpp:57-65) as planes:
+ * float accum[5][y_pixel_count][x_pixel_count] = sum w*L.r, .g, .b, sum w*alpha, sum w.
+ * rt_film_bind: accumulate into caller-provided DEVICE memory (e.g. a torch tensor that is
+ * later all-reduced by RCCL); pass NULL to let the library allocate. Zeroes nothing. */
+int rt_film_bind(RtScene *s, void *device_accum, int32_t x_pixel_count, int32_t y_pixel_count);
+int rt_film_clear(RtScene *s);
+int rt_film_read(RtScene *s, float *host_accum);          /* 5*W*H floats, synchronises */
+/* ImageFilm::WriteImage minus the file: XYZ round trip, /weightSum, clamps, premultiply
+ * (image.cpp:157-203).  rgb_out[H][W][3], alpha_out[H][W] host buffers. */
+int rt_film_resolve(RtScene *s, int premultiply_alpha, float *rgb_out, float *alpha_out);
+
+/* Scene::Render's sample loop (scene.cpp:42-84) for this shard, asynchronous on the
+ * handle's stream.  rt_sync waits.  Counters accumulate until rt_counters_reset. */
+int rt_render(RtScene *s, const RtRenderDesc *rd);
+int rt_sync(RtScene *s);
+int rt_counters(RtScene *s, RtCounters *out);             /* synchronises */
+int rt_counters_reset(RtScene *s);
+/* elapsed GPU milliseconds of the last rt_render launch sequence (HIP events on the
+ * handle's stream) and of its dominant kernel */
+int rt_last_render_ms(RtScene *s, float *total_ms, float *kernel_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PBRT_HIP_H */

@@ -1,0 +1,360 @@
+"""pbrt-v1 Scene::Render hot path on MI355X -- Python harness over the C ABI.
+
+This package is *plumbing*: ctypes bindings of ``lib/libpbrt_hip.so`` (include/pbrt_hip.h,
+the HIP kernels + C ABI) and ``lib/libpbrt_host.so`` (the C++ host mirror of pbrt-v1's scene
+API), used by tests/, bench.py and __graft_entry__.py.  There is no CPU fallback anywhere:
+if the HIP library is missing or no GPU is visible, calls raise.
+
+The directory name ``pbrt-v1_amd`` is not an importable identifier; load it with
+``__graft_entry__.load_package()`` (importlib, module name ``pbrt_v1_amd``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+HIP_LIB = os.path.join(LIB_DIR, "libpbrt_hip.so")
+HOST_LIB = os.path.join(LIB_DIR, "libpbrt_host.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+               "-Wno-unused-value"]
+HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-msse2", "-mfpmath=sse"]
+
+
+def build(force: bool = False, verbose: bool = False) -> None:
+    """Compile both shared libraries in-tree (hipcc cross-compiles gfx950 without a GPU)."""
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hip_src = [os.path.join(CSRC, "hip", f) for f in ("rt_kernels.hip", "kd_build.cpp")]
+    hip_dep = [os.path.join(CSRC, "hip", f) for f in os.listdir(os.path.join(CSRC, "hip"))] + \
+              [os.path.join(_HERE, "..", "include", "pbrt_hip.h")]
+    host_src = [os.path.join(CSRC, "host", "scene_api.cpp")]
+    host_dep = [os.path.join(CSRC, "host", f) for f in os.listdir(os.path.join(CSRC, "host"))] + \
+               [os.path.join(_HERE, "..", "include", "pbrt_hip.h")]
+
+    def stale(out, deps):
+        return force or not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
+
+    if stale(HIP_LIB, hip_dep):
+        cmd = ["hipcc"] + HIPCC_FLAGS + hip_src + ["-o", HIP_LIB]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    if stale(HOST_LIB, host_dep):
+        cmd = ["g++"] + HOST_FLAGS + host_src + ["-o", HOST_LIB]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+
+
+# --------------------------------------------------------------------------- C ABI structs
+class RtCounters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("camera_rays", "closest_rays", "any_rays", "nodes_visited", "leaf_refs",
+                                          "tri_tests", "bad_samples", "stack_overflows")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class RtAccelInfo(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint32), ("n_leaf_refs", C.c_uint32), ("max_depth", C.c_uint32), ("n_tris", C.c_uint32),
+                ("bounds", C.c_float * 6), ("build_seconds", C.c_double)]
+
+
+RAY_DTYPE = np.dtype([("o", np.float32, 3), ("d", np.float32, 3), ("mint", np.float32), ("maxt", np.float32)])
+HIT_DTYPE = np.dtype([("prim", np.int32), ("t", np.float32), ("b1", np.float32), ("b2", np.float32)])
+
+_hip = None
+_host = None
+
+
+def hip_lib():
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_LIB):
+            raise RuntimeError("libpbrt_hip.so is not built (run __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(HIP_LIB)
+        L.rt_last_error.restype = C.c_char_p
+        for name in ("rt_scene_create", "rt_scene_destroy", "rt_scene_set_stream", "rt_scene_accel_info",
+                     "rt_scene_accel_copy", "rt_camera_rays", "rt_trace_closest", "rt_trace_any", "rt_film_bind",
+                     "rt_film_clear", "rt_film_read", "rt_film_resolve", "rt_render", "rt_sync", "rt_counters",
+                     "rt_counters_reset", "rt_last_render_ms", "rt_device_count"):
+            getattr(L, name).restype = C.c_int
+        L.rt_scene_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.rt_scene_destroy.argtypes = [C.c_void_p]
+        L.rt_scene_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.rt_scene_accel_info.argtypes = [C.c_void_p, C.POINTER(RtAccelInfo)]
+        L.rt_scene_accel_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rt_camera_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
+        L.rt_trace_closest.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.rt_trace_any.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.rt_film_bind.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+        L.rt_film_clear.argtypes = [C.c_void_p]
+        L.rt_film_read.argtypes = [C.c_void_p, C.c_void_p]
+        L.rt_film_resolve.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.rt_render.argtypes = [C.c_void_p, C.c_void_p]
+        L.rt_sync.argtypes = [C.c_void_p]
+        L.rt_counters.argtypes = [C.c_void_p, C.POINTER(RtCounters)]
+        L.rt_counters_reset.argtypes = [C.c_void_p]
+        L.rt_last_render_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.rt_device_count.argtypes = [C.POINTER(C.c_int)]
+        _hip = L
+    return _hip
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB):
+            raise RuntimeError("libpbrt_host.so is not built (run __graft_entry__.build())")
+        L = C.CDLL(HOST_LIB)
+        L.pbrt_host_parse_file.restype = C.c_void_p
+        L.pbrt_host_parse_file.argtypes = [C.c_char_p, C.c_int]
+        L.pbrt_host_parse_string.restype = C.c_void_p
+        L.pbrt_host_parse_string.argtypes = [C.c_char_p, C.c_int]
+        L.pbrt_host_free.argtypes = [C.c_void_p]
+        L.pbrt_host_frame_count.argtypes = [C.c_void_p]
+        L.pbrt_host_frame_valid.argtypes = [C.c_void_p, C.c_int]
+        L.pbrt_host_scene_desc.restype = C.c_void_p
+        L.pbrt_host_scene_desc.argtypes = [C.c_void_p, C.c_int]
+        L.pbrt_host_render_desc.restype = C.c_void_p
+        L.pbrt_host_render_desc.argtypes = [C.c_void_p, C.c_int]
+        L.pbrt_host_premultiply.argtypes = [C.c_void_p, C.c_int]
+        L.pbrt_host_filename.restype = C.c_char_p
+        L.pbrt_host_filename.argtypes = [C.c_void_p, C.c_int]
+        L.pbrt_host_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.pbrt_host_set_seed.argtypes = [C.c_void_p, C.c_uint]
+        L.pbrt_host_film_dims.argtypes = [C.c_void_p, C.POINTER(C.c_int * 8)]
+        L.pbrt_host_scene_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint * 4)]
+        L.pbrt_host_camera.restype = C.POINTER(C.c_float)
+        L.pbrt_host_camera.argtypes = [C.c_void_p]
+        L.pbrt_host_tri_verts.restype = C.POINTER(C.c_float)
+        L.pbrt_host_tri_verts.argtypes = [C.c_void_p]
+        _host = L
+    return _host
+
+
+class RtError(RuntimeError):
+    pass
+
+
+def _chk(rc):
+    if rc != 0:
+        raise RtError("rt error %d: %s" % (rc, hip_lib().rt_last_error().decode()))
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = hip_lib().rt_device_count(C.byref(n))
+    return int(n.value) if rc == 0 else 0
+
+
+class ParsedScene:
+    """A .pbrt description run through the host API mirror (scene_api.cpp): flat scene + frame descriptors."""
+
+    def __init__(self, text: str | None = None, path: str | None = None, quiet: bool = True, frame: int = 0):
+        H = host_lib()
+        if path is not None:
+            self._h = H.pbrt_host_parse_file(path.encode(), int(quiet))
+        else:
+            self._h = H.pbrt_host_parse_string(text.encode(), int(quiet))
+        self.warnings = H.pbrt_host_warnings()
+        self.errors = H.pbrt_host_errors()
+        self.n_frames = H.pbrt_host_frame_count(self._h)
+        if self.n_frames == 0:
+            raise RtError("scene description has no WorldEnd (errors: %d)" % self.errors)
+        self.frame = frame
+        self.valid = bool(H.pbrt_host_frame_valid(self._h, frame))
+        self.scene_desc = H.pbrt_host_scene_desc(self._h, frame)
+        self.render_desc = H.pbrt_host_render_desc(self._h, frame)
+        self.premultiply = bool(H.pbrt_host_premultiply(self._h, frame))
+        dims = (C.c_int * 8)()
+        H.pbrt_host_film_dims(self.render_desc, C.byref(dims))
+        self.width, self.height = dims[0], dims[1]
+        self.sample_extent = (dims[2], dims[3], dims[4], dims[5])
+        self.spp = dims[6]
+        self.integrator = dims[7]
+        cnt = (C.c_uint * 4)()
+        H.pbrt_host_scene_counts(self.scene_desc, C.byref(cnt))
+        self.n_tris, self.n_materials, self.n_lights, self.n_light_tris = (int(c) for c in cnt)
+
+    @property
+    def n_camera_samples(self) -> int:
+        x0, x1, y0, y1 = self.sample_extent
+        return (x1 - x0) * (y1 - y0) * self.spp
+
+    def set_shard(self, index: int, count: int, tile_pixels: int = 64):
+        host_lib().pbrt_host_set_shard(self.render_desc, index, count, tile_pixels)
+
+    def set_seed(self, seed: int):
+        host_lib().pbrt_host_set_seed(self.render_desc, seed)
+
+    def camera_matrices(self):
+        p = host_lib().pbrt_host_camera(self.scene_desc)
+        a = np.ctypeslib.as_array(p, shape=(32,)).copy()
+        return a[:16].reshape(4, 4), a[16:].reshape(4, 4)
+
+    def tri_verts(self):
+        p = host_lib().pbrt_host_tri_verts(self.scene_desc)
+        return np.ctypeslib.as_array(p, shape=(self.n_tris, 3, 3)).copy()
+
+    def close(self):
+        if self._h:
+            host_lib().pbrt_host_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceScene:
+    """rt_scene_create: kd-tree build + upload.  Holds the film unless one is bound externally."""
+
+    def __init__(self, parsed: ParsedScene, device: int = -1):
+        self.parsed = parsed
+        self._s = C.c_void_p()
+        _chk(hip_lib().rt_scene_create(parsed.scene_desc, device, C.byref(self._s)))
+        self._film_bound = False
+
+    def accel_info(self) -> RtAccelInfo:
+        info = RtAccelInfo()
+        _chk(hip_lib().rt_scene_accel_info(self._s, C.byref(info)))
+        return info
+
+    def accel_arrays(self):
+        info = self.accel_info()
+        nodes = np.zeros((info.n_nodes, 2), np.uint32)
+        refs = np.zeros(max(info.n_leaf_refs, 1), np.uint32)
+        _chk(hip_lib().rt_scene_accel_copy(self._s, nodes.ctypes.data, refs.ctypes.data))
+        return nodes, refs[:info.n_leaf_refs]
+
+    def set_stream(self, stream_ptr: int):
+        _chk(hip_lib().rt_scene_set_stream(self._s, C.c_void_p(stream_ptr)))
+
+    def bind_film(self, device_ptr: int | None = None):
+        _chk(hip_lib().rt_film_bind(self._s, C.c_void_p(device_ptr) if device_ptr else None,
+                                     self.parsed.width, self.parsed.height))
+        self._film_bound = True
+
+    def clear_film(self):
+        _chk(hip_lib().rt_film_clear(self._s))
+
+    def render(self, sync: bool = True):
+        if not self._film_bound:
+            self.bind_film()
+        _chk(hip_lib().rt_render(self._s, self.parsed.render_desc))
+        if sync:
+            self.sync()
+
+    def sync(self):
+        _chk(hip_lib().rt_sync(self._s))
+
+    def film_accum(self) -> np.ndarray:
+        out = np.zeros((5, self.parsed.height, self.parsed.width), np.float32)
+        _chk(hip_lib().rt_film_read(self._s, out.ctypes.data))
+        return out
+
+    def film(self, premultiply: bool | None = None):
+        rgb = np.zeros((self.parsed.height, self.parsed.width, 3), np.float32)
+        alpha = np.zeros((self.parsed.height, self.parsed.width), np.float32)
+        pm = self.parsed.premultiply if premultiply is None else premultiply
+        _chk(hip_lib().rt_film_resolve(self._s, int(pm), rgb.ctypes.data, alpha.ctypes.data))
+        return rgb, alpha
+
+    def counters(self) -> dict:
+        c = RtCounters()
+        _chk(hip_lib().rt_counters(self._s, C.byref(c)))
+        return c.as_dict()
+
+    def reset_counters(self):
+        _chk(hip_lib().rt_counters_reset(self._s))
+
+    def last_ms(self):
+        a, b = C.c_float(0), C.c_float(0)
+        _chk(hip_lib().rt_last_render_ms(self._s, C.byref(a), C.byref(b)))
+        return float(a.value), float(b.value)
+
+    def camera_rays(self, first: int, count: int) -> np.ndarray:
+        rays = np.zeros(count, RAY_DTYPE)
+        _chk(hip_lib().rt_camera_rays(self._s, self.parsed.render_desc, first, count, rays.ctypes.data))
+        return rays
+
+    def trace_closest(self, rays: np.ndarray) -> np.ndarray:
+        rays = np.ascontiguousarray(rays, RAY_DTYPE)
+        hits = np.zeros(len(rays), HIT_DTYPE)
+        _chk(hip_lib().rt_trace_closest(self._s, rays.ctypes.data, len(rays), hits.ctypes.data))
+        return hits
+
+    def trace_any(self, rays: np.ndarray) -> np.ndarray:
+        rays = np.ascontiguousarray(rays, RAY_DTYPE)
+        occ = np.zeros(len(rays), np.uint8)
+        _chk(hip_lib().rt_trace_any(self._s, rays.ctypes.data, len(rays), occ.ctypes.data))
+        return occ
+
+    def close(self):
+        if self._s:
+            hip_lib().rt_scene_destroy(self._s)
+            self._s = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def render_text(scene_text: str, device: int = -1):
+    """Convenience: parse -> create -> render -> (rgb, alpha, counters)."""
+    ps = ParsedScene(text=scene_text)
+    ds = DeviceScene(ps, device)
+    ds.render()
+    rgb, alpha = ds.film()
+    cnt = ds.counters()
+    ms = ds.last_ms()[0]
+    ds.close()
+    return rgb, alpha, cnt, ms
+
+
+# --------------------------------------------------------------------------- reference film dumps
+def load_ref_film(path: str):
+    """Read a float film dumped by oracle/ref/ref_driver.cpp (WriteRGBAImage tap)."""
+    b = open(path, "rb").read()
+    if b[:8] != b"PBRTFILM":
+        raise ValueError("not a PBRTFILM dump: " + path)
+    h = np.frombuffer(b[8:32], np.int32)
+    n = int(h[0]) * int(h[1])
+    rgb = np.frombuffer(b[32:32 + 12 * n], np.float32).reshape(h[1], h[0], 3).copy()
+    alpha = np.frombuffer(b[32 + 12 * n:32 + 16 * n], np.float32).reshape(h[1], h[0]).copy()
+    return rgb, alpha, h
+
+
+REF_DIR = os.path.join(_HERE, "..", "oracle", "_ref")
+
+
+def run_reference(scene_text: str, keyed: bool = True, workdir: str | None = None, timeout: float = 3600):
+    """Run the compiled reference (oracle/_ref) on a scene; returns (rgb, alpha, stats dict).
+    TEST/BENCH infrastructure only -- never on the product path."""
+    import json
+    import tempfile
+    exe = os.path.join(REF_DIR, "pbrt_ref_keyed" if keyed else "pbrt_ref")
+    if not os.path.exists(exe):
+        raise FileNotFoundError(exe)
+    d = workdir or tempfile.mkdtemp(prefix="pbrtref_")
+    sp = os.path.join(d, "scene.pbrt")
+    fp = os.path.join(d, "film.bin")
+    with open(sp, "w") as f:
+        f.write(scene_text)
+    env = dict(os.environ, PBRT_SEARCHPATH=os.path.join(REF_DIR, "bin"))
+    r = subprocess.run([exe, "--quiet", "--out", fp, sp], env=env, capture_output=True, text=True, timeout=timeout, cwd=d)
+    if r.returncode != 0:
+        raise RuntimeError("reference run failed: %s\n%s" % (r.stdout, r.stderr[-2000:]))
+    stats = json.loads(r.stdout.strip().splitlines()[-1])
+    rgb, alpha, _ = load_ref_film(fp)
+    return rgb, alpha, stats

@@ -1,0 +1,74 @@
+// rt_device.h -- device-visible scene / frame descriptors (HBM layout; see DESIGN.md "Data layout")
+#pragma once
+#include "rt_math.h"
+#include "../../../include/pbrt_hip.h"
+
+namespace rt {
+
+// One triangle = three 16-byte vectors (48 B, one 128-B line holds 2.67 of them):
+//   q0 = p1.x p1.y p1.z p2.x | q1 = p2.y p2.z p3.x p3.y | q2 = p3.z, bits(material | flags<<16), bits(light), 0
+struct DevTri { float4 q0, q1, q2; };
+
+struct DevMaterial {
+    int type;
+    float r[3];      // Kd / Kr
+    float t[3];      // Kt
+    float on_a, on_b;  // Oren-Nayar A,B (reflection.h:268-277); on_b < 0 => Lambertian
+    float ior;
+    int has_r, has_t;  // glass.cpp:56-61: a lobe exists only if its colour is not black
+};
+
+struct DevLight {
+    int type;
+    float color[3];
+    float pos[3];
+    int n_samples;
+    unsigned first_tri, n_tris;
+    int reverse_orientation, flip_normal;
+    float area;        // ShapeSet::area / Triangle::Area() (shape.h:123-131, trianglemesh.cpp:329-335)
+};
+
+#define RT_MAX_DIM_REQ 40
+struct DimReq { unsigned f_base, u_base; unsigned short n; unsigned short dims; };
+
+struct DevScene {
+    const DevTri *tris;
+    const uint2 *nodes;
+    const unsigned *leaf_refs;
+    const DevMaterial *materials;
+    const DevLight *lights;
+    const float *light_tris;   // [n][12]: 9 vertex floats, per-triangle area, area CDF, pad
+    unsigned n_tris, n_lights;
+    float bounds[6];
+    RtCamera cam;
+    RtVolume vol;
+};
+
+struct DevFrame {
+    int integrator, max_depth, strategy, volume_integrator;
+    float step_size;
+    int sampler, xs, ys, jitter, spp;
+    unsigned seed;
+    int x_pixel_start, y_pixel_start, x_pixel_count, y_pixel_count;
+    int x_start, x_end, y_start, y_end;
+    float fxw, fyw, inv_fxw, inv_fyw;
+    const float *filter_table;   // 256 floats in HBM (L1/L2 resident)
+    float *accum;                // 5 planes
+    int shard_index, shard_count, tile_pixels;
+    unsigned long long total_work;     // samples this shard renders
+    unsigned long long total_pixels;   // pixels in the sample extent
+    // sampler dimension table (Sample::oneD/twoD, sampling.cpp:41-70)
+    int n1d, n2d;
+    unsigned lhs_total;          // draws consumed by LatinHypercube per sample
+    unsigned pixgen_draws;       // draws consumed when a new pixel's strata are generated
+    DimReq one_d[RT_MAX_DIM_REQ];
+    DimReq two_d[RT_MAX_DIM_REQ];
+    // scratch
+    unsigned long long *work_counter;
+    unsigned long long *counters;   // RtCounters as 8 u64
+    uint2 *spill;                   // traversal-stack overflow  [entry][thread]
+    float *frames;                  // specular recursion frames [frame][field][thread]
+    unsigned n_threads;
+};
+
+}  // namespace rt

@@ -1,0 +1,502 @@
+// rt_integrate.h -- the per-lane path state machine of the persistent wavefront renderer.
+//
+// pbrt-v1 evaluates a camera sample with recursive C++ calls (Scene::Render scene.cpp:42-84 ->
+// SurfaceIntegrator::Li -> EstimateDirect -> Scene::Intersect...).  Here each lane of a 64-wide wavefront
+// owns one camera sample at a time and runs it as an explicit state machine whose ONLY blocking
+// operation is "trace the ray I just set up"; all lanes share one traversal loop (rt_kernels.hip), and a
+// lane whose sample finishes immediately fetches the next one (persistent threads + ray regeneration).
+// Whitted / DirectLighting recursion (whitted.cpp:82-137, directlighting.cpp:127-183) is flattened to
+// explicit frames that keep the reference's evaluation order, so partial sums are formed in the same
+// order as the recursion forms them.
+//
+// RNG: draw #c of camera sample #n is pcg(c + pcg(n + seed*K)) (rt_math.h); the order in which the
+// reference consumes draws per sample is reproduced exactly.
+#pragma once
+#include "rt_shade.h"
+
+namespace rt {
+
+enum Stage {
+    ST_FETCH = 0, ST_VERTEX, ST_DIRECT_NEXT, ST_SHADOW_DONE, ST_MIS_DONE, ST_ED_DONE,
+    ST_BOUNCE, ST_SPECULAR, ST_SPEC_TRANS, ST_RETURN, ST_FINISH, ST_EXIT
+};
+
+struct Rng {
+    uint32_t base, ctr;
+    RT_DEV float next_float() { return rng_f32(base, ctr++); }
+    RT_DEV uint32_t next_u32() { return rng_u32(base, ctr++); }
+};
+
+#define RT_FRAME_WORDS 22
+
+struct Lane {
+    // --- the camera sample being evaluated
+    uint32_t sample_index;
+    float image_x, image_y;
+    uint32_t dim_base;      // counter at which this sample's LatinHypercube block starts
+    Rng rng;
+    // --- radiance bookkeeping
+    V3 L;                   // path: L of PathIntegrator::Li; whitted/direct: L of the current recursion frame
+    V3 thr;                 // path throughput
+    float alpha;
+    int depth;              // pathLength (path) or rayDepth (whitted/direct)
+    int fsp;                // number of suspended recursion frames
+    bool specular;
+    // --- current surface vertex
+    Vertex v;
+    // --- direct-lighting loop state
+    int li, lj;             // light / sample-of-light cursor
+    int cur_light;          // light of the EstimateDirect in flight
+    V3 Ld;                  // EstimateDirect's Ld            (transport.cpp:127)
+    V3 Ld_light;            // UniformSampleAllLights' per-light Ld (transport.cpp:42)
+    V3 L_all;               // UniformSampleAllLights' L     (transport.cpp:36)
+    V3 pend;                // contribution added if the ray in flight confirms it
+    float bs1, bs2, bcs;    // BSDF-half sample values of the EstimateDirect in flight
+    // --- control
+    int stage;
+    bool has_ray;
+    Trav tv;
+};
+
+// ---- sampler dimensions: Sample::oneD / twoD produced by LatinHypercube (sampling.cpp:98-113) -------------
+// value j, dimension d of request r.  n == 1 is the common case (a single draw, the permutation of one
+// element is the identity); n > 1 replays the per-dimension swap chain backwards to find which stratum
+// ends at position j, using the fact that every draw is addressable by its counter.
+RT_DEV float lhs_value(const Lane &ln, const DimReq &r, int j, int d) {
+    const uint32_t fb = ln.dim_base + r.f_base, ub = ln.dim_base + r.u_base;
+    if (r.n == 1) return (0 + rng_f32(ln.rng.base, fb + d)) * 1.f;
+    int pos = j;
+    const int n = r.n;
+    for (int k = n - 1; k >= 0; --k) {
+        int other = int(rng_u32(ln.rng.base, ub + d * n + k) % uint32_t(n));
+        if (pos == k) pos = other; else if (pos == other) pos = k;
+    }
+    float delta = 1.f / n;
+    return (pos + rng_f32(ln.rng.base, fb + pos * r.dims + d)) * delta;
+}
+
+// ---- Scene::Render's radiance sanity check (scene.cpp:60-74) + ImageFilm::AddSample (image.cpp:103-142)
+RT_DEV void film_add(const DevFrame &fr, const Lane &ln, V3 Ls, float alpha, unsigned &bad) {
+    const float y = lum_y(Ls);
+    if (Ls.x != Ls.x || Ls.y != Ls.y || Ls.z != Ls.z) { Ls = mk3(0.f); ++bad; }
+    else if (y < -1e-5) { Ls = mk3(0.f); ++bad; }
+    else if (isinf(y)) { Ls = mk3(0.f); ++bad; }
+    const float dImageX = ln.image_x - 0.5f, dImageY = ln.image_y - 0.5f;
+    int x0 = int(ceilf(dImageX - fr.fxw)), x1 = int(floorf(dImageX + fr.fxw));
+    int y0 = int(ceilf(dImageY - fr.fyw)), y1 = int(floorf(dImageY + fr.fyw));
+    x0 = max(x0, fr.x_pixel_start); x1 = min(x1, fr.x_pixel_start + fr.x_pixel_count - 1);
+    y0 = max(y0, fr.y_pixel_start); y1 = min(y1, fr.y_pixel_start + fr.y_pixel_count - 1);
+    if ((x1 - x0) < 0 || (y1 - y0) < 0) return;
+    const size_t plane = size_t(fr.x_pixel_count) * fr.y_pixel_count;
+    for (int yy = y0; yy <= y1; ++yy) {
+        const float fy = fabsf((yy - dImageY) * fr.inv_fyw * 16);
+        const int ify = min(int(floorf(fy)), 15);
+        for (int xx = x0; xx <= x1; ++xx) {
+            const float fx = fabsf((xx - dImageX) * fr.inv_fxw * 16);
+            const int ifx = min(int(floorf(fx)), 15);
+            const float wt = fr.filter_table[ify * 16 + ifx];
+            const size_t px = size_t(yy - fr.y_pixel_start) * fr.x_pixel_count + (xx - fr.x_pixel_start);
+            unsafeAtomicAdd(fr.accum + px, wt * Ls.x);
+            unsafeAtomicAdd(fr.accum + plane + px, wt * Ls.y);
+            unsafeAtomicAdd(fr.accum + 2 * plane + px, wt * Ls.z);
+            unsafeAtomicAdd(fr.accum + 3 * plane + px, alpha * wt);
+            unsafeAtomicAdd(fr.accum + 4 * plane + px, wt);
+        }
+    }
+}
+
+// ---- camera sample -> camera ray -----------------------------------------------------------------------
+// StratifiedSampler (samplers/stratified.cpp:51-131, sampling.cpp:72-97): image position of sample s of
+// pixel (px,py); lens position only when the camera has a lens (needs the Shuffle replay).
+RT_DEV void stratified_camera_sample(const DevFrame &fr, uint32_t pixel_index, int s, int px, int py,
+                                     uint32_t pix_base, float &ix, float &iy, float &lu, float &lv, bool need_lens) {
+    const int n = fr.spp;
+    const int sx = s % fr.xs, sy = s / fr.xs;
+    const float dx = 1.f / fr.xs, dy = 1.f / fr.ys;
+    float jx = 0.5f, jy = 0.5f;
+    if (fr.jitter) { jx = rng_f32(pix_base, 2 * s); jy = rng_f32(pix_base, 2 * s + 1); }
+    ix = (sx + jx) * dx; iy = (sy + jy) * dy;
+    ix += px; iy += py;
+    lu = lv = 0.5f;
+    if (need_lens) {
+        // Shuffle(lensSamples, n, 2): draws start after the strata draws (5n when jittered, else 0)
+        const uint32_t ub = fr.jitter ? 5u * n : 0u;
+        int pos = s;
+        for (int k = n - 1; k >= 0; --k) {
+            int other = int(rng_u32(pix_base, ub + k) % uint32_t(n));
+            if (pos == k) pos = other; else if (pos == other) pos = k;
+        }
+        const int lx = pos % fr.xs, ly = pos / fr.xs;
+        float kx = 0.5f, ky = 0.5f;
+        if (fr.jitter) { kx = rng_f32(pix_base, 2 * n + 2 * pos); ky = rng_f32(pix_base, 2 * n + 2 * pos + 1); }
+        lu = (lx + kx) * dx; lv = (ly + ky) * dy;
+    }
+    (void)pixel_index;
+}
+
+// PerspectiveCamera::GenerateRay cameras/perspective.cpp:51-82
+RT_DEV Ray camera_ray(const RtCamera &cam, float ix, float iy, float lensU, float lensV) {
+    V3 Pcamera = xform_point(cam.raster_to_camera, mk3(ix, iy, 0.f));
+    Ray r;
+    r.o = Pcamera;
+    r.d = Pcamera;
+    if (cam.lens_radius > 0.f) {
+        float lu, lv; concentric_disk(lensU, lensV, lu, lv);
+        lu *= cam.lens_radius; lv *= cam.lens_radius;
+        float ft = (cam.focal_distance - cam.hither) / r.d.z;
+        V3 Pfocus = r.o + r.d * ft;
+        r.o.x += lu * (cam.focal_distance - cam.hither) / cam.focal_distance;
+        r.o.y += lv * (cam.focal_distance - cam.hither) / cam.focal_distance;
+        r.d = Pfocus - r.o;
+    }
+    r.d = normalize3(r.d);
+    r.mint = 0.f;
+    r.maxt = (cam.yon - cam.hither) / r.d.z;
+    r.o = xform_point(cam.camera_to_world, r.o);
+    r.d = xform_vector(cam.camera_to_world, r.d);
+    return r;
+}
+
+// map a work index of this shard to (pixel, sample-in-pixel); false if it falls off the image
+RT_DEV bool work_to_sample(const DevFrame &fr, unsigned long long w, unsigned long long &pixel, int &s) {
+    const unsigned long long per_tile = (unsigned long long)fr.tile_pixels * fr.spp;
+    const unsigned long long lt = w / per_tile, rem = w % per_tile;
+    const unsigned long long tile = lt * fr.shard_count + fr.shard_index;
+    pixel = tile * fr.tile_pixels + rem / fr.spp;
+    s = int(rem % fr.spp);
+    return pixel < fr.total_pixels;
+}
+
+RT_DEV void setup_sample(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigned long long pixel, int s, Ray &ray) {
+    const int w = fr.x_end - fr.x_start;
+    const int px = fr.x_start + int(pixel % w), py = fr.y_start + int(pixel / w);
+    const uint32_t n0 = uint32_t(pixel * fr.spp);
+    ln.sample_index = n0 + uint32_t(s);
+    ln.rng.base = rng_base(ln.sample_index, fr.seed);
+    // the first pixel's strata are drawn by the sampler's constructor, before any sample key exists
+    const uint32_t pix_base = (pixel == 0) ? rng_base(0xFFFFFFFFu, fr.seed) : rng_base(n0, fr.seed);
+    ln.dim_base = (s == 0 && pixel != 0) ? fr.pixgen_draws : 0u;
+    ln.rng.ctr = ln.dim_base + fr.lhs_total;
+    float lu, lv;
+    stratified_camera_sample(fr, uint32_t(pixel), s, px, py, pix_base, ln.image_x, ln.image_y, lu, lv,
+                             sc.cam.lens_radius > 0.f);
+    ray = camera_ray(sc.cam, ln.image_x, ln.image_y, lu, lv);
+}
+
+// ---- recursion frames (whitted / directlighting) ---------------------------------------------------------
+RT_DEV float *frame_ptr(const DevFrame &fr, int frame, unsigned gtid) {
+    return fr.frames + (size_t(frame) * RT_FRAME_WORDS) * fr.n_threads + gtid;
+}
+RT_DEV void frame_push(const DevFrame &fr, Lane &ln, unsigned gtid, V3 f, float absdot, int after) {
+    float *q = frame_ptr(fr, ln.fsp, gtid); const size_t st = fr.n_threads;
+    q[0 * st] = ln.L.x; q[1 * st] = ln.L.y; q[2 * st] = ln.L.z;
+    q[3 * st] = f.x; q[4 * st] = f.y; q[5 * st] = f.z; q[6 * st] = absdot;
+    q[7 * st] = __int_as_float(after); q[8 * st] = __int_as_float(ln.depth);
+    q[9 * st] = ln.v.p.x; q[10 * st] = ln.v.p.y; q[11 * st] = ln.v.p.z;
+    q[12 * st] = ln.v.nn.x; q[13 * st] = ln.v.nn.y; q[14 * st] = ln.v.nn.z;
+    q[15 * st] = ln.v.sn.x; q[16 * st] = ln.v.sn.y; q[17 * st] = ln.v.sn.z;
+    q[18 * st] = ln.v.wo.x; q[19 * st] = ln.v.wo.y; q[20 * st] = ln.v.wo.z;
+    q[21 * st] = __int_as_float(ln.v.mat);
+    ++ln.fsp;
+}
+RT_DEV int frame_pop(const DevFrame &fr, Lane &ln, unsigned gtid, V3 child) {
+    --ln.fsp;
+    const float *q = frame_ptr(fr, ln.fsp, gtid); const size_t st = fr.n_threads;
+    V3 Lp = mk3(q[0 * st], q[1 * st], q[2 * st]);
+    V3 f = mk3(q[3 * st], q[4 * st], q[5 * st]);
+    float absdot = q[6 * st];
+    ln.L = Lp + (child * f) * absdot;                       // L += scene->Li(rd) * f * AbsDot(wi, n)
+    int after = __float_as_int(q[7 * st]);
+    ln.depth = __float_as_int(q[8 * st]);
+    ln.v.p = mk3(q[9 * st], q[10 * st], q[11 * st]);
+    ln.v.nn = mk3(q[12 * st], q[13 * st], q[14 * st]);
+    ln.v.sn = mk3(q[15 * st], q[16 * st], q[17 * st]);
+    ln.v.tn = cross3(ln.v.nn, ln.v.sn);
+    ln.v.wo = mk3(q[18 * st], q[19 * st], q[20 * st]);
+    ln.v.mat = __float_as_int(q[21 * st]);
+    return after;
+}
+
+RT_DEV void launch_ray(Lane &ln, const DevScene &sc, V3 o, V3 d, float mint, float maxt, bool any, int next_stage) {
+    Ray r; r.o = o; r.d = d; r.mint = mint; r.maxt = maxt;
+    trav_begin(ln.tv, sc, r, any);
+    ln.has_ray = true;
+    ln.stage = next_stage;
+}
+
+// ---- EstimateDirect (core/transport.cpp:123-194), split at its two ray casts ------------------------------
+// BSDF-sampling half; returns with either a MIS ray in flight (ST_MIS_DONE) or ST_ED_DONE.
+RT_DEV void estimate_direct_bsdf(const DevScene &sc, Lane &ln) {
+    const DevLight &Lt = sc.lights[ln.cur_light];
+    ln.stage = ST_ED_DONE;
+    if (Lt.type == RT_LIGHT_POINT) return;                                      // IsDeltaLight()
+    const DevMaterial &m = sc.materials[ln.v.mat];
+    V3 wi; float bsdfPdf; int sampled;
+    V3 f = bsdf_sample_f(m, ln.v, ln.v.wo, wi, ln.bs1, ln.bs2, ln.bcs, bsdfPdf, BX_ALL & ~BX_SPECULAR, sampled);
+    if (!is_black(f) && bsdfPdf > 0.f) {
+        float lightPdf = area_light_pdf(sc, Lt, ln.v.p, wi);
+        if (lightPdf > 0.f) {
+            float fw = 1 * bsdfPdf, gw = 1 * lightPdf;                            // PowerHeuristic mc.h:55-59
+            float weight = (fw * fw) / (fw * fw + gw * gw);
+            // Li is Lemit iff the closest hit is this emitter seen from its front side; decided after the trace
+            ln.pend = div_s(((f * mat_color(Lt.color)) * absdot3(wi, ln.v.nn)) * weight, bsdfPdf);
+            launch_ray(ln, sc, ln.v.p, wi, RT_RAY_EPSILON, RT_INF, false, ST_MIS_DONE);
+        }
+    }
+}
+
+// light-sampling half
+RT_DEV void estimate_direct_begin(const DevScene &sc, Lane &ln, int light, float ls1, float ls2) {
+    ln.cur_light = light;
+    ln.Ld = mk3(0.f);
+    const DevLight &Lt = sc.lights[light];
+    const DevMaterial &m = sc.materials[ln.v.mat];
+    V3 wi, Li, pseg; float lightPdf;
+    if (Lt.type == RT_LIGHT_POINT) {                                            // point.cpp:55-66
+        V3 lp = mat_color(Lt.pos);
+        wi = normalize3(lp - ln.v.p);
+        lightPdf = 1.f;
+        V3 dd = lp - ln.v.p;
+        Li = div_s(mat_color(Lt.color), dd.x * dd.x + dd.y * dd.y + dd.z * dd.z);
+        pseg = lp;
+    } else {                                                                    // area.cpp:58-68
+        V3 ns;
+        V3 ps = area_sample_point(sc, Lt, ls1, ls2, ln.rng, ns);
+        wi = normalize3(ps - ln.v.p);
+        lightPdf = area_light_pdf(sc, Lt, ln.v.p, wi);
+        Li = area_L(Lt, ns, -wi);
+        pseg = ps;
+    }
+    if (lightPdf > 0.f && !is_black(Li)) {
+        V3 f = bsdf_f(m, ln.v, ln.v.wo, wi);
+        if (!is_black(f)) {
+            if (Lt.type == RT_LIGHT_POINT) ln.pend = div_s((f * Li) * absdot3(wi, ln.v.nn), lightPdf);
+            else {
+                float bsdfPdf = bsdf_pdf(m, ln.v, ln.v.wo, wi);
+                float fw = 1 * lightPdf, gw = 1 * bsdfPdf;
+                float weight = (fw * fw) / (fw * fw + gw * gw);
+                ln.pend = div_s(((f * Li) * absdot3(wi, ln.v.nn)) * weight, lightPdf);
+            }
+            // VisibilityTester::SetSegment light.h:78-80
+            launch_ray(ln, sc, ln.v.p, pseg - ln.v.p, RT_RAY_EPSILON, 1.f - RT_RAY_EPSILON, true, ST_SHADOW_DONE);
+            return;
+        }
+    }
+    estimate_direct_bsdf(sc, ln);
+}
+
+// One stage transition.  Returns when the lane has a ray in flight or has changed stage.
+template <bool COUNT>
+RT_DEV void advance(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigned gtid,
+                    unsigned long long *wave_work_base, unsigned *c_cam, unsigned *c_closest, unsigned *c_any,
+                    unsigned *c_bad) {
+    switch (ln.stage) {
+    case ST_VERTEX: {
+        if (COUNT) ++*c_closest;
+        const bool hit = ln.tv.hit_prim >= 0;
+        if (fr.integrator == RT_INTEGRATOR_PATH) {
+            if (!hit) {                                                         // path.cpp:68-83: point/area lights have Le(ray)=0
+                if (ln.depth == 0) ln.alpha = (ln.L.x != 0.f || ln.L.y != 0.f || ln.L.z != 0.f) ? 1.f : 0.f;
+                ln.stage = ST_FINISH; return;
+            }
+            make_vertex(sc, ln.tv, ln.v);
+            if (ln.depth == 0) ln.alpha = 1.f;
+            if ((ln.depth == 0 || ln.specular) && ln.v.light >= 0)              // path.cpp:91-92
+                ln.L = ln.L + ln.thr * area_L(sc.lights[ln.v.light], ln.v.nn, ln.v.wo);
+        } else {
+            if (!hit) {                                                         // whitted.cpp:52-59
+                ln.L = mk3(0.f);
+                if (ln.depth == 0) ln.alpha = 0.f;
+                ln.stage = ST_RETURN; return;
+            }
+            make_vertex(sc, ln.tv, ln.v);
+            if (ln.depth == 0) ln.alpha = 1.f;
+            ln.L = mk3(0.f);
+            if (ln.v.light >= 0) ln.L = ln.L + area_L(sc.lights[ln.v.light], ln.v.nn, ln.v.wo);
+        }
+        ln.li = 0; ln.lj = 0; ln.L_all = mk3(0.f); ln.Ld_light = mk3(0.f);
+        ln.stage = ST_DIRECT_NEXT;
+        return;
+    }
+    case ST_DIRECT_NEXT: {
+        const int nLights = int(sc.n_lights);
+        if (fr.integrator == RT_INTEGRATOR_PATH || (fr.integrator == RT_INTEGRATOR_DIRECT && fr.strategy == RT_STRATEGY_ONE)) {
+            // UniformSampleOneLight transport.cpp:51-70
+            if (nLights == 0 || ln.li > 0) { ln.stage = (fr.integrator == RT_INTEGRATOR_PATH) ? ST_BOUNCE : ST_SPECULAR; return; }
+            ln.li = 1;
+            const int k = (fr.integrator == RT_INTEGRATOR_PATH) ? ln.depth : 0;
+            const bool from_sampler = (fr.integrator == RT_INTEGRATOR_DIRECT) || k < 3;   // SAMPLE_DEPTH path.cpp:40
+            float un, ls1, ls2;
+            if (from_sampler) {
+                const int i1 = (fr.integrator == RT_INTEGRATOR_PATH) ? 3 * k : 0;
+                const int i2 = (fr.integrator == RT_INTEGRATOR_PATH) ? 3 * k : 0;
+                un = lhs_value(ln, fr.one_d[i1], 0, 0);
+                ls1 = lhs_value(ln, fr.two_d[i2], 0, 0); ls2 = lhs_value(ln, fr.two_d[i2], 0, 1);
+                ln.bs1 = lhs_value(ln, fr.two_d[i2 + 1], 0, 0); ln.bs2 = lhs_value(ln, fr.two_d[i2 + 1], 0, 1);
+                ln.bcs = lhs_value(ln, fr.one_d[i1 + 1], 0, 0);
+            } else {
+                un = ln.rng.next_float();
+                ls1 = ln.rng.next_float(); ls2 = ln.rng.next_float();           // transport.cpp:141-145
+                ln.bs1 = ln.rng.next_float(); ln.bs2 = ln.rng.next_float(); ln.bcs = ln.rng.next_float();
+            }
+            int lightNum = min(int(floorf(un * nLights)), nLights - 1);
+            estimate_direct_begin(sc, ln, lightNum, ls1, ls2);
+            return;
+        }
+        if (fr.integrator == RT_INTEGRATOR_DIRECT) {
+            // UniformSampleAllLights transport.cpp:31-50 with the dimensions of directlighting.cpp:46-53
+            if (ln.li >= nLights) { ln.L = ln.L + ln.L_all; ln.stage = ST_SPECULAR; return; }
+            const DimReq &rl = fr.two_d[2 * ln.li], &rb = fr.two_d[2 * ln.li + 1], &rc = fr.one_d[ln.li];
+            if (ln.lj == 0) ln.Ld_light = mk3(0.f);
+            const float ls1 = lhs_value(ln, rl, ln.lj, 0), ls2 = lhs_value(ln, rl, ln.lj, 1);
+            ln.bs1 = lhs_value(ln, rb, ln.lj, 0); ln.bs2 = lhs_value(ln, rb, ln.lj, 1);
+            ln.bcs = lhs_value(ln, rc, ln.lj, 0);
+            estimate_direct_begin(sc, ln, ln.li, ls1, ls2);
+            return;
+        }
+        // Whitted: one sample per light, unweighted (whitted.cpp:73-81)
+        if (ln.li >= nLights) { ln.stage = ST_SPECULAR; return; }
+        {
+            const DevLight &Lt = sc.lights[ln.li];
+            const DevMaterial &m = sc.materials[ln.v.mat];
+            const int cur = ln.li++;
+            V3 wi, Li, pseg;
+            if (Lt.type == RT_LIGHT_POINT) {                                    // point.cpp:55-60
+                V3 lp = mat_color(Lt.pos);
+                wi = normalize3(lp - ln.v.p);
+                V3 dd = lp - ln.v.p;
+                Li = div_s(mat_color(Lt.color), dd.x * dd.x + dd.y * dd.y + dd.z * dd.z);
+                pseg = lp;
+            } else {                                                            // area.cpp:96-105
+                float u2 = ln.rng.next_float();     // g++ evaluates the two RandomFloat() arguments right to left
+                float u1 = ln.rng.next_float();
+                V3 ns; V3 ps = area_sample_point(sc, Lt, u1, u2, ln.rng, ns);
+                wi = normalize3(ps - ln.v.p);
+                float pdf = area_light_pdf(sc, Lt, ln.v.p, wi);
+                Li = (pdf == 0.f) ? mk3(0.f) : div_s(area_L(Lt, ns, -wi), pdf);
+                pseg = ps;
+            }
+            (void)cur;
+            if (is_black(Li)) return;
+            V3 f = bsdf_f(m, ln.v, ln.v.wo, wi);
+            if (is_black(f)) return;
+            ln.pend = (f * Li) * absdot3(wi, ln.v.nn);
+            launch_ray(ln, sc, ln.v.p, pseg - ln.v.p, RT_RAY_EPSILON, 1.f - RT_RAY_EPSILON, true, ST_SHADOW_DONE);
+        }
+        return;
+    }
+    case ST_SHADOW_DONE: {
+        if (COUNT) ++*c_any;
+        const bool occluded = ln.tv.hit_prim >= 0;
+        if (fr.integrator == RT_INTEGRATOR_WHITTED) {
+            if (!occluded) ln.L = ln.L + ln.pend;
+            ln.stage = ST_DIRECT_NEXT;
+            return;
+        }
+        if (!occluded) ln.Ld = ln.Ld + ln.pend;
+        estimate_direct_bsdf(sc, ln);
+        return;
+    }
+    case ST_MIS_DONE: {
+        if (COUNT) ++*c_closest;
+        if (ln.tv.hit_prim >= 0) {                                              // transport.cpp:180-184
+            V3 p1, p2, p3; unsigned bits; int light;
+            tri_verts(sc.tris, unsigned(ln.tv.hit_prim), p1, p2, p3, bits, light);
+            if (light == ln.cur_light) {
+                V3 nh, dpdu; tri_frame(p1, p2, p3, (bits >> 16) & 1u, nh, dpdu);
+                if (dot3(nh, -ln.tv.d) > 0) ln.Ld = ln.Ld + ln.pend;           // isect.Le(-wi) non-black
+            }
+        }
+        ln.stage = ST_ED_DONE;
+        return;
+    }
+    case ST_ED_DONE: {
+        const int nLights = int(sc.n_lights);
+        if (fr.integrator == RT_INTEGRATOR_PATH) {
+            ln.L = ln.L + ln.thr * (ln.Ld * float(nLights));                    // path.cpp:99-110
+            ln.stage = ST_BOUNCE;
+        } else if (fr.strategy == RT_STRATEGY_ONE) {
+            ln.L = ln.L + ln.Ld * float(nLights);
+            ln.stage = ST_SPECULAR;
+        } else {
+            ln.Ld_light = ln.Ld_light + ln.Ld;
+            const int ns = fr.two_d[2 * ln.li].n;
+            if (++ln.lj >= ns) {
+                ln.L_all = ln.L_all + ln.Ld_light * (1.f / float(ns));           // L += Ld / nSamples
+                ln.lj = 0; ++ln.li;
+            }
+            ln.stage = ST_DIRECT_NEXT;
+        }
+        return;
+    }
+    case ST_BOUNCE: {                                                           // path.cpp:111-143
+        const DevMaterial &m = sc.materials[ln.v.mat];
+        const int k = ln.depth;
+        float bs1, bs2, bcs;
+        if (k < 3) {
+            bs1 = lhs_value(ln, fr.two_d[3 * k + 2], 0, 0); bs2 = lhs_value(ln, fr.two_d[3 * k + 2], 0, 1);
+            bcs = lhs_value(ln, fr.one_d[3 * k + 2], 0, 0);
+        } else { bs1 = ln.rng.next_float(); bs2 = ln.rng.next_float(); bcs = ln.rng.next_float(); }
+        V3 wi; float pdf; int flags;
+        V3 f = bsdf_sample_f(m, ln.v, ln.v.wo, wi, bs1, bs2, bcs, pdf, BX_ALL, flags);
+        if (is_black(f) || pdf == 0.f) { ln.stage = ST_FINISH; return; }
+        ln.specular = (flags & BX_SPECULAR) != 0;
+        ln.thr = ln.thr * div_s(f * absdot3(wi, ln.v.nn), pdf);
+        if (k > 3) {
+            if (ln.rng.next_float() > .5f) { ln.stage = ST_FINISH; return; }
+            ln.thr = div_s(ln.thr, .5f);
+        }
+        if (k == fr.max_depth) { ln.stage = ST_FINISH; return; }
+        ++ln.depth;
+        launch_ray(ln, sc, ln.v.p, wi, RT_RAY_EPSILON, RT_INF, false, ST_VERTEX);
+        return;
+    }
+    case ST_SPECULAR: {                                                         // whitted.cpp:82-109
+        if (!(ln.depth < fr.max_depth)) { ln.stage = ST_RETURN; return; }       // rayDepth++ < maxDepth
+        const DevMaterial &m = sc.materials[ln.v.mat];
+        float u3 = ln.rng.next_float(), u2 = ln.rng.next_float(), u1 = ln.rng.next_float();
+        V3 wi; float pdf; int flags;
+        V3 f = bsdf_sample_f(m, ln.v, ln.v.wo, wi, u1, u2, u3, pdf, BX_REFLECTION | BX_SPECULAR, flags);
+        if (!is_black(f) && pdf > 0.f) f = div_s(f, pdf);                       // reflection.cpp:399
+        const float ad = absdot3(wi, ln.v.nn);
+        if (!is_black(f) && ad > 0.f) {
+            frame_push(fr, ln, gtid, f, ad, ST_SPEC_TRANS);
+            ++ln.depth;
+            launch_ray(ln, sc, ln.v.p, wi, RT_RAY_EPSILON, RT_INF, false, ST_VERTEX);
+            return;
+        }
+        ln.stage = ST_SPEC_TRANS;
+        return;
+    }
+    case ST_SPEC_TRANS: {                                                       // whitted.cpp:110-135
+        const DevMaterial &m = sc.materials[ln.v.mat];
+        float u3 = ln.rng.next_float(), u2 = ln.rng.next_float(), u1 = ln.rng.next_float();
+        V3 wi; float pdf; int flags;
+        V3 f = bsdf_sample_f(m, ln.v, ln.v.wo, wi, u1, u2, u3, pdf, BX_TRANSMISSION | BX_SPECULAR, flags);
+        if (!is_black(f) && pdf > 0.f) f = div_s(f, pdf);
+        const float ad = absdot3(wi, ln.v.nn);
+        if (!is_black(f) && ad > 0.f) {
+            frame_push(fr, ln, gtid, f, ad, ST_RETURN);
+            ++ln.depth;
+            launch_ray(ln, sc, ln.v.p, wi, RT_RAY_EPSILON, RT_INF, false, ST_VERTEX);
+            return;
+        }
+        ln.stage = ST_RETURN;
+        return;
+    }
+    case ST_RETURN: {
+        if (ln.fsp == 0) { ln.stage = ST_FINISH; return; }
+        ln.stage = frame_pop(fr, ln, gtid, ln.L);
+        return;
+    }
+    case ST_FINISH: {
+        film_add(fr, ln, ln.L, ln.alpha, *c_bad);
+        ln.stage = ST_FETCH;
+        return;
+    }
+    default: break;
+    }
+    (void)wave_work_base; (void)c_cam;
+}
+
+}  // namespace rt

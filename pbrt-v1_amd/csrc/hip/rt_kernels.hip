@@ -1,0 +1,523 @@
+// rt_kernels.hip -- gfx950 kernels and the C ABI (include/pbrt_hip.h) of libpbrt_hip.so.
+//
+// Kernels
+//   render_kernel   persistent-thread wavefront renderer: Scene::Render's sample loop (scene.cpp:42-84).
+//                   Every lane runs the state machine of rt_integrate.h; all lanes of a wave share ONE
+//                   kd-tree traversal loop (rt_traverse.h) whatever kind of ray they carry (camera,
+//                   bounce, MIS closest-hit, shadow any-hit); finished lanes refill from a global work
+//                   counter with one wave-aggregated atomic.  No MFMA: the work is pointer chasing and
+//                   3-vector arithmetic, bounded by HBM/L2 latency and bandwidth, not by dense math.
+//   trace_kernel    Scene::Intersect / IntersectP for caller-supplied rays (unit parity entry points).
+//   camera_kernel   Sampler + Camera::GenerateRay only.
+// Compile: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (parity with the reference's non-FMA build).
+#include "rt_integrate.h"
+#include "rt_internal.h"
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <cmath>
+
+namespace rt {
+
+// ------------------------------------------------------------------------------------------ kernels
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void render_kernel(DevScene sc, DevFrame fr) {
+    __shared__ uint2 lds_stack[RT_STACK_LDS * RT_BLOCK];
+    const unsigned gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    Lane ln;
+    ln.stage = ST_FETCH; ln.has_ray = false; ln.fsp = 0; ln.tv.active = false; ln.tv.hit_prim = -1;
+    ln.L = mk3(0.f); ln.thr = mk3(1.f); ln.alpha = 0.f; ln.depth = 0; ln.specular = false;
+    TravCounters tc; tc.nodes = tc.leaf_refs = tc.tris = tc.spills = 0;
+    unsigned c_cam = 0, c_closest = 0, c_any = 0, c_bad = 0;
+
+    for (;;) {
+        // ---- shade / regenerate: run every lane that is not waiting on a ray until it is (or is out of work)
+        for (;;) {
+            const unsigned long long want = __ballot(!ln.has_ray && ln.stage == ST_FETCH);
+            if (want) {                                                   // wave-aggregated work fetch
+                const int leader = __ffsll((long long)want) - 1;
+                unsigned long long base = 0;
+                if (lane == leader) base = atomicAdd(fr.work_counter, (unsigned long long)__popcll(want));
+                base = __shfl(base, leader);
+                if (!ln.has_ray && ln.stage == ST_FETCH) {
+                    const unsigned long long w = base + __popcll(want & ((1ull << lane) - 1ull));
+                    if (w >= fr.total_work) ln.stage = ST_EXIT;
+                    else {
+                        unsigned long long pixel; int s;
+                        if (work_to_sample(fr, w, pixel, s)) {
+                            Ray ray;
+                            setup_sample(sc, fr, ln, pixel, s, ray);
+                            ln.L = mk3(0.f); ln.thr = mk3(1.f); ln.alpha = 0.f; ln.depth = 0; ln.fsp = 0;
+                            ln.specular = false;
+                            if (COUNT) ++c_cam;
+                            trav_begin(ln.tv, sc, ray, false);
+                            ln.has_ray = true; ln.stage = ST_VERTEX;
+                        }
+                    }
+                }
+            }
+            if (!ln.has_ray && ln.stage != ST_EXIT && ln.stage != ST_FETCH)
+                advance<COUNT>(sc, fr, ln, gtid, nullptr, &c_cam, &c_closest, &c_any, &c_bad);
+            if (!__any(!ln.has_ray && ln.stage != ST_EXIT)) break;
+        }
+        if (!__any(ln.has_ray)) break;
+        // ---- extend: one shared traversal loop
+        while (__any(ln.has_ray && ln.tv.active)) {
+            if (ln.has_ray && ln.tv.active) trav_step<COUNT>(ln.tv, sc, lds_stack, fr.spill, fr.n_threads, gtid, tc);
+        }
+        if (ln.has_ray && !ln.tv.active) ln.has_ray = false;
+    }
+
+    if (COUNT) {
+        unsigned long long v[8] = {c_cam, c_closest, c_any, tc.nodes, tc.leaf_refs, tc.tris, c_bad, tc.spills};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            unsigned long long x = v[k];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+            if (lane == 0 && x) atomicAdd(fr.counters + k, x);
+        }
+    }
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void trace_kernel(DevScene sc, const RtRay *rays, unsigned n, int any,
+                                                         RtHit *hits, unsigned char *occ, uint2 *spill,
+                                                         unsigned n_threads, unsigned long long *counters) {
+    __shared__ uint2 lds_stack[RT_STACK_LDS * RT_BLOCK];
+    const unsigned gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
+    TravCounters tc; tc.nodes = tc.leaf_refs = tc.tris = tc.spills = 0;
+    for (unsigned i = gtid; i < n; i += n_threads) {
+        Ray r; r.o = mk3(rays[i].o[0], rays[i].o[1], rays[i].o[2]); r.d = mk3(rays[i].d[0], rays[i].d[1], rays[i].d[2]);
+        r.mint = rays[i].mint; r.maxt = rays[i].maxt;
+        Trav tv; trav_begin(tv, sc, r, any != 0);
+        while (tv.active) trav_step<true>(tv, sc, lds_stack, spill, n_threads, gtid, tc);
+        if (any) occ[i] = tv.hit_prim >= 0 ? 1 : 0;
+        else { hits[i].prim = tv.hit_prim; hits[i].t = tv.hit_prim >= 0 ? tv.maxt : 0.f; hits[i].b1 = tv.b1; hits[i].b2 = tv.b2; }
+    }
+    if (counters) {
+        atomicAdd(counters + 3, (unsigned long long)tc.nodes);
+        atomicAdd(counters + 4, (unsigned long long)tc.leaf_refs);
+        atomicAdd(counters + 5, (unsigned long long)tc.tris);
+        atomicAdd(counters + 7, (unsigned long long)tc.spills);
+    }
+}
+
+__global__ void camera_kernel(DevScene sc, DevFrame fr, unsigned long long first, unsigned count, RtRay *out) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const unsigned long long n = first + i;
+    Lane ln; Ray r;
+    setup_sample(sc, fr, ln, n / fr.spp, int(n % fr.spp), r);
+    out[i].o[0] = r.o.x; out[i].o[1] = r.o.y; out[i].o[2] = r.o.z;
+    out[i].d[0] = r.d.x; out[i].d[1] = r.d.y; out[i].d[2] = r.d.z;
+    out[i].mint = r.mint; out[i].maxt = r.maxt;
+}
+
+}  // namespace rt
+
+// ------------------------------------------------------------------------------------------ host side
+using namespace rt;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(RT_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));                \
+    } while (0)
+
+struct RtScene {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    KdTree tree;
+    DevScene dev{};
+    std::vector<void *> allocs;
+    // film
+    float *accum = nullptr; bool own_accum = false; int film_w = 0, film_h = 0;
+    float *filter_dev = nullptr;
+    // per-launch scratch
+    unsigned long long *work_counter = nullptr, *counters = nullptr;
+    uint2 *spill = nullptr; size_t spill_entries = 0;
+    float *frames = nullptr; size_t frames_floats = 0;
+    unsigned grid = 0, n_threads = 0;
+    int spill_depth = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool have_timing = false;
+    uint32_t n_tris = 0;
+};
+
+template <class T>
+static int upload(RtScene *s, const T *host, size_t n, const T **dev) {
+    void *p = nullptr;
+    size_t bytes = (n ? n : 1) * sizeof(T);
+    HIPCHK(hipMalloc(&p, bytes));
+    s->allocs.push_back(p);
+    if (n) HIPCHK(hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice));
+    *dev = static_cast<const T *>(p);
+    return RT_OK;
+}
+
+extern "C" {
+
+const char *rt_last_error(void) { return g_err.c_str(); }
+
+int rt_device_count(int *count) {
+    if (!count) return fail(RT_EINVAL, "rt_device_count: null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(RT_EDEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+    *count = n; return RT_OK;
+}
+
+int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
+    if (!d || !out) return fail(RT_EINVAL, "rt_scene_create: null argument");
+    if (d->n_tris && (!d->tri_verts || !d->tri_material || !d->tri_light || !d->tri_flags))
+        return fail(RT_EINVAL, "rt_scene_create: missing triangle arrays");
+    if (d->accel.kind != RT_ACCEL_KDTREE) return fail(RT_EINVAL, "rt_scene_create: only the kd-tree accelerator is built by this version");
+    for (uint32_t i = 0; i < d->n_tris; ++i)
+        if (d->tri_material[i] >= d->n_materials) return fail(RT_EINVAL, "rt_scene_create: material index out of range");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(RT_EDEVICE, "rt_scene_create: no HIP device visible (the product path has no CPU fallback)");
+    RtScene *s = new RtScene();
+    if (device >= 0) { hipError_t e = hipSetDevice(device); if (e != hipSuccess) { delete s; return fail(RT_EDEVICE, "hipSetDevice failed"); } }
+    HIPCHK(hipGetDevice(&s->device));
+    HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)); s->own_stream = true;
+    HIPCHK(hipEventCreate(&s->ev0)); HIPCHK(hipEventCreate(&s->ev1));
+    s->n_tris = d->n_tris;
+
+    build_kdtree(d->tri_verts, d->n_tris, d->accel, s->tree);
+
+    // triangles -> 48-byte records
+    std::vector<DevTri> tris(d->n_tris);
+    for (uint32_t i = 0; i < d->n_tris; ++i) {
+        const float *v = d->tri_verts + size_t(9) * i;
+        uint32_t bits = uint32_t(d->tri_material[i]) | (uint32_t(d->tri_flags[i] & 1u) << 16);
+        int32_t light = d->tri_light[i];
+        float fb, fl; std::memcpy(&fb, &bits, 4); std::memcpy(&fl, &light, 4);
+        tris[i].q0 = make_float4(v[0], v[1], v[2], v[3]);
+        tris[i].q1 = make_float4(v[4], v[5], v[6], v[7]);
+        tris[i].q2 = make_float4(v[8], fb, fl, 0.f);
+    }
+    int rc;
+    if ((rc = upload(s, tris.data(), tris.size(), &s->dev.tris))) return rc;
+    const uint2 *nodes_dev = nullptr;
+    if ((rc = upload(s, reinterpret_cast<const uint2 *>(s->tree.nodes.data()), s->tree.nodes.size(), &nodes_dev))) return rc;
+    s->dev.nodes = nodes_dev;
+    if ((rc = upload(s, s->tree.leaf_refs.data(), s->tree.leaf_refs.size(), &s->dev.leaf_refs))) return rc;
+
+    // materials (OrenNayar constants: reflection.h:268-277)
+    std::vector<DevMaterial> mats(d->n_materials);
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
+        const RtMaterial &m = d->materials[i]; DevMaterial &o = mats[i];
+        o.type = m.type; o.ior = m.ior; o.on_a = 1.f; o.on_b = -1.f;
+        for (int c = 0; c < 3; ++c) { o.r[c] = m.kd[c]; o.t[c] = m.kt[c]; }
+        o.has_r = (m.kd[0] != 0.f || m.kd[1] != 0.f || m.kd[2] != 0.f);
+        o.has_t = (m.kt[0] != 0.f || m.kt[1] != 0.f || m.kt[2] != 0.f);
+        if (m.type == RT_MAT_MATTE && m.sigma != 0.f) {
+            float sigma = (3.14159265358979323846f / 180.f) * m.sigma;
+            float sigma2 = sigma * sigma;
+            o.on_a = 1.f - (sigma2 / (2.f * (sigma2 + 0.33f)));
+            o.on_b = 0.45f * sigma2 / (sigma2 + 0.09f);
+        }
+    }
+    if ((rc = upload(s, mats.data(), mats.size(), &s->dev.materials))) return rc;
+
+    // lights + emitter triangles with ShapeSet area CDF (shape.h:122-135)
+    std::vector<float> ltris(size_t(d->n_light_tris) * 12, 0.f);
+    std::vector<DevLight> lights(d->n_lights);
+    for (uint32_t i = 0; i < d->n_lights; ++i) {
+        const RtLight &L = d->lights[i]; DevLight &o = lights[i];
+        o.type = L.type; o.n_samples = L.n_samples < 1 ? 1 : L.n_samples;
+        for (int c = 0; c < 3; ++c) { o.color[c] = L.color[c]; o.pos[c] = L.pos[c]; }
+        o.first_tri = L.first_tri; o.n_tris = L.n_tris; o.reverse_orientation = L.reverse_orientation;
+        o.flip_normal = L.flip_normal; o.area = 0.f;
+        if (L.type != RT_LIGHT_AREA) continue;
+        if (size_t(L.first_tri) + L.n_tris > d->n_light_tris) return fail(RT_EINVAL, "rt_scene_create: light triangle range out of bounds");
+        float area = 0.f; std::vector<float> areas;
+        for (uint32_t k = 0; k < L.n_tris; ++k) {
+            const float *v = d->light_tris + size_t(L.first_tri + k) * 9;
+            float *q = &ltris[size_t(L.first_tri + k) * 12];
+            std::memcpy(q, v, 9 * sizeof(float));
+            // Triangle::Area trianglemesh.cpp:329-335
+            float ax = v[3] - v[0], ay = v[4] - v[1], az = v[5] - v[2];
+            float bx = v[6] - v[0], by = v[7] - v[1], bz = v[8] - v[2];
+            float cx = (ay * bz) - (az * by), cy = (az * bx) - (ax * bz), cz = (ax * by) - (ay * bx);
+            float a = 0.5f * sqrtf(cx * cx + cy * cy + cz * cz);
+            q[9] = a; area += a; areas.push_back(a);
+        }
+        float prev = 0.f;
+        for (uint32_t k = 0; k < L.n_tris; ++k) {
+            float c = prev + areas[k] / area;
+            ltris[size_t(L.first_tri + k) * 12 + 10] = c; prev = c;
+        }
+        o.area = (L.n_tris == 1) ? areas[0] : area;
+    }
+    if ((rc = upload(s, lights.data(), lights.size(), &s->dev.lights))) return rc;
+    if ((rc = upload(s, ltris.data(), ltris.size(), &s->dev.light_tris))) return rc;
+
+    s->dev.n_tris = d->n_tris; s->dev.n_lights = d->n_lights;
+    std::memcpy(s->dev.bounds, s->tree.bounds, sizeof s->dev.bounds);
+    s->dev.cam = d->camera; s->dev.vol = d->volume;
+
+    // persistent launch geometry: as many resident blocks as the kernel's registers/LDS admit
+    int per_cu = 0; hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, s->device));
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<true>, RT_BLOCK, 0));
+    if (per_cu < 1) per_cu = 1;
+    s->grid = unsigned(prop.multiProcessorCount) * unsigned(per_cu);
+    s->n_threads = s->grid * RT_BLOCK;
+    s->spill_depth = s->tree.max_depth > RT_STACK_LDS ? s->tree.max_depth - RT_STACK_LDS + 1 : 1;
+    HIPCHK(hipMalloc((void **)&s->spill, size_t(s->spill_depth) * s->n_threads * sizeof(uint2)));
+    HIPCHK(hipMalloc((void **)&s->work_counter, sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void **)&s->counters, 8 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(s->counters, 0, 8 * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void **)&s->filter_dev, 256 * sizeof(float)));
+    *out = s;
+    return RT_OK;
+}
+
+int rt_scene_destroy(RtScene *s) {
+    if (!s) return RT_OK;
+    hipSetDevice(s->device);
+    hipStreamSynchronize(s->stream);
+    for (void *p : s->allocs) hipFree(p);
+    if (s->own_accum && s->accum) hipFree(s->accum);
+    hipFree(s->spill); hipFree(s->work_counter); hipFree(s->counters); hipFree(s->filter_dev);
+    if (s->frames) hipFree(s->frames);
+    if (s->ev0) hipEventDestroy(s->ev0);
+    if (s->ev1) hipEventDestroy(s->ev1);
+    if (s->own_stream && s->stream) hipStreamDestroy(s->stream);
+    delete s;
+    return RT_OK;
+}
+
+int rt_scene_set_stream(RtScene *s, void *hip_stream) {
+    if (!s) return fail(RT_EINVAL, "null scene");
+    if (s->own_stream && s->stream) { hipStreamSynchronize(s->stream); hipStreamDestroy(s->stream); }
+    s->stream = static_cast<hipStream_t>(hip_stream); s->own_stream = false;
+    return RT_OK;
+}
+
+int rt_scene_accel_info(const RtScene *s, RtAccelInfo *info) {
+    if (!s || !info) return fail(RT_EINVAL, "null argument");
+    info->n_nodes = uint32_t(s->tree.nodes.size()); info->n_leaf_refs = uint32_t(s->tree.leaf_refs.size());
+    info->max_depth = uint32_t(s->tree.max_depth); info->n_tris = s->n_tris;
+    std::memcpy(info->bounds, s->tree.bounds, sizeof info->bounds);
+    info->build_seconds = s->tree.build_seconds;
+    return RT_OK;
+}
+
+int rt_scene_accel_copy(const RtScene *s, uint32_t *nodes, uint32_t *leaf_refs) {
+    if (!s) return fail(RT_EINVAL, "null scene");
+    if (nodes) std::memcpy(nodes, s->tree.nodes.data(), s->tree.nodes.size() * sizeof(Node));
+    if (leaf_refs) std::memcpy(leaf_refs, s->tree.leaf_refs.data(), s->tree.leaf_refs.size() * sizeof(uint32_t));
+    return RT_OK;
+}
+
+// Build the per-frame device descriptor: film geometry + the Sample layout the integrators request
+// (Sample::Sample sampling.cpp:41-70; RequestSamples of directlighting.cpp:39-66, path.cpp:47-57,
+// emission.cpp:42-46 / single.cpp:43-47; LatinHypercube draw counts sampling.cpp:98-113).
+static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool need_film) {
+    if (rd->sampler != RT_SAMPLER_STRATIFIED) return fail(RT_EINVAL, "only the stratified sampler is implemented in this version");
+    if (rd->x_samples < 1 || rd->y_samples < 1) return fail(RT_EINVAL, "bad xsamples/ysamples");
+    std::memset(&fr, 0, sizeof fr);
+    fr.integrator = rd->integrator; fr.max_depth = rd->max_depth; fr.strategy = rd->strategy;
+    fr.volume_integrator = rd->volume_integrator; fr.step_size = rd->step_size;
+    fr.sampler = rd->sampler; fr.xs = rd->x_samples; fr.ys = rd->y_samples; fr.jitter = rd->jitter;
+    fr.spp = rd->x_samples * rd->y_samples; fr.seed = rd->seed;
+    fr.x_pixel_start = rd->x_pixel_start; fr.y_pixel_start = rd->y_pixel_start;
+    fr.x_pixel_count = rd->x_pixel_count; fr.y_pixel_count = rd->y_pixel_count;
+    fr.x_start = rd->x_start; fr.x_end = rd->x_end; fr.y_start = rd->y_start; fr.y_end = rd->y_end;
+    if (fr.x_end <= fr.x_start || fr.y_end <= fr.y_start) return fail(RT_EINVAL, "empty sample extent");
+    fr.fxw = rd->filter_x_width; fr.fyw = rd->filter_y_width;
+    fr.inv_fxw = 1.f / fr.fxw; fr.inv_fyw = 1.f / fr.fyw;
+    fr.filter_table = s->filter_dev; fr.accum = s->accum;
+    fr.shard_index = rd->shard_index; fr.shard_count = rd->shard_count < 1 ? 1 : rd->shard_count;
+    fr.tile_pixels = rd->tile_pixels < 1 ? 1 : rd->tile_pixels;
+    if (fr.shard_index < 0 || fr.shard_index >= fr.shard_count) return fail(RT_EINVAL, "bad shard index");
+    fr.total_pixels = (unsigned long long)(fr.x_end - fr.x_start) * (unsigned long long)(fr.y_end - fr.y_start);
+    if (fr.total_pixels * fr.spp > 0xFFFFFFFFull) return fail(RT_EINVAL, "more than 2^32 camera samples per frame");
+    const unsigned long long n_tiles = (fr.total_pixels + fr.tile_pixels - 1) / fr.tile_pixels;
+    const unsigned long long my_tiles = n_tiles > (unsigned long long)fr.shard_index
+        ? (n_tiles - fr.shard_index + fr.shard_count - 1) / fr.shard_count : 0;
+    fr.total_work = my_tiles * fr.tile_pixels * fr.spp;
+
+    // sample layout
+    std::vector<int> n1, n2;
+    const int nl = int(s->dev.n_lights);
+    if (rd->integrator == RT_INTEGRATOR_DIRECT && rd->strategy == RT_STRATEGY_ALL) {
+        std::vector<DevLight> lights(nl);
+        if (nl) HIPCHK(hipMemcpy(lights.data(), s->dev.lights, nl * sizeof(DevLight), hipMemcpyDeviceToHost));
+        for (int i = 0; i < nl; ++i) { int ns = lights[i].n_samples; n2.push_back(ns); n2.push_back(ns); n1.push_back(ns); }
+    } else if (rd->integrator == RT_INTEGRATOR_DIRECT) { n2 = {1, 1}; n1 = {1, 1}; }
+    else if (rd->integrator == RT_INTEGRATOR_PATH) { n1.assign(9, 1); n2.assign(9, 1); }
+    else if (rd->integrator != RT_INTEGRATOR_WHITTED) return fail(RT_EINVAL, "unknown integrator");
+    n1.push_back(1); n1.push_back(1);                   // the volume integrator's tau / scatter samples
+    if (n1.size() > RT_MAX_DIM_REQ || n2.size() > RT_MAX_DIM_REQ) return fail(RT_EINVAL, "too many lights for the sample table");
+    unsigned c = 0;
+    fr.n1d = int(n1.size()); fr.n2d = int(n2.size());
+    for (size_t i = 0; i < n1.size(); ++i) { fr.one_d[i] = DimReq{c, c + unsigned(n1[i]), (unsigned short)n1[i], 1}; c += 2u * n1[i]; }
+    for (size_t i = 0; i < n2.size(); ++i) { fr.two_d[i] = DimReq{c, c + 2u * n2[i], (unsigned short)n2[i], 2}; c += 4u * n2[i]; }
+    fr.lhs_total = c;
+    fr.pixgen_draws = fr.jitter ? 7u * fr.spp : 2u * fr.spp;
+    fr.work_counter = s->work_counter; fr.counters = s->counters; fr.spill = s->spill; fr.n_threads = s->n_threads;
+    fr.frames = s->frames;
+    if (need_film && !s->accum) return fail(RT_ESTATE, "rt_render: no film bound (call rt_film_bind first)");
+    if (need_film && (fr.x_pixel_count != s->film_w || fr.y_pixel_count != s->film_h))
+        return fail(RT_EINVAL, "rt_render: film size does not match the bound film");
+    return RT_OK;
+}
+
+int rt_camera_rays(RtScene *s, const RtRenderDesc *rd, uint64_t first, uint32_t count, RtRay *rays_out) {
+    if (!s || !rd || !rays_out) return fail(RT_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(s->device));
+    DevFrame fr; int rc = make_frame(s, rd, fr, false); if (rc) return rc;
+    RtRay *dev = nullptr;
+    HIPCHK(hipMalloc((void **)&dev, size_t(count ? count : 1) * sizeof(RtRay)));
+    hipLaunchKernelGGL(camera_kernel, dim3((count + 255) / 256), dim3(256), 0, s->stream, s->dev, fr,
+                       (unsigned long long)first, count, dev);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipMemcpy(rays_out, dev, size_t(count) * sizeof(RtRay), hipMemcpyDeviceToHost));
+    hipFree(dev);
+    return RT_OK;
+}
+
+static int trace_common(RtScene *s, const RtRay *rays, uint32_t n, int any, RtHit *hits, uint8_t *occ) {
+    if (!s || !rays || (!hits && !occ)) return fail(RT_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(s->device));
+    RtRay *drays = nullptr; void *dout = nullptr;
+    const size_t out_bytes = any ? size_t(n) : size_t(n) * sizeof(RtHit);
+    HIPCHK(hipMalloc((void **)&drays, size_t(n ? n : 1) * sizeof(RtRay)));
+    HIPCHK(hipMalloc(&dout, out_bytes ? out_bytes : 1));
+    HIPCHK(hipMemcpy(drays, rays, size_t(n) * sizeof(RtRay), hipMemcpyHostToDevice));
+    hipEventRecord(s->ev0, s->stream);
+    hipLaunchKernelGGL(trace_kernel, dim3(s->grid), dim3(RT_BLOCK), 0, s->stream, s->dev, drays, n, any,
+                       (RtHit *)(any ? nullptr : dout), (unsigned char *)(any ? dout : nullptr), s->spill, s->n_threads, s->counters);
+    hipEventRecord(s->ev1, s->stream); s->have_timing = true;
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipMemcpy(any ? (void *)occ : (void *)hits, dout, out_bytes, hipMemcpyDeviceToHost));
+    hipFree(drays); hipFree(dout);
+    return RT_OK;
+}
+int rt_trace_closest(RtScene *s, const RtRay *rays, uint32_t n, RtHit *hits_out) { return trace_common(s, rays, n, 0, hits_out, nullptr); }
+int rt_trace_any(RtScene *s, const RtRay *rays, uint32_t n, uint8_t *occluded_out) { return trace_common(s, rays, n, 1, nullptr, occluded_out); }
+
+int rt_film_bind(RtScene *s, void *device_accum, int32_t w, int32_t h) {
+    if (!s || w < 1 || h < 1) return fail(RT_EINVAL, "rt_film_bind: bad argument");
+    HIPCHK(hipSetDevice(s->device));
+    if (s->own_accum && s->accum) { hipFree(s->accum); s->accum = nullptr; }
+    s->film_w = w; s->film_h = h;
+    if (device_accum) { s->accum = static_cast<float *>(device_accum); s->own_accum = false; }
+    else {
+        HIPCHK(hipMalloc((void **)&s->accum, size_t(5) * w * h * sizeof(float))); s->own_accum = true;
+        HIPCHK(hipMemset(s->accum, 0, size_t(5) * w * h * sizeof(float)));
+    }
+    return RT_OK;
+}
+int rt_film_clear(RtScene *s) {
+    if (!s || !s->accum) return fail(RT_ESTATE, "no film bound");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipMemsetAsync(s->accum, 0, size_t(5) * s->film_w * s->film_h * sizeof(float), s->stream));
+    return RT_OK;
+}
+int rt_film_read(RtScene *s, float *host_accum) {
+    if (!s || !s->accum || !host_accum) return fail(RT_ESTATE, "no film bound / null buffer");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipMemcpy(host_accum, s->accum, size_t(5) * s->film_w * s->film_h * sizeof(float), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+// ImageFilm::WriteImage film/image.cpp:157-203; Spectrum::XYZ color.h:177-184, weights color.cpp:35-43
+int rt_film_resolve(RtScene *s, int premultiply, float *rgb_out, float *alpha_out) {
+    if (!s || !rgb_out || !alpha_out) return fail(RT_EINVAL, "null argument");
+    const size_t n = size_t(s->film_w) * s->film_h;
+    std::vector<float> acc(5 * n);
+    int rc = rt_film_read(s, acc.data()); if (rc) return rc;
+    const float XW[3] = {0.412453f, 0.357580f, 0.180423f}, YW[3] = {0.212671f, 0.715160f, 0.072169f},
+                ZW[3] = {0.019334f, 0.119193f, 0.950227f};
+    for (size_t i = 0; i < n; ++i) {
+        const float c[3] = {acc[i], acc[n + i], acc[2 * n + i]};
+        float xyz[3] = {0.f, 0.f, 0.f};
+        for (int k = 0; k < 3; ++k) { xyz[0] += XW[k] * c[k]; xyz[1] += YW[k] * c[k]; xyz[2] += ZW[k] * c[k]; }
+        float r = 3.240479f * xyz[0] + -1.537150f * xyz[1] + -0.498535f * xyz[2];
+        float g = -0.969256f * xyz[0] + 1.875991f * xyz[1] + 0.041556f * xyz[2];
+        float b = 0.055648f * xyz[0] + -0.204043f * xyz[1] + 1.057311f * xyz[2];
+        float a = acc[3 * n + i];
+        const float ws = acc[4 * n + i];
+        if (ws != 0.f) {
+            const float inv = 1.f / ws;
+            r = r * inv; r = r < 0.f ? 0.f : r;
+            g = g * inv; g = g < 0.f ? 0.f : g;
+            b = b * inv; b = b < 0.f ? 0.f : b;
+            a = a * inv; a = a < 0.f ? 0.f : (a > 1.f ? 1.f : a);
+        }
+        if (premultiply) { r *= a; g *= a; b *= a; }
+        rgb_out[3 * i] = r; rgb_out[3 * i + 1] = g; rgb_out[3 * i + 2] = b; alpha_out[i] = a;
+    }
+    return RT_OK;
+}
+
+int rt_render(RtScene *s, const RtRenderDesc *rd) {
+    if (!s || !rd) return fail(RT_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(s->device));
+    // recursion frames for whitted / directlighting
+    if (rd->integrator != RT_INTEGRATOR_PATH) {
+        const size_t need = size_t(rd->max_depth + 2) * RT_FRAME_WORDS * s->n_threads;
+        if (need > s->frames_floats) {
+            if (s->frames) { HIPCHK(hipStreamSynchronize(s->stream)); hipFree(s->frames); s->frames = nullptr; }
+            HIPCHK(hipMalloc((void **)&s->frames, need * sizeof(float))); s->frames_floats = need;
+        }
+    }
+    DevFrame fr; int rc = make_frame(s, rd, fr, true); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(s->filter_dev, rd->filter_table, 256 * sizeof(float), hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemsetAsync(s->work_counter, 0, sizeof(unsigned long long), s->stream));
+    HIPCHK(hipEventRecord(s->ev0, s->stream));
+    hipLaunchKernelGGL(render_kernel<true>, dim3(s->grid), dim3(RT_BLOCK), 0, s->stream, s->dev, fr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(s->ev1, s->stream));
+    s->have_timing = true;
+    return RT_OK;
+}
+
+int rt_sync(RtScene *s) {
+    if (!s) return fail(RT_EINVAL, "null scene");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return RT_OK;
+}
+
+int rt_counters(RtScene *s, RtCounters *out) {
+    if (!s || !out) return fail(RT_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    unsigned long long v[8];
+    HIPCHK(hipMemcpy(v, s->counters, sizeof v, hipMemcpyDeviceToHost));
+    out->camera_rays = v[0]; out->closest_rays = v[1]; out->any_rays = v[2]; out->nodes_visited = v[3];
+    out->leaf_refs = v[4]; out->tri_tests = v[5]; out->bad_samples = v[6]; out->stack_overflows = v[7];
+    return RT_OK;
+}
+int rt_counters_reset(RtScene *s) {
+    if (!s) return fail(RT_EINVAL, "null scene");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipMemsetAsync(s->counters, 0, 8 * sizeof(unsigned long long), s->stream));
+    return RT_OK;
+}
+int rt_last_render_ms(RtScene *s, float *total_ms, float *kernel_ms) {
+    if (!s || !s->have_timing) return fail(RT_ESTATE, "no timed launch yet");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipEventSynchronize(s->ev1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    if (total_ms) *total_ms = ms;
+    if (kernel_ms) *kernel_ms = ms;
+    return RT_OK;
+}
+
+}  // extern "C"

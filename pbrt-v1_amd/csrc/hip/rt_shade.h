@@ -1,0 +1,250 @@
+// rt_shade.h -- device-side surface interaction: differential geometry of a triangle hit,
+// the BSDF set the three materials can produce, and the two light types.
+// Each function names the reference code whose arithmetic (and association order) it follows.
+#pragma once
+#include "rt_traverse.h"
+
+namespace rt {
+
+// BxDFType bits (core/reflection.h:52-68)
+enum { BX_REFLECTION = 1, BX_TRANSMISSION = 2, BX_DIFFUSE = 4, BX_GLOSSY = 8, BX_SPECULAR = 16,
+       BX_ALL = 31 };
+
+struct Vertex {
+    V3 p, nn, sn, tn;   // hit point, (geometric == shading) normal, BSDF frame
+    V3 wo;
+    int mat, light;     // material index, area-light index of the primitive or -1
+};
+
+// DifferentialGeometry for a triangle without per-vertex uv/N/S:
+//   Triangle::Intersect trianglemesh.cpp:248-274 with GetUVs' defaults (0,0),(1,0),(1,1) (:321-326):
+//   du1=-1 du2=0 dv1=-1 dv2=-1, determinant 1  =>  dpdu = (dv2*dp1 - dv1*dp2)*invdet,  dpdv = (-du2*dp1 + du1*dp2)*invdet
+//   DifferentialGeometry ctor shape.cpp:37-51: nn = Normalize(Cross(dpdu,dpdv)), flipped iff
+//   reverseOrientation ^ transformSwapsHandedness.
+//   GetShadingGeometry is the identity (trianglemesh.cpp:71-75, no N/S) and Material::Bump with the always
+//   present constant-0 bump texture (paramset.cpp:452-465, material.cpp:29-71) re-derives the same nn:
+//   dpdu + 0/du*nn + 0*dndu leaves dpdu/dpdv unchanged, and the final "face the geometric normal" flip is
+//   a no-op because both normals are the same vector.  BSDF frame: reflection.cpp:471-479.
+RT_DEV void tri_frame(V3 p1, V3 p2, V3 p3, bool flip, V3 &nn, V3 &dpdu) {
+    const float du1 = 0.f - 1.f, du2 = 1.f - 1.f, dv1 = 0.f - 1.f, dv2 = 0.f - 1.f;
+    V3 dp1 = p1 - p3, dp2 = p2 - p3;
+    const float determinant = du1 * dv2 - dv1 * du2;
+    const float invdet = 1.f / determinant;
+    dpdu = (dv2 * dp1 - dv1 * dp2) * invdet;
+    V3 dpdv = (-du2 * dp1 + du1 * dp2) * invdet;
+    nn = normalize3(cross3(dpdu, dpdv));
+    if (flip) nn = nn * -1.f;
+}
+
+RT_DEV void make_vertex(const DevScene &sc, const Trav &tv, Vertex &v) {
+    V3 p1, p2, p3; unsigned bits; int light;
+    tri_verts(sc.tris, unsigned(tv.hit_prim), p1, p2, p3, bits, light);
+    v.p = tv.o + tv.d * tv.maxt;                         // ray(t), geometry.h:210
+    V3 dpdu;
+    tri_frame(p1, p2, p3, (bits >> 16) & 1u, v.nn, dpdu);
+    v.sn = normalize3(dpdu);
+    v.tn = cross3(v.nn, v.sn);
+    v.wo = -tv.d;
+    v.mat = int(bits & 0xffffu);
+    v.light = light;
+}
+
+RT_DEV V3 to_local(const Vertex &v, V3 w) { return mk3(dot3(w, v.sn), dot3(w, v.tn), dot3(w, v.nn)); }
+RT_DEV V3 to_world(const Vertex &v, V3 w) {
+    return mk3(v.sn.x * w.x + v.tn.x * w.y + v.nn.x * w.z, v.sn.y * w.x + v.tn.y * w.y + v.nn.y * w.z,
+               v.sn.z * w.x + v.tn.z * w.y + v.nn.z * w.z);
+}
+
+// ---- BxDFs -------------------------------------------------------------------------------
+RT_DEV float sin_theta(V3 w) { return sqrtf(fmaxf(0.f, 1.f - w.z * w.z)); }
+RT_DEV float sin_theta2(V3 w) { return fmaxf(0.f, 1.f - w.z * w.z); }
+RT_DEV float cos_phi(V3 w) { float s = sin_theta(w); if (s == 0.f) return 1.f; return clampf(w.x / s, -1.f, 1.f); }
+RT_DEV float sin_phi(V3 w) { float s = sin_theta(w); if (s == 0.f) return 0.f; return clampf(w.y / s, -1.f, 1.f); }
+
+RT_DEV V3 mat_color(const float *c) { return mk3(c[0], c[1], c[2]); }
+
+// Lambertian::f reflection.cpp:128-131 / OrenNayar::f :132-156
+RT_DEV V3 diffuse_f(const DevMaterial &m, V3 wo, V3 wi) {
+    V3 R = mat_color(m.r);
+    if (m.on_b < 0.f) return R * RT_INV_PI;
+    float sinthetai = sin_theta(wi), sinthetao = sin_theta(wo);
+    float maxcos = 0.f;
+    if (sinthetai > 1e-4 && sinthetao > 1e-4) {
+        float sinphii = sin_phi(wi), cosphii = cos_phi(wi);
+        float sinphio = sin_phi(wo), cosphio = cos_phi(wo);
+        float dcos = cosphii * cosphio + sinphii * sinphio;
+        maxcos = fmaxf(0.f, dcos);
+    }
+    float sinalpha, tanbeta;
+    if (fabsf(wi.z) > fabsf(wo.z)) { sinalpha = sinthetao; tanbeta = sinthetai / fabsf(wi.z); }
+    else { sinalpha = sinthetai; tanbeta = sinthetao / fabsf(wo.z); }
+    return R * RT_INV_PI * (m.on_a + m.on_b * maxcos * sinalpha * tanbeta);
+}
+
+// FresnelDielectric::Evaluate reflection.cpp:77-95 + FrDiel :31-39 (all three channels equal)
+RT_DEV float fresnel_dielectric(float cosi, float eta_i, float eta_t) {
+    cosi = clampf(cosi, -1.f, 1.f);
+    bool entering = cosi > 0.f;
+    float ei = eta_i, et = eta_t;
+    if (!entering) { float tmp = ei; ei = et; et = tmp; }
+    float sint = ei / et * sqrtf(fmaxf(0.f, 1.f - cosi * cosi));
+    if (sint >= 1.f) return 1.f;
+    float cost = sqrtf(fmaxf(0.f, 1.f - sint * sint));
+    float ac = fabsf(cosi);
+    float Rparl = ((et * ac) - (ei * cost)) / ((et * ac) + (ei * cost));
+    float Rperp = ((ei * ac) - (et * cost)) / ((ei * ac) + (et * cost));
+    return (Rparl * Rparl + Rperp * Rperp) * (1.f / 2.f);
+}
+
+// ConcentricSampleDisk core/mc.cpp:92-135
+RT_DEV void concentric_disk(float u1, float u2, float &dx, float &dy) {
+    float r, theta;
+    float sx = 2 * u1 - 1;
+    float sy = 2 * u2 - 1;
+    if (sx == 0.0f && sy == 0.0f) { dx = 0.f; dy = 0.f; return; }
+    if (sx >= -sy) {
+        if (sx > sy) { r = sx; if (sy > 0.0f) theta = sy / r; else theta = 8.0f + sy / r; }
+        else { r = sy; theta = 2.0f - sx / r; }
+    } else {
+        if (sx <= sy) { r = -sx; theta = 4.0f - sy / r; }
+        else { r = -sy; theta = 6.0f + sx / r; }
+    }
+    theta *= RT_PI / 4.f;
+    dx = r * cosf(theta);
+    dy = r * sinf(theta);
+}
+
+RT_DEV int bsdf_num_components(const DevMaterial &m, int flags) {
+    int n = 0;
+    if (m.type == RT_MAT_MATTE) { if (((BX_REFLECTION | BX_DIFFUSE) & flags) == (BX_REFLECTION | BX_DIFFUSE)) ++n; }
+    else {
+        if (m.has_r && ((BX_REFLECTION | BX_SPECULAR) & flags) == (BX_REFLECTION | BX_SPECULAR)) ++n;
+        if (m.type == RT_MAT_GLASS && m.has_t && ((BX_TRANSMISSION | BX_SPECULAR) & flags) == (BX_TRANSMISSION | BX_SPECULAR)) ++n;
+    }
+    return n;
+}
+RT_DEV int bsdf_total_components(const DevMaterial &m) { return bsdf_num_components(m, BX_ALL); }
+
+// BSDF::f reflection.cpp:480-494 (flags = BSDF_ALL): only the diffuse lobe has a non-zero f
+RT_DEV V3 bsdf_f(const DevMaterial &m, const Vertex &v, V3 woW, V3 wiW) {
+    if (m.type != RT_MAT_MATTE) return mk3(0.f);
+    V3 wi = to_local(v, wiW), wo = to_local(v, woW);
+    if (dot3(wiW, v.nn) * dot3(woW, v.nn) > 0) return mk3(0.f) + diffuse_f(m, wo, wi);   // BRDFs only
+    return mk3(0.f);                                                                    // BTDFs only: none
+}
+
+// BSDF::Pdf reflection.cpp:458-470 (flags = BSDF_ALL)
+RT_DEV float bsdf_pdf(const DevMaterial &m, const Vertex &v, V3 woW, V3 wiW) {
+    int nc = bsdf_total_components(m);
+    if (nc == 0) return 0.f;
+    if (m.type != RT_MAT_MATTE) return 0.f / float(nc);
+    V3 wo = to_local(v, woW), wi = to_local(v, wiW);
+    float pdf = 0.f;
+    pdf += (wo.z * wi.z > 0.f) ? fabsf(wi.z) * RT_INV_PI : 0.f;      // BxDF::Pdf reflection.cpp:227-230
+    return pdf / nc;
+}
+
+// BSDF::Sample_f reflection.cpp:402-457.  Returns f; pdf == 0 means "no sample".
+RT_DEV V3 bsdf_sample_f(const DevMaterial &m, const Vertex &v, V3 woW, V3 &wiW, float u1, float u2, float u3,
+                        float &pdf, int flags, int &sampled) {
+    sampled = 0; pdf = 0.f;
+    int matching = bsdf_num_components(m, flags);
+    if (matching == 0) return mk3(0.f);
+    int which = min(int(floorf(u3 * matching)), matching - 1);     // Floor2Int(double(u3*matching))
+    V3 wo = to_local(v, woW);
+    V3 wi, f;
+    if (m.type == RT_MAT_MATTE) {
+        // BxDF::Sample_f reflection.cpp:219-226 with CosineSampleHemisphere mc.h:38-44
+        float dx, dy; concentric_disk(u1, u2, dx, dy);
+        wi = mk3(dx, dy, sqrtf(fmaxf(0.f, 1.f - dx * dx - dy * dy)));
+        if (wo.z < 0.f) wi.z *= -1.f;
+        pdf = (wo.z * wi.z > 0.f) ? fabsf(wi.z) * RT_INV_PI : 0.f;
+        if (pdf == 0.f) return mk3(0.f);
+        sampled = BX_REFLECTION | BX_DIFFUSE;
+        wiW = to_world(v, wi);
+        f = mk3(0.f);
+        if (dot3(wiW, v.nn) * dot3(woW, v.nn) > 0) f = f + diffuse_f(m, wo, wi);
+        return f;
+    }
+    // specular lobes, in the order the material added them (glass.cpp:56-61, mirror.cpp:51-53)
+    bool reflect_has = m.has_r && ((BX_REFLECTION | BX_SPECULAR) & flags) == (BX_REFLECTION | BX_SPECULAR);
+    bool pick_reflect = reflect_has && which == 0;
+    if (pick_reflect) {
+        // SpecularReflection::Sample_f reflection.cpp:96-103
+        wi = mk3(-wo.x, -wo.y, wo.z);
+        pdf = 1.f;
+        float F = (m.type == RT_MAT_GLASS) ? fresnel_dielectric(wo.z, 1.f, m.ior) : 1.f;
+        f = div_s(mk3(F) * mat_color(m.r), fabsf(wi.z));
+        sampled = BX_REFLECTION | BX_SPECULAR;
+    } else {
+        // SpecularTransmission::Sample_f reflection.cpp:104-127
+        bool entering = wo.z > 0.f;
+        float ei = 1.f, et = m.ior;
+        if (!entering) { float tmp = ei; ei = et; et = tmp; }
+        float sini2 = sin_theta2(wo);
+        float eta = ei / et;
+        float sint2 = eta * eta * sini2;
+        if (sint2 >= 1.f) return mk3(0.f);                 // pdf stays 0
+        float cost = sqrtf(fmaxf(0.f, 1.f - sint2));
+        if (entering) cost = -cost;
+        wi = mk3(eta * -wo.x, eta * -wo.y, cost);
+        pdf = 1.f;
+        float F = fresnel_dielectric(wo.z, 1.f, m.ior);
+        f = div_s(((mk3(1.f) - mk3(F)) * ((et * et) / (ei * ei))) * mat_color(m.t), fabsf(wi.z));
+        sampled = BX_TRANSMISSION | BX_SPECULAR;
+    }
+    wiW = to_world(v, wi);
+    if (matching > 1) pdf /= matching;
+    return f;
+}
+
+// ---- lights ------------------------------------------------------------------------------
+RT_DEV void light_tri(const DevScene &sc, unsigned k, V3 &p1, V3 &p2, V3 &p3) {
+    const float *t = sc.light_tris + size_t(k) * 12;
+    p1 = mk3(t[0], t[1], t[2]); p2 = mk3(t[3], t[4], t[5]); p3 = mk3(t[6], t[7], t[8]);
+}
+
+// Shape::Pdf(p, wi) shape.h:96-107 evaluated on the emitter's own triangles:
+// ShapeSet::Intersect (shape.h:150-156) keeps the LAST triangle hit, the ray's maxt is never shortened.
+RT_DEV float area_light_pdf(const DevScene &sc, const DevLight &L, V3 p, V3 wi) {
+    bool any = false; float thit = 0.f; V3 nl = mk3(0.f);
+    for (unsigned k = 0; k < L.n_tris; ++k) {
+        V3 p1, p2, p3; light_tri(sc, L.first_tri + k, p1, p2, p3);
+        float t, b1, b2;
+        if (tri_test(p1, p2, p3, p, wi, RT_RAY_EPSILON, RT_INF, t, b1, b2)) {
+            any = true; thit = t;
+            V3 dpdu; tri_frame(p1, p2, p3, L.flip_normal != 0, nl, dpdu);
+        }
+    }
+    if (!any) return 0.f;
+    V3 ph = p + wi * thit;
+    V3 dd = p - ph;
+    float ad = absdot3(nl, -wi);
+    float pdf = (dd.x * dd.x + dd.y * dd.y + dd.z * dd.z) / (ad * L.area);
+    if (ad == 0.f) pdf = 0.f;
+    return pdf;
+}
+
+// AreaLight::L light.h:93-96
+RT_DEV V3 area_L(const DevLight &L, V3 n, V3 w) { return dot3(n, w) > 0 ? mat_color(L.color) : mk3(0.f); }
+
+// shape->Sample(p,u1,u2,&ns): ShapeSet::Sample shape.h:115-121 (one extra RandomFloat when the emitter has
+// more than one triangle) + Triangle::Sample trianglemesh.cpp:336-349 + UniformSampleTriangle mc.cpp:136-141
+template <class RNG>
+RT_DEV V3 area_sample_point(const DevScene &sc, const DevLight &L, float u1, float u2, RNG &rng, V3 &ns) {
+    unsigned k = 0;
+    if (L.n_tris > 1) {
+        float ls = rng.next_float();
+        for (k = 0; k < L.n_tris - 1; ++k)
+            if (ls < sc.light_tris[size_t(L.first_tri + k) * 12 + 10]) break;
+    }
+    V3 p1, p2, p3; light_tri(sc, L.first_tri + k, p1, p2, p3);
+    float su1 = sqrtf(u1);
+    float b1 = 1.f - su1, b2 = u2 * su1;
+    V3 ps = b1 * p1 + b2 * p2 + (1.f - b1 - b2) * p3;
+    ns = normalize3(cross3(p2 - p1, p3 - p1));
+    if (L.reverse_orientation) ns = ns * -1.f;
+    return ps;
+}
+
+}  // namespace rt

@@ -1,0 +1,145 @@
+// rt_traverse.h -- kd-tree traversal + ray/triangle test as a resumable per-lane state machine.
+//
+// Semantics follow KdTreeAccel::Intersect / IntersectP (reference accelerators/kdtree.cpp:313-488),
+// BBox::IntersectP (core/geometry.cpp:51-68) and Triangle::Intersect(P)
+// (shapes/trianglemesh.cpp:213-314); see SURVEY.md Appendix B items B6, B10-B12.
+// MI355X design points:
+//   * nodes are 8 B (one global_load_dwordx2 per visit), triangles 48 B (three dwordx4);
+//   * the todo stack lives in LDS as stack[entry][lane] (conflict-free ds_write_b64/ds_read_b64),
+//     8 B per entry {far child, tmax}: the popped tmin is always the tmax of the leaf just
+//     finished, because the leaves visited partition [tmin,tmax] contiguously, so it need not
+//     be stored (the reference stores 12 B + pointer);
+//   * entries beyond RT_STACK_LDS spill to HBM (counted), so depth is unbounded like MAX_TODO=64
+//     never is in practice (<= 17 at 1M triangles);
+//   * one step() = one node visit, so a wave can leave the loop when few lanes are still
+//     traversing and let the others shade / fetch new rays (persistent-thread scheme).
+//   * no mailboxing: re-testing a triangle returns the same t (ties accepted, B6).
+#pragma once
+#include "rt_device.h"
+
+#ifndef RT_STACK_LDS
+#define RT_STACK_LDS 24
+#endif
+#ifndef RT_BLOCK
+#define RT_BLOCK 256
+#endif
+
+namespace rt {
+
+struct Ray { V3 o, d; float mint, maxt; };
+
+struct Trav {
+    // ray being traced
+    V3 o, d, inv;
+    float mint, maxt;
+    // traversal cursor
+    unsigned node;
+    float tmin, tmax;
+    int sp;
+    // result
+    int hit_prim;       // closest: primitive index or -1; any: 0/-1
+    float b1, b2;
+    bool any;           // IntersectP semantics
+    bool active;
+};
+
+struct TravCounters { unsigned nodes, leaf_refs, tris, spills; };
+
+RT_DEV void tri_verts(const DevTri *tris, unsigned prim, V3 &p1, V3 &p2, V3 &p3, unsigned &bits, int &light) {
+    const float4 q0 = tris[prim].q0, q1 = tris[prim].q1, q2 = tris[prim].q2;
+    p1 = mk3(q0.x, q0.y, q0.z); p2 = mk3(q0.w, q1.x, q1.y); p3 = mk3(q1.z, q1.w, q2.x);
+    bits = __float_as_uint(q2.y); light = __float_as_int(q2.z);
+}
+
+// Triangle::Intersect up to the acceptance test (trianglemesh.cpp:213-246); exact comparison forms.
+RT_DEV bool tri_test(V3 p1, V3 p2, V3 p3, V3 o, V3 d, float mint, float maxt, float &t_out, float &b1_out, float &b2_out) {
+    V3 e1 = p2 - p1;
+    V3 e2 = p3 - p1;
+    V3 s1 = cross3(d, e2);
+    float divisor = dot3(s1, e1);
+    if (divisor == 0.f) return false;
+    float invDivisor = 1.f / divisor;
+    V3 dd = o - p1;
+    float b1 = dot3(dd, s1) * invDivisor;
+    if (b1 < 0.f || b1 > 1.f) return false;
+    V3 s2 = cross3(dd, e1);
+    float b2 = dot3(d, s2) * invDivisor;
+    if (b2 < 0.f || b1 + b2 > 1.f) return false;
+    float t = dot3(e2, s2) * invDivisor;
+    if (t < mint || t > maxt) return false;
+    t_out = t; b1_out = b1; b2_out = b2;
+    return true;
+}
+
+// start a traversal: slab-clip against the tree bounds (geometry.cpp:51-68, NaN-preserving ternaries)
+RT_DEV void trav_begin(Trav &tv, const DevScene &sc, const Ray &r, bool any) {
+    tv.o = r.o; tv.d = r.d; tv.mint = r.mint; tv.maxt = r.maxt; tv.any = any;
+    tv.hit_prim = -1; tv.b1 = 0.f; tv.b2 = 0.f; tv.sp = 0; tv.node = 0;
+    float t0 = r.mint, t1 = r.maxt;
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float invRayDir = 1.f / comp(r.d, i);
+        float tNear = (sc.bounds[i] - comp(r.o, i)) * invRayDir;
+        float tFar = (sc.bounds[3 + i] - comp(r.o, i)) * invRayDir;
+        if (tNear > tFar) { float tmp = tNear; tNear = tFar; tFar = tmp; }
+        t0 = tNear > t0 ? tNear : t0;
+        t1 = tFar < t1 ? tFar : t1;
+        if (t0 > t1) ok = false;     // reference returns at the first failing slab; later slabs cannot un-fail it
+    }
+    tv.tmin = t0; tv.tmax = t1;
+    tv.inv = mk3(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z);
+    tv.active = ok && sc.n_tris > 0;
+}
+
+// one node visit
+template <bool COUNT>
+RT_DEV void trav_step(Trav &tv, const DevScene &sc, uint2 *lds_stack, uint2 *spill, unsigned n_threads,
+                      unsigned gtid, TravCounters &cnt) {
+    if (!tv.any && tv.maxt < tv.tmin) { tv.active = false; return; }      // kdtree.cpp:330
+    const uint2 nd = sc.nodes[tv.node];
+    if (COUNT) ++cnt.nodes;
+    if ((nd.x & 3u) != 3u) {
+        const int axis = int(nd.x & 3u);
+        const float split = __uint_as_float(nd.x);                         // perturbed split, B10
+        const float oa = comp(tv.o, axis), da = comp(tv.d, axis);
+        const float tplane = (split - oa) * comp(tv.inv, axis);
+        const bool belowFirst = (oa < split) || (oa == split && da >= 0.f);
+        const unsigned first = belowFirst ? tv.node + 1 : nd.y;
+        const unsigned second = belowFirst ? nd.y : tv.node + 1;
+        if (tplane > tv.tmax || tplane <= 0.f) tv.node = first;
+        else if (tplane < tv.tmin) tv.node = second;
+        else {
+            const uint2 e = make_uint2(second, __float_as_uint(tv.tmax));
+            if (tv.sp < RT_STACK_LDS) lds_stack[tv.sp * RT_BLOCK + threadIdx.x] = e;
+            else { spill[size_t(tv.sp - RT_STACK_LDS) * n_threads + gtid] = e; if (COUNT) ++cnt.spills; }
+            ++tv.sp;
+            tv.node = first;
+            tv.tmax = tplane;
+        }
+        return;
+    }
+    // leaf
+    const unsigned np = nd.x >> 2;
+    for (unsigned i = 0; i < np; ++i) {
+        const unsigned prim = (np == 1) ? nd.y : sc.leaf_refs[nd.y + i];
+        if (COUNT) { ++cnt.tris; if (np > 1) ++cnt.leaf_refs; }
+        V3 p1, p2, p3; unsigned bits; int light;
+        tri_verts(sc.tris, prim, p1, p2, p3, bits, light);
+        float t, b1, b2;
+        if (tri_test(p1, p2, p3, tv.o, tv.d, tv.mint, tv.maxt, t, b1, b2)) {
+            if (tv.any) { tv.hit_prim = 0; tv.active = false; return; }    // kdtree.cpp:432-434
+            tv.maxt = t; tv.hit_prim = int(prim); tv.b1 = b1; tv.b2 = b2;  // primitive.cpp:120
+        }
+    }
+    if (tv.sp > 0) {
+        --tv.sp;
+        const uint2 e = (tv.sp < RT_STACK_LDS) ? lds_stack[tv.sp * RT_BLOCK + threadIdx.x]
+                                                : spill[size_t(tv.sp - RT_STACK_LDS) * n_threads + gtid];
+        tv.node = e.x;
+        tv.tmin = tv.tmax;
+        tv.tmax = __uint_as_float(e.y);
+    } else tv.active = false;
+}
+
+}  // namespace rt

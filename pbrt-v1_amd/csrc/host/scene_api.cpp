@@ -1,0 +1,534 @@
+// scene_api.cpp -- see scene_api.h.  Citations are to the reference tree (/root/reference).
+#include "scene_api.h"
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace pbrthip {
+
+// ------------------------------------------------------------------ diagnostics (core/util.cpp:36-97)
+static int g_warnings = 0, g_errors = 0; static bool g_quiet = false;
+int WarningCount() { return g_warnings; }
+int ErrorCount() { return g_errors; }
+void ResetDiagnostics() { g_warnings = g_errors = 0; }
+void SetQuiet(bool q) { g_quiet = q; }
+void Warning(const char *fmt, ...) {
+    ++g_warnings; if (g_quiet) return;
+    va_list a; va_start(a, fmt); std::fprintf(stderr, "Warning: "); std::vfprintf(stderr, fmt, a); std::fprintf(stderr, "\n"); va_end(a);
+}
+void Error(const char *fmt, ...) {
+    ++g_errors; if (g_quiet) return;
+    va_list a; va_start(a, fmt); std::fprintf(stderr, "Error: "); std::vfprintf(stderr, fmt, a); std::fprintf(stderr, "\n"); va_end(a);
+}
+
+// ------------------------------------------------------------------ filters (filters/*.cpp)
+float Filter::Evaluate(float x, float y) const {
+    if (name == "box") return 1.f;                                                  // box.cpp:36-38
+    if (name == "triangle")                                                         // triangle.cpp:36-39
+        return std::fmax(0.f, xWidth - std::fabs(x)) * std::fmax(0.f, yWidth - std::fabs(y));
+    if (name == "gaussian") {                                                       // gaussian.cpp:29-50
+        const float alpha = p0, expX = p1, expY = p2;
+        float gx = std::fmax(0.f, float(expf(-alpha * x * x) - expX));
+        float gy = std::fmax(0.f, float(expf(-alpha * y * y) - expY));
+        return gx * gy;
+    }
+    if (name == "mitchell") {                                                       // mitchell.cpp:34-51
+        const float B = p0, C = p1;
+        auto m1 = [B, C](float v) {
+            v = std::fabs(2.f * v);
+            if (v > 1.f) return ((-B - 6 * C) * v * v * v + (6 * B + 30 * C) * v * v + (-12 * B - 48 * C) * v + (8 * B + 24 * C)) * (1.f / 6.f);
+            return ((12 - 9 * B - 6 * C) * v * v * v + (-18 + 12 * B + 6 * C) * v * v + (6 - 2 * B)) * (1.f / 6.f);
+        };
+        return m1(x * invXWidth) * m1(y * invYWidth);
+    }
+    if (name == "sinc") {                                                           // sinc.cpp:41-53
+        const float tau = p0;
+        auto s1 = [tau](float v) {
+            v = std::fabs(v);
+            if (v < 1e-5) return 1.f;
+            if (v > 1.) return 0.f;
+            v *= 3.14159265358979323846f;
+            float sinc = sinf(v * tau) / (v * tau);
+            float lanczos = sinf(v) / v;
+            return sinc * lanczos;
+        };
+        return s1(x * invXWidth) * s1(y * invYWidth);
+    }
+    return 1.f;
+}
+
+Filter MakeFilter(const std::string &name, const ParamSet &ps, bool *ok) {
+    Filter f; f.name = name; *ok = true;
+    float xw, yw;
+    if (name == "box") { xw = ps.FindOneFloat("xwidth", .5f); yw = ps.FindOneFloat("ywidth", .5f); }
+    else if (name == "triangle") { xw = ps.FindOneFloat("xwidth", 2.); yw = ps.FindOneFloat("ywidth", 2.); }
+    else if (name == "gaussian") {
+        xw = ps.FindOneFloat("xwidth", 2.); yw = ps.FindOneFloat("ywidth", 2.);
+        f.p0 = ps.FindOneFloat("alpha", 2.f);
+        f.p1 = expf(-f.p0 * xw * xw); f.p2 = expf(-f.p0 * yw * yw);
+    } else if (name == "mitchell") {
+        xw = ps.FindOneFloat("xwidth", 2.); yw = ps.FindOneFloat("ywidth", 2.);
+        f.p0 = ps.FindOneFloat("B", 1.f / 3.f); f.p1 = ps.FindOneFloat("C", 1.f / 3.f);
+    } else if (name == "sinc") {
+        xw = ps.FindOneFloat("xwidth", 4.); yw = ps.FindOneFloat("ywidth", 4.);
+        f.p0 = ps.FindOneFloat("tau", 3.f);
+    } else { Error("Unable to load plugin \"%s\" (pixel filter)", name.c_str()); *ok = false; xw = yw = .5f; f.name = "box"; }
+    f.xWidth = xw; f.yWidth = yw; f.invXWidth = 1.f / xw; f.invYWidth = 1.f / yw;
+    ps.ReportUnused();
+    return f;
+}
+
+// ------------------------------------------------------------------ film (film/image.cpp:69-101,148-156,213-233)
+static int ceil2int(double v) { return int(std::ceil(v)); }
+static int floor2int(double v) { return int(std::floor(v)); }
+
+Film MakeFilm(const std::string &name, const ParamSet &ps, const Filter &filt, bool *ok) {
+    Film f; *ok = true;
+    if (name != "image") { Error("Unable to load plugin \"%s\" (film)", name.c_str()); *ok = false; }
+    f.filename = ps.FindOneString("filename", "pbrt.exr");
+    f.premultiplyAlpha = ps.FindOneBool("premultiplyalpha", true);
+    f.xResolution = ps.FindOneInt("xresolution", 640);
+    f.yResolution = ps.FindOneInt("yresolution", 480);
+    float crop[4] = {0, 1, 0, 1};
+    int cwi; const float *cr = ps.FindFloat("cropwindow", &cwi);
+    auto clamp01 = [](float v) { return v < 0.f ? 0.f : (v > 1.f ? 1.f : v); };
+    if (cr && cwi == 4) {
+        crop[0] = clamp01(std::fmin(cr[0], cr[1])); crop[1] = clamp01(std::fmax(cr[0], cr[1]));
+        crop[2] = clamp01(std::fmin(cr[2], cr[3])); crop[3] = clamp01(std::fmax(cr[2], cr[3]));
+    }
+    f.writeFrequency = ps.FindOneInt("writefrequency", -1);
+    std::memcpy(f.cropWindow, crop, sizeof crop);
+    f.xPixelStart = ceil2int(f.xResolution * crop[0]);
+    f.xPixelCount = std::max(1, ceil2int(f.xResolution * crop[1]) - f.xPixelStart);
+    f.yPixelStart = ceil2int(f.yResolution * crop[2]);
+    f.yPixelCount = std::max(1, ceil2int(f.yResolution * crop[3]) - f.yPixelStart);
+    f.filter = filt;
+    float *ftp = f.filterTable;
+    for (int y = 0; y < 16; ++y) {
+        float fy = ((float)y + .5f) * filt.yWidth / 16;
+        for (int x = 0; x < 16; ++x) {
+            float fx = ((float)x + .5f) * filt.xWidth / 16;
+            *ftp++ = filt.Evaluate(fx, fy);
+        }
+    }
+    ps.ReportUnused();
+    return f;
+}
+void Film::GetSampleExtent(int *xs, int *xe, int *ys, int *ye) const {
+    *xs = floor2int(xPixelStart + .5f - filter.xWidth);
+    *xe = floor2int(xPixelStart + .5f + xPixelCount + filter.xWidth);
+    *ys = floor2int(yPixelStart + .5f - filter.yWidth);
+    *ye = floor2int(yPixelStart + .5f + yPixelCount + filter.yWidth);
+}
+
+// ------------------------------------------------------------------ samplers
+Sampler MakeSampler(const std::string &nameIn, const ParamSet &ps, const Film &, bool *ok) {
+    Sampler s; *ok = true; s.seed = 0; s.pixelsamples = 4; s.xsamples = s.ysamples = 2; s.jitter = true;
+    std::string name = nameIn;
+    if (name == "keyed") {     // oracle-side wrapper (oracle/ref/keyed_sampler.cpp): this renderer's RNG is always keyed
+        name = ps.FindOneString("inner", "stratified");
+        s.seed = unsigned(ps.FindOneInt("seed", 0));
+    }
+    if (name == "stratified") {                                                     // stratified.cpp:132-141
+        s.kind = RT_SAMPLER_STRATIFIED;
+        s.jitter = ps.FindOneBool("jitter", true);
+        s.xsamples = ps.FindOneInt("xsamples", 2); s.ysamples = ps.FindOneInt("ysamples", 2);
+    } else if (name == "lowdiscrepancy") {                                          // lowdiscrepancy.cpp:129-136
+        s.kind = RT_SAMPLER_LOWDISCREPANCY; s.pixelsamples = ps.FindOneInt("pixelsamples", 4);
+    } else if (name == "random") {                                                  // random.cpp:118-126
+        s.kind = RT_SAMPLER_RANDOM; s.xsamples = ps.FindOneInt("xsamples", 2); s.ysamples = ps.FindOneInt("ysamples", 2);
+    } else { Error("Unable to load plugin \"%s\" (sampler)", name.c_str()); *ok = false; s.kind = RT_SAMPLER_STRATIFIED; }
+    ps.ReportUnused();
+    return s;
+}
+
+// ------------------------------------------------------------------ integrators
+SurfaceIntegrator MakeSurfaceIntegrator(const std::string &name, const ParamSet &ps, bool *ok) {
+    SurfaceIntegrator si; *ok = true; si.strategy = RT_STRATEGY_ALL;
+    si.maxDepth = ps.FindOneInt("maxdepth", 5);              // whitted.cpp:143, directlighting.cpp:196, path.cpp:147
+    if (name == "whitted") si.kind = RT_INTEGRATOR_WHITTED;
+    else if (name == "path") si.kind = RT_INTEGRATOR_PATH;
+    else if (name == "directlighting") {                     // directlighting.cpp:195-208
+        si.kind = RT_INTEGRATOR_DIRECT;
+        std::string st = ps.FindOneString("strategy", "all");
+        if (st == "one") si.strategy = RT_STRATEGY_ONE;
+        else if (st == "all") si.strategy = RT_STRATEGY_ALL;
+        else if (st == "weighted") {
+            Warning("Strategy \"weighted\" keeps a sequentially updated light CDF (directlighting.cpp:75-76, "
+                    "transport.cpp:71-122) that has no parallel definition; using \"one\".");
+            si.strategy = RT_STRATEGY_ONE;
+        } else { Warning("Strategy \"%s\" for direct lighting unknown. Using \"all\".", st.c_str()); si.strategy = RT_STRATEGY_ALL; }
+    } else { Error("Unable to load plugin \"%s\" (surface integrator)", name.c_str()); *ok = false; si.kind = RT_INTEGRATOR_WHITTED; }
+    ps.ReportUnused();
+    return si;
+}
+VolumeIntegrator MakeVolumeIntegrator(const std::string &name, const ParamSet &ps, bool *ok) {
+    VolumeIntegrator vi; *ok = true;
+    vi.stepSize = ps.FindOneFloat("stepsize", 1.f);          // emission.cpp:97, single.cpp:118
+    if (name == "emission") vi.kind = RT_VOLUME_EMISSION;
+    else if (name == "single") vi.kind = RT_VOLUME_SINGLE;
+    else { Error("Unable to load plugin \"%s\" (volume integrator)", name.c_str()); *ok = false; vi.kind = RT_VOLUME_EMISSION; }
+    ps.ReportUnused();
+    return vi;
+}
+Accelerator MakeAccelerator(const std::string &nameIn, const ParamSet &ps, bool *ok) {
+    Accelerator a; *ok = true; std::memset(&a.params, 0, sizeof a.params);
+    std::string name = nameIn;
+    if (name == "countaccel") name = ps.FindOneString("inner", "kdtree");   // oracle-side wrapper; rays are always counted here
+    a.params.kind = RT_ACCEL_KDTREE;
+    if (name == "grid") {
+        a.params.kind = RT_ACCEL_GRID;
+        ps.FindOneBool("refineimmediately", false);
+    } else if (name != "kdtree") { Error("Unable to load plugin \"%s\" (accelerator)", name.c_str()); *ok = false; }
+    a.params.isect_cost = ps.FindOneInt("intersectcost", 80);              // kdtree.cpp:491-495
+    a.params.trav_cost = ps.FindOneInt("traversalcost", 1);
+    a.params.empty_bonus = ps.FindOneFloat("emptybonus", 0.5f);
+    a.params.max_prims = ps.FindOneInt("maxprims", 1);
+    a.params.max_depth = ps.FindOneInt("maxdepth", -1);
+    a.params.build_threads = ps.FindOneInt("buildthreads", 0);
+    ps.ReportUnused();
+    return a;
+}
+
+// ------------------------------------------------------------------ camera (perspective.cpp:83-115, camera.cpp:50-70)
+bool MakeCamera(const std::string &name, const ParamSet &ps, const Xform &world2cam, const Film &film, RtCamera *out) {
+    if (name != "perspective") { Error("Unable to load plugin \"%s\" (camera): only \"perspective\" is on the accelerated path", name.c_str()); return false; }
+    float hither = std::fmax(1e-4f, ps.FindOneFloat("hither", 1e-3f));
+    float yon = std::fmin(ps.FindOneFloat("yon", 1e30f), 1e30f);
+    float shutteropen = ps.FindOneFloat("shutteropen", 0.f);
+    float shutterclose = ps.FindOneFloat("shutterclose", 1.f);
+    float lensradius = ps.FindOneFloat("lensradius", 0.f);
+    float focaldistance = ps.FindOneFloat("focaldistance", 1e30f);
+    float frame = ps.FindOneFloat("frameaspectratio", float(film.xResolution) / float(film.yResolution));
+    float screen[4];
+    if (frame > 1.f) { screen[0] = -frame; screen[1] = frame; screen[2] = -1.f; screen[3] = 1.f; }
+    else { screen[0] = -1.f; screen[1] = 1.f; screen[2] = -1.f / frame; screen[3] = 1.f / frame; }
+    int swi; const float *sw = ps.FindFloat("screenwindow", &swi);
+    if (sw && swi == 4) std::memcpy(screen, sw, 4 * sizeof(float));
+    float fov = ps.FindOneFloat("fov", 90.);
+    ps.ReportUnused();
+    Xform cameraToScreen = Perspective(fov, hither, yon);
+    Xform screenToRaster = Scale(float(film.xResolution), float(film.yResolution), 1.f) *
+                           Scale(1.f / (screen[1] - screen[0]), 1.f / (screen[2] - screen[3]), 1.f) *
+                           Translate(-screen[0], -screen[3], 0.f);
+    Xform rasterToScreen = screenToRaster.inverse();
+    Xform rasterToCamera = cameraToScreen.inverse() * rasterToScreen;
+    Xform cameraToWorld = world2cam.inverse();
+    std::memcpy(out->raster_to_camera, rasterToCamera.m.m, 16 * sizeof(float));
+    std::memcpy(out->camera_to_world, cameraToWorld.m.m, 16 * sizeof(float));
+    out->lens_radius = lensradius; out->focal_distance = focaldistance; out->hither = hither; out->yon = yon;
+    out->shutter_open = shutteropen; out->shutter_close = shutterclose;
+    return true;
+}
+
+// ------------------------------------------------------------------ API state machine (core/api.cpp)
+void SceneDescription::finalize_pointers() {
+    scene.n_tris = uint32_t(tri_material.size());
+    scene.tri_verts = tri_verts.data(); scene.tri_material = tri_material.data();
+    scene.tri_light = tri_light.data(); scene.tri_flags = tri_flags.data();
+    scene.n_materials = uint32_t(materials.size()); scene.materials = materials.data();
+    scene.n_lights = uint32_t(lights.size()); scene.lights = lights.data();
+    scene.n_light_tris = uint32_t(light_tris.size() / 9); scene.light_tris = light_tris.data();
+}
+
+PbrtApi::PbrtApi() : state(STATE_OPTIONS), nVolumes(0), inObject(false) {
+    // RenderOptions defaults api.cpp:62-71.  The reference's default sampler is "bestcandidate" (a
+    // precomputed 4096-entry tile pattern, samplers/bestcandidate.cpp) which is out of scope; scenes for
+    // this path name their sampler explicitly, and an unnamed one gets the reference's 2x2 stratified.
+    filterOpt.name = "mitchell"; filmOpt.name = "image"; samplerOpt.name = "stratified"; accelOpt.name = "kdtree";
+    surfOpt.name = "directlighting"; volOpt.name = "emission"; cameraOpt.name = "perspective";
+    std::memset(&volume, 0, sizeof volume);
+}
+PbrtApi::~PbrtApi() { for (SceneDescription *f : frames) delete f; }
+void PbrtApi::Diagnostic(int severity, const std::string &msg) { if (severity) Error("%s", msg.c_str()); else Warning("%s", msg.c_str()); }
+
+bool PbrtApi::verifyOptions(const char *fn) {
+    if (state == STATE_WORLD) { Error("Options cannot be set inside world block; \"%s\" not allowed.  Ignoring.", fn); return false; }
+    return true;
+}
+bool PbrtApi::verifyWorld(const char *fn) {
+    if (state == STATE_OPTIONS) { Error("Scene description must be inside world block; \"%s\" not allowed. Ignoring.", fn); return false; }
+    return true;
+}
+void PbrtApi::Identity() { ctm = Xform(); }
+void PbrtApi::Translate(float x, float y, float z) { ctm = ctm * pbrthip::Translate(x, y, z); }
+void PbrtApi::Rotate(float a, float x, float y, float z) { ctm = ctm * pbrthip::Rotate(a, x, y, z); }
+void PbrtApi::Scale(float x, float y, float z) { ctm = ctm * pbrthip::Scale(x, y, z); }
+void PbrtApi::LookAt(const float v[9]) { ctm = ctm * pbrthip::LookAt(v, v + 3, v + 6); }
+static Mat4 from_column_major(const float t[16]) {                                  // api.cpp:179-194
+    return Mat4(t[0], t[4], t[8], t[12], t[1], t[5], t[9], t[13], t[2], t[6], t[10], t[14], t[3], t[7], t[11], t[15]);
+}
+void PbrtApi::ConcatTransform(const float m[16]) { ctm = ctm * Xform(from_column_major(m)); }
+void PbrtApi::Transform(const float m[16]) { ctm = Xform(from_column_major(m)); }
+void PbrtApi::CoordinateSystem(const std::string &n) { named[n] = ctm; }
+void PbrtApi::CoordSysTransform(const std::string &n) { if (named.count(n)) ctm = named[n]; }
+void PbrtApi::PixelFilter(const std::string &n, const ParamList &p) { if (verifyOptions("PixelFilter")) { filterOpt.name = n; filterOpt.params = ParamSet(p); } }
+void PbrtApi::Film(const std::string &n, const ParamList &p) { if (verifyOptions("Film")) { filmOpt.name = n; filmOpt.params = ParamSet(p); } }
+void PbrtApi::Sampler(const std::string &n, const ParamList &p) { if (verifyOptions("Sampler")) { samplerOpt.name = n; samplerOpt.params = ParamSet(p); } }
+void PbrtApi::Accelerator(const std::string &n, const ParamList &p) { if (verifyOptions("Accelerator")) { accelOpt.name = n; accelOpt.params = ParamSet(p); } }
+void PbrtApi::SurfaceIntegrator(const std::string &n, const ParamList &p) { if (verifyOptions("SurfaceIntegrator")) { surfOpt.name = n; surfOpt.params = ParamSet(p); } }
+void PbrtApi::VolumeIntegrator(const std::string &n, const ParamList &p) { if (verifyOptions("VolumeIntegrator")) { volOpt.name = n; volOpt.params = ParamSet(p); } }
+void PbrtApi::Camera(const std::string &n, const ParamList &p) {
+    if (!verifyOptions("Camera")) return;
+    cameraOpt.name = n; cameraOpt.params = ParamSet(p);
+    worldToCamera = ctm; named["camera"] = ctm.inverse();
+}
+void PbrtApi::SearchPath(const std::string &) { verifyOptions("SearchPath"); /* plugins are compiled in */ }
+void PbrtApi::WorldBegin() {
+    if (!verifyOptions("WorldBegin")) return;
+    state = STATE_WORLD; ctm = Xform(); named["world"] = ctm;
+}
+void PbrtApi::AttributeBegin() { if (!verifyWorld("AttributeBegin")) return; gsStack.push_back(gs); xfStack.push_back(ctm); }
+void PbrtApi::AttributeEnd() {
+    if (!verifyWorld("AttributeEnd")) return;
+    if (gsStack.empty()) { Error("Unmatched pbrtAttributeEnd() encountered. Ignoring it."); return; }
+    gs = gsStack.back(); ctm = xfStack.back(); gsStack.pop_back(); xfStack.pop_back();
+}
+void PbrtApi::TransformBegin() { if (verifyWorld("TransformBegin")) xfStack.push_back(ctm); }
+void PbrtApi::TransformEnd() {
+    if (!verifyWorld("TransformEnd")) return;
+    if (xfStack.empty()) { Error("Unmatched pbrtTransformEnd() encountered. Ignoring it."); return; }
+    ctm = xfStack.back(); xfStack.pop_back();
+}
+void PbrtApi::Texture(const std::string &name, const std::string &type, const std::string &cls, const ParamList &p) {
+    if (!verifyWorld("Texture")) return;
+    ParamSet ps(p);
+    if (cls != "constant") {                 // textures/*.cpp other than constant.cpp are out of scope
+        Error("Unable to load plugin \"%s\" (texture): only \"constant\" textures are on the accelerated path", cls.c_str());
+        return;
+    }
+    if (type == "float") gs.floatTextures[name] = ps.FindOneFloat("value", 1.f);            // textures/constant.cpp
+    else if (type == "color") gs.spectrumTextures[name] = ps.FindOneSpectrum("value", Float3{1.f, 1.f, 1.f});
+    else Error("Texture type \"%s\" unknown.", type.c_str());
+}
+void PbrtApi::Material(const std::string &n, const ParamList &p) { if (verifyWorld("Material")) { gs.material = n; gs.materialParams = ParamSet(p); } }
+void PbrtApi::AreaLightSource(const std::string &n, const ParamList &p) { if (verifyWorld("AreaLightSource")) { gs.areaLight = n; gs.areaLightParams = ParamSet(p); } }
+void PbrtApi::ReverseOrientation() { if (verifyWorld("ReverseOrientation")) gs.reverseOrientation = !gs.reverseOrientation; }
+
+void PbrtApi::LightSource(const std::string &n, const ParamList &p) {
+    if (!verifyWorld("LightSource")) return;
+    ParamSet ps(p);
+    if (n != "point") { Error("pbrtLightSource: light type \"%s\" unknown.", n.c_str()); return; }
+    // CreateLight lights/point.cpp:78-84 + PointLight ctor :49-54
+    Float3 I = ps.FindOneSpectrum("I", Float3{1.f, 1.f, 1.f});
+    Float3 P = ps.FindOnePoint("from", Float3{0, 0, 0});
+    Xform l2w = pbrthip::Translate(P.x, P.y, P.z) * ctm;
+    ps.ReportUnused();
+    RtLight L; std::memset(&L, 0, sizeof L);
+    L.type = RT_LIGHT_POINT; L.color[0] = I.x; L.color[1] = I.y; L.color[2] = I.z; L.n_samples = 1;
+    const float origin[3] = {0, 0, 0}; l2w.point(origin, L.pos);
+    lights.push_back(L);
+}
+
+Float3 PbrtApi::spectrumParam(const ParamSet &geom, const ParamSet &mat, const std::string &n, Float3 d) {   // paramset.cpp:434-449
+    std::string tex = geom.FindTexture(n); if (tex.empty()) tex = mat.FindTexture(n);
+    if (!tex.empty()) {
+        if (gs.spectrumTextures.count(tex)) return gs.spectrumTextures[tex];
+        Error("Couldn't find spectrumtexture named \"%s\"", n.c_str());
+    }
+    return geom.FindOneSpectrum(n, mat.FindOneSpectrum(n, d));
+}
+float PbrtApi::floatParam(const ParamSet &geom, const ParamSet &mat, const std::string &n, float d) {         // paramset.cpp:450-465
+    std::string tex = geom.FindTexture(n); if (tex.empty()) tex = mat.FindTexture(n);
+    if (!tex.empty()) {
+        if (gs.floatTextures.count(tex)) return gs.floatTextures[tex];
+        Error("Couldn't find float texture named \"%s\"", n.c_str());
+    }
+    return geom.FindOneFloat(n, mat.FindOneFloat(n, d));
+}
+
+int PbrtApi::makeMaterial(const ParamSet &shapeParams) {
+    auto clamp0 = [](Float3 c) { Float3 r = {c.x < 0.f ? 0.f : c.x, c.y < 0.f ? 0.f : c.y, c.z < 0.f ? 0.f : c.z}; return r; };
+    RtMaterial m; std::memset(&m, 0, sizeof m);
+    std::string name = gs.material;
+    if (name != "matte" && name != "mirror" && name != "glass") {
+        Error("Unable to load plugin \"%s\" (material); using \"matte\" (api.cpp:376-379)", name.c_str());
+        name = "matte";
+    }
+    const ParamSet &mp = gs.materialParams;
+    if (floatParam(shapeParams, mp, "bumpmap", 0.f) != 0.f)
+        Warning("Non-zero constant \"bumpmap\" displaces uniformly and leaves the shading frame unchanged");
+    if (name == "matte") {                                                          // matte.cpp:46-71
+        Float3 kd = clamp0(spectrumParam(shapeParams, mp, "Kd", Float3{1.f, 1.f, 1.f}));
+        float sig = floatParam(shapeParams, mp, "sigma", 0.f); sig = sig < 0.f ? 0.f : (sig > 90.f ? 90.f : sig);
+        m.type = RT_MAT_MATTE; m.kd[0] = kd.x; m.kd[1] = kd.y; m.kd[2] = kd.z; m.sigma = sig; m.ior = 1.f;
+    } else if (name == "mirror") {                                                  // mirror.cpp:42-61
+        Float3 kr = clamp0(spectrumParam(shapeParams, mp, "Kr", Float3{1.f, 1.f, 1.f}));
+        m.type = RT_MAT_MIRROR; m.kd[0] = kr.x; m.kd[1] = kr.y; m.kd[2] = kr.z; m.ior = 1.f;
+    } else {                                                                        // glass.cpp:46-70
+        Float3 kr = clamp0(spectrumParam(shapeParams, mp, "Kr", Float3{1.f, 1.f, 1.f}));
+        Float3 kt = clamp0(spectrumParam(shapeParams, mp, "Kt", Float3{1.f, 1.f, 1.f}));
+        m.type = RT_MAT_GLASS; m.kd[0] = kr.x; m.kd[1] = kr.y; m.kd[2] = kr.z; m.kt[0] = kt.x; m.kt[1] = kt.y; m.kt[2] = kt.z;
+        m.ior = floatParam(shapeParams, mp, "index", 1.5f);
+    }
+    materials.push_back(m);
+    return int(materials.size()) - 1;
+}
+
+void PbrtApi::Shape(const std::string &n, const ParamList &p) {                     // api.cpp:354-396
+    if (!verifyWorld("Shape")) return;
+    ParamSet ps(p);
+    if (n != "trianglemesh") {
+        Error("Unable to load plugin \"%s\" (shape): only \"trianglemesh\" is on the accelerated path (SURVEY.md rows 12-13)", n.c_str());
+        return;
+    }
+    // CreateShape shapes/trianglemesh.cpp:350-406
+    int nvi = 0, npi = 0, nuvi = 0;
+    const int *vi = ps.FindInt("indices", &nvi);
+    const Float3 *P = ps.FindPoint("P", &npi);
+    const float *uvs = ps.FindFloat("uv", &nuvi); if (!uvs) uvs = ps.FindFloat("st", &nuvi);
+    if (!vi || !P) return;
+    int nni = 0, nsi = 0;
+    const Float3 *N = ps.FindNormal("N", &nni); const Float3 *S = ps.FindVector("S", &nsi);
+    if (uvs || N || S)
+        Warning("trianglemesh \"uv\"/\"N\"/\"S\" are ignored: per-vertex shading data is not on the accelerated path (constant textures only)");
+    for (int i = 0; i < nvi; ++i)
+        if (vi[i] >= npi || vi[i] < 0) { Error("trianglemesh has out of-bounds vertex index %d (%d \"P\" values were given", vi[i], npi); return; }
+    if (inObject) { Error("Object instancing is not on the accelerated path (SURVEY.md row 9); shape ignored"); return; }
+    ps.ReportUnused();
+    const int ntris = nvi / 3;
+    std::vector<float> world(size_t(npi) * 3);
+    for (int i = 0; i < npi; ++i) ctm.point(&P[i].x, &world[size_t(3) * i]);        // trianglemesh.cpp:166-168
+    Mesh mesh;
+    mesh.flags = uint8_t((gs.reverseOrientation ^ ctm.swaps_handedness()) ? 1 : 0);   // shape.cpp:27-35,49-50
+    mesh.verts.resize(size_t(ntris) * 9);
+    for (int t = 0; t < ntris; ++t)
+        for (int k = 0; k < 3; ++k) std::memcpy(&mesh.verts[size_t(t) * 9 + 3 * k], &world[size_t(3) * vi[3 * t + k]], 3 * sizeof(float));
+    mesh.light = -1;
+    if (!gs.areaLight.empty()) {                                                    // api.cpp:362-366, area.cpp:106-111
+        if (gs.areaLight != "area") Error("Unable to load plugin \"%s\" (area light)", gs.areaLight.c_str());
+        else if (ntris > 0) {
+            Float3 Le = gs.areaLightParams.FindOneSpectrum("L", Float3{1.f, 1.f, 1.f});
+            int ns = gs.areaLightParams.FindOneInt("nsamples", 1);
+            RtLight L; std::memset(&L, 0, sizeof L);
+            L.type = RT_LIGHT_AREA; L.color[0] = Le.x; L.color[1] = Le.y; L.color[2] = Le.z; L.n_samples = std::max(1, ns);
+            L.first_tri = uint32_t(light_tris.size() / 9); L.n_tris = uint32_t(ntris);
+            L.reverse_orientation = gs.reverseOrientation ? 1 : 0; L.flip_normal = mesh.flags;
+            // AreaLight ctor area.cpp:33-54: the refinement stack pops the LAST triangle first
+            for (int t = ntris - 1; t >= 0; --t) light_tris.insert(light_tris.end(), &mesh.verts[size_t(t) * 9], &mesh.verts[size_t(t) * 9] + 9);
+            mesh.light = int(lights.size());
+            lights.push_back(L);
+        }
+    }
+    mesh.material = makeMaterial(ps);
+    meshes.push_back(std::move(mesh));
+}
+
+void PbrtApi::Volume(const std::string &n, const ParamList &p) {                    // api.cpp:403-409, homogeneous.cpp:76-88
+    if (!verifyWorld("Volume")) return;
+    ParamSet ps(p);
+    if (n != "homogeneous") { Error("Unable to load plugin \"%s\" (volume region): only \"homogeneous\" is on the accelerated path", n.c_str()); return; }
+    if (nVolumes++ > 0) { Error("Only one volume region is supported on the accelerated path (AggregateVolume is out of scope)"); return; }
+    Float3 sa = ps.FindOneSpectrum("sigma_a", Float3{0, 0, 0}), ss = ps.FindOneSpectrum("sigma_s", Float3{0, 0, 0});
+    float g = ps.FindOneFloat("g", 0.);
+    Float3 Le = ps.FindOneSpectrum("Le", Float3{0, 0, 0});
+    Float3 p0 = ps.FindOnePoint("p0", Float3{0, 0, 0}), p1 = ps.FindOnePoint("p1", Float3{1, 1, 1});
+    ps.ReportUnused();
+    volume.present = 1;
+    Xform w2v = ctm.inverse();
+    std::memcpy(volume.world_to_volume, w2v.m.m, 16 * sizeof(float));
+    // BBox(p0,p1) geometry.h:237-244
+    volume.p0[0] = std::fmin(p0.x, p1.x); volume.p0[1] = std::fmin(p0.y, p1.y); volume.p0[2] = std::fmin(p0.z, p1.z);
+    volume.p1[0] = std::fmax(p0.x, p1.x); volume.p1[1] = std::fmax(p0.y, p1.y); volume.p1[2] = std::fmax(p0.z, p1.z);
+    volume.sigma_a[0] = sa.x; volume.sigma_a[1] = sa.y; volume.sigma_a[2] = sa.z;
+    volume.sigma_s[0] = ss.x; volume.sigma_s[1] = ss.y; volume.sigma_s[2] = ss.z;
+    volume.le[0] = Le.x; volume.le[1] = Le.y; volume.le[2] = Le.z; volume.g = g;
+}
+void PbrtApi::ObjectBegin(const std::string &) { if (!verifyWorld("ObjectBegin")) return; AttributeBegin(); inObject = true; }
+void PbrtApi::ObjectEnd() { if (!verifyWorld("ObjectEnd")) return; inObject = false; AttributeEnd(); }
+void PbrtApi::ObjectInstance(const std::string &n) { if (verifyWorld("ObjectInstance")) Error("Object instancing is not on the accelerated path; instance \"%s\" ignored", n.c_str()); }
+
+void PbrtApi::resetWorld() {
+    meshes.clear(); materials.clear(); lights.clear(); light_tris.clear();
+    std::memset(&volume, 0, sizeof volume); nVolumes = 0;
+}
+
+void PbrtApi::WorldEnd() {                                                          // api.cpp:458-529
+    if (!verifyWorld("WorldEnd")) return;
+    while (!gsStack.empty()) { Warning("Missing end to pbrtAttributeBegin()"); gsStack.pop_back(); xfStack.pop_back(); }
+    SceneDescription *sd = new SceneDescription();
+    bool ok, all = true;
+    Filter filter = MakeFilter(filterOpt.name, filterOpt.params, &ok); all &= ok;
+    sd->film = MakeFilm(filmOpt.name, filmOpt.params, filter, &ok); all &= ok;
+    std::memset(&sd->scene, 0, sizeof sd->scene); std::memset(&sd->render, 0, sizeof sd->render);
+    all &= MakeCamera(cameraOpt.name, cameraOpt.params, worldToCamera, sd->film, &sd->scene.camera);
+    pbrthip::Sampler smp = MakeSampler(samplerOpt.name, samplerOpt.params, sd->film, &ok); all &= ok;
+    pbrthip::SurfaceIntegrator si = MakeSurfaceIntegrator(surfOpt.name, surfOpt.params, &ok); all &= ok;
+    pbrthip::VolumeIntegrator vi = MakeVolumeIntegrator(volOpt.name, volOpt.params, &ok); all &= ok;
+    pbrthip::Accelerator acc = MakeAccelerator(accelOpt.name, accelOpt.params, &ok);
+    if (!ok) { ParamSet none; acc = MakeAccelerator("kdtree", none, &ok); }       // api.cpp:497-502
+    if (!all) Error("Unable to create scene due to missing plug-ins");
+    if (lights.empty()) Warning("No light sources defined in scene; possibly rendering a black image.");
+
+    // primitives in KdTreeAccel order: per mesh, last triangle first (primitive.cpp:40-53, kdtree.cpp:146-148)
+    for (const Mesh &m : meshes) {
+        const int nt = int(m.verts.size() / 9);
+        for (int t = nt - 1; t >= 0; --t) {
+            sd->tri_verts.insert(sd->tri_verts.end(), &m.verts[size_t(t) * 9], &m.verts[size_t(t) * 9] + 9);
+            sd->tri_material.push_back(uint16_t(m.material)); sd->tri_light.push_back(m.light); sd->tri_flags.push_back(m.flags);
+        }
+    }
+    if (materials.size() > 65535) Error("more than 65535 material instances");
+    sd->materials = materials; sd->lights = lights; sd->light_tris = light_tris;
+    sd->scene.volume = volume; sd->scene.accel = acc.params;
+    RtRenderDesc &r = sd->render;
+    r.integrator = si.kind; r.max_depth = si.maxDepth; r.strategy = si.strategy;
+    r.volume_integrator = vi.kind; r.step_size = vi.stepSize;
+    r.sampler = smp.kind; r.x_samples = smp.xsamples; r.y_samples = smp.ysamples; r.jitter = smp.jitter; r.pixel_samples = smp.pixelsamples;
+    r.seed = smp.seed;
+    r.x_res = sd->film.xResolution; r.y_res = sd->film.yResolution;
+    r.x_pixel_start = sd->film.xPixelStart; r.y_pixel_start = sd->film.yPixelStart;
+    r.x_pixel_count = sd->film.xPixelCount; r.y_pixel_count = sd->film.yPixelCount;
+    sd->film.GetSampleExtent(&r.x_start, &r.x_end, &r.y_start, &r.y_end);
+    r.filter_x_width = filter.xWidth; r.filter_y_width = filter.yWidth;
+    std::memcpy(r.filter_table, sd->film.filterTable, sizeof r.filter_table);
+    r.shard_index = 0; r.shard_count = 1; r.tile_pixels = 64;
+    sd->finalize_pointers();
+    sd->valid = all;
+    frames.push_back(sd);
+    // api.cpp:476-482
+    state = STATE_OPTIONS; ctm = Xform(); named.clear(); resetWorld();
+}
+
+}  // namespace pbrthip
+
+// ------------------------------------------------------------------ C entry points for the Python harness
+using namespace pbrthip;
+extern "C" {
+struct PbrtHostScene { PbrtApi api; };
+
+PbrtHostScene *pbrt_host_parse_file(const char *path, int quiet) {
+    SetQuiet(quiet != 0); ResetDiagnostics();
+    PbrtHostScene *h = new PbrtHostScene();
+    SceneParser parser(h->api);
+    parser.ParseFile(path);
+    return h;
+}
+PbrtHostScene *pbrt_host_parse_string(const char *text, int quiet) {
+    SetQuiet(quiet != 0); ResetDiagnostics();
+    PbrtHostScene *h = new PbrtHostScene();
+    SceneParser parser(h->api);
+    parser.ParseString(text);
+    return h;
+}
+void pbrt_host_free(PbrtHostScene *h) { delete h; }
+int pbrt_host_frame_count(PbrtHostScene *h) { return int(h->api.frames.size()); }
+int pbrt_host_frame_valid(PbrtHostScene *h, int i) { return h->api.frames[i]->valid ? 1 : 0; }
+const RtSceneDesc *pbrt_host_scene_desc(PbrtHostScene *h, int i) { return &h->api.frames[i]->scene; }
+RtRenderDesc *pbrt_host_render_desc(PbrtHostScene *h, int i) { return &h->api.frames[i]->render; }
+int pbrt_host_premultiply(PbrtHostScene *h, int i) { return h->api.frames[i]->film.premultiplyAlpha ? 1 : 0; }
+const char *pbrt_host_filename(PbrtHostScene *h, int i) { return h->api.frames[i]->film.filename.c_str(); }
+int pbrt_host_warnings() { return WarningCount(); }
+int pbrt_host_errors() { return ErrorCount(); }
+// field access without mirroring struct layouts in Python
+void pbrt_host_set_shard(RtRenderDesc *r, int index, int count, int tile_pixels) { r->shard_index = index; r->shard_count = count; r->tile_pixels = tile_pixels; }
+void pbrt_host_set_seed(RtRenderDesc *r, unsigned seed) { r->seed = seed; }
+void pbrt_host_film_dims(const RtRenderDesc *r, int *out8) {
+    out8[0] = r->x_pixel_count; out8[1] = r->y_pixel_count; out8[2] = r->x_start; out8[3] = r->x_end;
+    out8[4] = r->y_start; out8[5] = r->y_end; out8[6] = r->x_samples * r->y_samples; out8[7] = r->integrator;
+}
+void pbrt_host_scene_counts(const RtSceneDesc *s, unsigned *out4) { out4[0] = s->n_tris; out4[1] = s->n_materials; out4[2] = s->n_lights; out4[3] = s->n_light_tris; }
+const float *pbrt_host_camera(const RtSceneDesc *s) { return s->camera.raster_to_camera; }
+const float *pbrt_host_tri_verts(const RtSceneDesc *s) { return s->tri_verts; }
+}

@@ -11,8 +11,8 @@
 // reference itself in oracle/ref (through an adapter onto core/api.h:29-85).
 //
 // Token rules honoured (pbrtlex.l):  '#' comments to end of line; numbers
-// [-+]?digits[.digits][e[-+]digits]; quoted strings with \n \t \r \b \f \" \\
-// and \ddd escapes; '[' ']' ; bare identifiers for directives; Include "file".
+// [-+]?digits[.digits][e[-+]digits]; quoted strings with the escapes n t r b f " and backslash,
+// plus 3-digit decimal escapes; '[' ']' ; bare identifiers for directives; Include "file".
 // Parameter typing rules (pbrtparse.y:470-600): "type name" with type one of
 // float integer bool point vector normal string texture color; integers are
 // parsed as floats and truncated; bools are the strings "true"/"false" (every
