@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s of the pbrt-v1 Scene::Render hot path on N MI355X GPUs (one process per GPU).
+
+A *step* is one full frame of the workload: every camera sample of BASELINE.json configs[1]
+("Cornell box, PathIntegrator maxdepth=5, 1024x1024 @ 64 spp, kd-tree") goes through camera-ray
+generation, kd-tree traversal + triangle intersection, the path-tracing radiance estimate and the
+filtered film splat, then (N > 1) one RCCL all-reduce(sum) of the film accumulators and the final
+ImageFilm::WriteImage normalisation on rank 0.  Rays = every Scene::Intersect + every
+Scene::IntersectP call (camera, bounce, MIS closest-hit and shadow rays), the metric's definition.
+Scene data is resident in HBM before the timed region; the frame is fixed, so N > 1 is strong scaling
+(image tiles dealt round-robin to ranks).
+
+Prints ONE JSON line on rank 0 (see the contract in the task description) including
+  roofline     : algorithmic bytes (8 B/node visit + 4 B/leaf ref + 48 B/triangle test + 48 B/ray,
+                 SURVEY.md section 8d) of one launch / its HIP-event duration, against 8 TB/s HBM
+  cpu_baseline : the *reference itself* (oracle/_ref/pbrt_ref, built from /root/reference with its own
+                 flags, single thread, its own MT19937 stream) timed on this box's host cores on a
+                 centre crop window of the same frame.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def workload(name: str):
+    from pbrt_v1_amd import scenes
+    if name == "c2":
+        text = scenes.cornell_scene(xres=1024, yres=1024, integrator="path", maxdepth=5, xsamples=8, ysamples=8,
+                                    jitter=True, pixel_filter="mitchell", accelerator="kdtree")
+        label = "Cornell box (12 tris + 2-tri area light), PathIntegrator maxdepth=5, 1024x1024 @ 64 spp (stratified 8x8 jittered), mitchell 2x2 filter, kd-tree"
+        crop = (0.4375, 0.5625, 0.4375, 0.5625)
+    elif name == "c1":
+        text = scenes.cornell_scene(xres=512, yres=512, integrator="whitted", xsamples=1, ysamples=1, jitter=False,
+                                    pixel_filter="box")
+        label = "Cornell box, WhittedIntegrator, 512x512 @ 1 spp, box filter, kd-tree"
+        crop = None
+    elif name.startswith("c3"):
+        ntri = 1_000_000 if name == "c3" else int(name.split("_")[1])
+        text = scenes.cornell_scene(xres=1920, yres=1080, integrator="directlighting", xsamples=4, ysamples=4,
+                                    jitter=True, pixel_filter="mitchell", soup_tris=ntri)
+        label = "Cornell + %d-triangle LCG soup, DirectLighting(all), 1920x1080 @ 16 spp, mitchell, kd-tree" % ntri
+        crop = (0.47, 0.53, 0.47, 0.53)
+    else:
+        raise SystemExit("unknown workload " + name)
+    return text, label, crop
+
+
+def cpu_baseline(pkg, name: str, crop, budget_s: float = 25.0):
+    """Time the compiled reference (single thread) on a crop window of the same frame."""
+    from pbrt_v1_amd import scenes
+    import re
+    text, _, _ = workload(name)
+    if crop is not None:
+        text = text.replace('"string filename"', '"float cropwindow" [%s %s %s %s] "string filename"' % crop)
+    text = re.sub(r'Accelerator "(\w+)"', r'Accelerator "countaccel" "string inner" ["\1"]', text)
+    try:
+        t0 = time.time()
+        _, _, st = pkg.run_reference(text, keyed=False, timeout=600)
+        rays = st["closest_rays"] + st["any_rays"]
+        return {"value": round(rays / st["render_s"] / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "reference",
+                "sample": "oracle/_ref/pbrt_ref (reference built with its own flags -O2 -msse2 -mfpmath=sse, 1 thread, MT19937) on "
+                          "cropwindow %s of the same frame: %d rays in %.2f s render (+%.3f s kd build); host has %d cores"
+                          % (crop, rays, st["render_s"], st["accel_build_s"], os.cpu_count()),
+                "wall_s": round(time.time() - t0, 2)}
+    except FileNotFoundError:
+        return {"value": None, "unit": "Mrays/s", "cores": 1, "kind": "port", "sample": "oracle/_ref missing on this box"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tile-pixels", type=int, default=64)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import __graft_entry__ as entry
+    pkg = entry.load_package()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    text, label, crop = workload(args.workload)
+    ps = pkg.ParsedScene(text=text)
+    ps.set_shard(rank, world, args.tile_pixels)
+    ds = pkg.DeviceScene(ps, device=local_rank)
+    info = ds.accel_info()
+    film = torch.zeros((5, ps.height, ps.width), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream()
+    ds.set_stream(stream.cuda_stream)
+    ds.bind_film(film.data_ptr())
+
+    def step():
+        film.zero_()
+        ds.render(sync=False)
+        if dist is not None:
+            dist.all_reduce(film, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            return ds.film()          # ImageFilm::WriteImage normalisation (synchronises)
+        return None
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # one counted frame: ray / node / triangle counts of this rank's shard (deterministic per frame)
+    ds.set_counting(True); ds.reset_counters()
+    step(); fence()
+    cnt = ds.counters()
+    ds.set_counting(False)
+    for _ in range(args.warmup):
+        step()
+    fence()
+    kern_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kern_ms.append(ds.last_ms()[1])     # HIP events around the render kernel on its stream
+    fence()
+    elapsed = time.perf_counter() - t0
+    rays_local = cnt["closest_rays"] + cnt["any_rays"]
+    tot = torch.tensor([float(rays_local), float(cnt["camera_rays"])], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    rays_total, cam_total = float(tot[0].item()), float(tot[1].item())
+    elapsed = float(tmax[0].item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        k_ms = float(np.mean(kern_ms))
+        alg_bytes = 8 * cnt["nodes_visited"] + 4 * cnt["leaf_refs"] + 48 * cnt["tri_tests"] + 48 * rays_local
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mrays/s (primary+secondary: every Scene::Intersect + Scene::IntersectP)",
+            "value": round(rays_total * args.steps / elapsed / 1e6, 3),
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "s_per_frame": round(ms_per_step / 1e3, 5),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": label, "camera_samples_per_frame": int(cam_total), "rays_per_frame": int(rays_total),
+                       "rays_per_camera_sample": round(rays_total / max(cam_total, 1), 3),
+                       "kd_nodes": int(info.n_nodes), "kd_build_s": round(info.build_seconds, 4),
+                       "parallelism": "tiles of %d pixels dealt round-robin to %d rank(s); RCCL all-reduce(sum) of the 5-plane film" % (args.tile_pixels, world),
+                       "rng": "counter-based keyed RNG, seed 0"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(achieved / 8000.0, 5), "traffic": None,
+                         "kernel": "rt::render_kernel<false>", "kernel_ms": round(k_ms, 3),
+                         "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "bytes_per_ray": round(alg_bytes / max(rays_local, 1), 1),
+                         "nodes_per_ray": round(cnt["nodes_visited"] / max(rays_local, 1), 2),
+                         "tri_tests_per_ray": round(cnt["tri_tests"] / max(rays_local, 1), 2)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pkg, args.workload, crop)
+            if out["cpu_baseline"].get("value"):
+                out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    ds.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

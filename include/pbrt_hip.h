@@ -189,6 +189,9 @@ int rt_render(RtScene *s, const RtRenderDesc *rd);
 int rt_sync(RtScene *s);
 int rt_counters(RtScene *s, RtCounters *out);             /* synchronises */
 int rt_counters_reset(RtScene *s);
+/* per-ray statistics cost a few VALU ops per node visit: enabled (default) for parity/accounting runs,
+ * disabled for timed runs; the frame is deterministic so counts of one run describe the other */
+int rt_set_counting(RtScene *s, int enabled);
 /* elapsed GPU milliseconds of the last rt_render launch sequence (HIP events on the
  * handle's stream) and of its dominant kernel */
 int rt_last_render_ms(RtScene *s, float *total_ms, float *kernel_ms);

@@ -82,7 +82,7 @@ def hip_lib():
         for name in ("rt_scene_create", "rt_scene_destroy", "rt_scene_set_stream", "rt_scene_accel_info",
                      "rt_scene_accel_copy", "rt_camera_rays", "rt_trace_closest", "rt_trace_any", "rt_film_bind",
                      "rt_film_clear", "rt_film_read", "rt_film_resolve", "rt_render", "rt_sync", "rt_counters",
-                     "rt_counters_reset", "rt_last_render_ms", "rt_device_count"):
+                     "rt_counters_reset", "rt_last_render_ms", "rt_device_count", "rt_set_counting"):
             getattr(L, name).restype = C.c_int
         L.rt_scene_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
         L.rt_scene_destroy.argtypes = [C.c_void_p]
@@ -102,6 +102,7 @@ def hip_lib():
         L.rt_counters_reset.argtypes = [C.c_void_p]
         L.rt_last_render_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.rt_device_count.argtypes = [C.POINTER(C.c_int)]
+        L.rt_set_counting.argtypes = [C.c_void_p, C.c_int]
         _hip = L
     return _hip
 
@@ -272,6 +273,9 @@ class DeviceScene:
         c = RtCounters()
         _chk(hip_lib().rt_counters(self._s, C.byref(c)))
         return c.as_dict()
+
+    def set_counting(self, enabled: bool):
+        _chk(hip_lib().rt_set_counting(self._s, int(enabled)))
 
     def reset_counters(self):
         _chk(hip_lib().rt_counters_reset(self._s))

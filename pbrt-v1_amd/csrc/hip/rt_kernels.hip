@@ -146,6 +146,7 @@ struct RtScene {
     int spill_depth = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_timing = false;
+    bool counting = true;
     uint32_t n_tris = 0;
 };
 
@@ -479,7 +480,8 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
     HIPCHK(hipMemcpyAsync(s->filter_dev, rd->filter_table, 256 * sizeof(float), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemsetAsync(s->work_counter, 0, sizeof(unsigned long long), s->stream));
     HIPCHK(hipEventRecord(s->ev0, s->stream));
-    hipLaunchKernelGGL(render_kernel<true>, dim3(s->grid), dim3(RT_BLOCK), 0, s->stream, s->dev, fr);
+    if (s->counting) hipLaunchKernelGGL(render_kernel<true>, dim3(s->grid), dim3(RT_BLOCK), 0, s->stream, s->dev, fr);
+    else hipLaunchKernelGGL(render_kernel<false>, dim3(s->grid), dim3(RT_BLOCK), 0, s->stream, s->dev, fr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->ev1, s->stream));
     s->have_timing = true;
@@ -507,6 +509,11 @@ int rt_counters_reset(RtScene *s) {
     if (!s) return fail(RT_EINVAL, "null scene");
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipMemsetAsync(s->counters, 0, 8 * sizeof(unsigned long long), s->stream));
+    return RT_OK;
+}
+int rt_set_counting(RtScene *s, int enabled) {
+    if (!s) return fail(RT_EINVAL, "null scene");
+    s->counting = enabled != 0;
     return RT_OK;
 }
 int rt_last_render_ms(RtScene *s, float *total_ms, float *kernel_ms) {
