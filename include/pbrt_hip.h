@@ -163,6 +163,14 @@ int rt_scene_accel_info(const RtScene *s, RtAccelInfo *info);
  * nodes = [n_nodes][2] u32, leaf_refs = [n_leaf_refs] u32 */
 int rt_scene_accel_copy(const RtScene *s, uint32_t *nodes, uint32_t *leaf_refs);
 
+/* The accelerator build alone, host-only (no device needed): KdTreeAccel's constructor,
+ * accelerators/kdtree.cpp:141-312.  rt_scene_create runs exactly this. */
+typedef struct RtKdTree RtKdTree;
+int rt_kdtree_build(const float *tri_verts, uint32_t n_tris, const RtAccelParams *params, RtKdTree **out);
+int rt_kdtree_info(const RtKdTree *t, RtAccelInfo *info);
+int rt_kdtree_copy(const RtKdTree *t, uint32_t *nodes, uint32_t *leaf_refs);
+int rt_kdtree_destroy(RtKdTree *t);
+
 /* Unit entry points (parity of one stage in isolation) */
 /* Camera::GenerateRay for `count` samples starting at camera-sample index `first`
  * (perspective.cpp:51-82 + the sampler's image/lens positions) */

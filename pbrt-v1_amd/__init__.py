@@ -82,7 +82,8 @@ def hip_lib():
         for name in ("rt_scene_create", "rt_scene_destroy", "rt_scene_set_stream", "rt_scene_accel_info",
                      "rt_scene_accel_copy", "rt_camera_rays", "rt_trace_closest", "rt_trace_any", "rt_film_bind",
                      "rt_film_clear", "rt_film_read", "rt_film_resolve", "rt_render", "rt_sync", "rt_counters",
-                     "rt_counters_reset", "rt_last_render_ms", "rt_device_count", "rt_set_counting"):
+                     "rt_counters_reset", "rt_last_render_ms", "rt_device_count", "rt_set_counting",
+                     "rt_kdtree_build", "rt_kdtree_info", "rt_kdtree_copy", "rt_kdtree_destroy"):
             getattr(L, name).restype = C.c_int
         L.rt_scene_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
         L.rt_scene_destroy.argtypes = [C.c_void_p]
@@ -103,6 +104,10 @@ def hip_lib():
         L.rt_last_render_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.rt_device_count.argtypes = [C.POINTER(C.c_int)]
         L.rt_set_counting.argtypes = [C.c_void_p, C.c_int]
+        L.rt_kdtree_build.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.rt_kdtree_info.argtypes = [C.c_void_p, C.POINTER(RtAccelInfo)]
+        L.rt_kdtree_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rt_kdtree_destroy.argtypes = [C.c_void_p]
         _hip = L
     return _hip
 
@@ -135,6 +140,8 @@ def host_lib():
         L.pbrt_host_camera.argtypes = [C.c_void_p]
         L.pbrt_host_tri_verts.restype = C.POINTER(C.c_float)
         L.pbrt_host_tri_verts.argtypes = [C.c_void_p]
+        L.pbrt_host_accel_params.restype = C.c_void_p
+        L.pbrt_host_accel_params.argtypes = [C.c_void_p]
         _host = L
     return _host
 
@@ -152,6 +159,20 @@ def device_count() -> int:
     n = C.c_int(0)
     rc = hip_lib().rt_device_count(C.byref(n))
     return int(n.value) if rc == 0 else 0
+
+
+def build_kdtree(tri_verts: np.ndarray, accel_params_ptr=None):
+    """Host-only kd-tree build (rt_kdtree_build).  Returns (nodes[n,2] u32, leaf_refs u32, bounds[6], info)."""
+    tv = np.ascontiguousarray(tri_verts, np.float32).reshape(-1, 9)
+    t = C.c_void_p()
+    _chk(hip_lib().rt_kdtree_build(tv.ctypes.data, len(tv), accel_params_ptr, C.byref(t)))
+    info = RtAccelInfo()
+    _chk(hip_lib().rt_kdtree_info(t, C.byref(info)))
+    nodes = np.zeros((info.n_nodes, 2), np.uint32)
+    refs = np.zeros(max(info.n_leaf_refs, 1), np.uint32)
+    _chk(hip_lib().rt_kdtree_copy(t, nodes.ctypes.data, refs.ctypes.data))
+    hip_lib().rt_kdtree_destroy(t)
+    return nodes, refs[:info.n_leaf_refs], np.array(list(info.bounds), np.float32), info
 
 
 class ParsedScene:
@@ -198,6 +219,13 @@ class ParsedScene:
         p = host_lib().pbrt_host_camera(self.scene_desc)
         a = np.ctypeslib.as_array(p, shape=(32,)).copy()
         return a[:16].reshape(4, 4), a[16:].reshape(4, 4)
+
+    def accel_params_ptr(self):
+        return host_lib().pbrt_host_accel_params(self.scene_desc)
+
+    def kdtree(self):
+        """The kd-tree rt_scene_create would build for this scene, built on the host only."""
+        return build_kdtree(self.tri_verts(), self.accel_params_ptr())
 
     def tri_verts(self):
         p = host_lib().pbrt_host_tri_verts(self.scene_desc)

@@ -319,6 +319,31 @@ int rt_scene_accel_copy(const RtScene *s, uint32_t *nodes, uint32_t *leaf_refs) 
     return RT_OK;
 }
 
+struct RtKdTree { KdTree tree; uint32_t n_tris; };
+int rt_kdtree_build(const float *tri_verts, uint32_t n_tris, const RtAccelParams *params, RtKdTree **out) {
+    if (!out || (n_tris && !tri_verts)) return fail(RT_EINVAL, "rt_kdtree_build: null argument");
+    RtAccelParams p; std::memset(&p, 0, sizeof p);
+    if (params) p = *params;
+    if (p.kind != RT_ACCEL_KDTREE) return fail(RT_EINVAL, "rt_kdtree_build: not a kd-tree description");
+    RtKdTree *t = new RtKdTree(); t->n_tris = n_tris;
+    build_kdtree(tri_verts, n_tris, p, t->tree);
+    *out = t; return RT_OK;
+}
+int rt_kdtree_info(const RtKdTree *t, RtAccelInfo *info) {
+    if (!t || !info) return fail(RT_EINVAL, "null argument");
+    info->n_nodes = uint32_t(t->tree.nodes.size()); info->n_leaf_refs = uint32_t(t->tree.leaf_refs.size());
+    info->max_depth = uint32_t(t->tree.max_depth); info->n_tris = t->n_tris;
+    std::memcpy(info->bounds, t->tree.bounds, sizeof info->bounds); info->build_seconds = t->tree.build_seconds;
+    return RT_OK;
+}
+int rt_kdtree_copy(const RtKdTree *t, uint32_t *nodes, uint32_t *leaf_refs) {
+    if (!t) return fail(RT_EINVAL, "null tree");
+    if (nodes) std::memcpy(nodes, t->tree.nodes.data(), t->tree.nodes.size() * sizeof(Node));
+    if (leaf_refs) std::memcpy(leaf_refs, t->tree.leaf_refs.data(), t->tree.leaf_refs.size() * sizeof(uint32_t));
+    return RT_OK;
+}
+int rt_kdtree_destroy(RtKdTree *t) { delete t; return RT_OK; }
+
 // Build the per-frame device descriptor: film geometry + the Sample layout the integrators request
 // (Sample::Sample sampling.cpp:41-70; RequestSamples of directlighting.cpp:39-66, path.cpp:47-57,
 // emission.cpp:42-46 / single.cpp:43-47; LatinHypercube draw counts sampling.cpp:98-113).

@@ -531,4 +531,5 @@ void pbrt_host_film_dims(const RtRenderDesc *r, int *out8) {
 void pbrt_host_scene_counts(const RtSceneDesc *s, unsigned *out4) { out4[0] = s->n_tris; out4[1] = s->n_materials; out4[2] = s->n_lights; out4[3] = s->n_light_tris; }
 const float *pbrt_host_camera(const RtSceneDesc *s) { return s->camera.raster_to_camera; }
 const float *pbrt_host_tri_verts(const RtSceneDesc *s) { return s->tri_verts; }
+const RtAccelParams *pbrt_host_accel_params(const RtSceneDesc *s) { return &s->accel; }
 }
