@@ -384,9 +384,19 @@ def run_reference(scene_text: str, keyed: bool = True, workdir: str | None = Non
     with open(sp, "w") as f:
         f.write(scene_text)
     env = dict(os.environ, PBRT_SEARCHPATH=os.path.join(REF_DIR, "bin"))
-    r = subprocess.run([exe, "--quiet", "--out", fp, sp], env=env, capture_output=True, text=True, timeout=timeout, cwd=d)
+    r = subprocess.run([exe, "--out", fp, sp], env=env, capture_output=True, text=True, timeout=timeout, cwd=d)
     if r.returncode != 0:
-        raise RuntimeError("reference run failed: %s\n%s" % (r.stdout, r.stderr[-2000:]))
-    stats = json.loads(r.stdout.strip().splitlines()[-1])
+        raise RuntimeError("reference run failed: %s\n%s" % (r.stdout[-2000:], r.stderr[-2000:]))
+    lines = r.stdout.strip().splitlines()
+    stats = json.loads(lines[-1])
+    # the reference's own StatsPrint block (core/util.cpp:228-262), e.g. "Interior kd-tree nodes made   1625"
+    table = {}
+    if "Statistics:" in lines:
+        for ln in lines[lines.index("Statistics:") + 1:-1]:
+            if ln.startswith("    ") and len(ln.split()) >= 2:
+                key = " ".join(ln.split()[:-1]) if not ln.rstrip().endswith(")") else " ".join(ln.split()[:-2])
+                val = ln.split()[-1] if not ln.rstrip().endswith(")") else ln.split()[-2]
+                table[key] = val
+    stats["stats"] = table
     rgb, alpha, _ = load_ref_film(fp)
     return rgb, alpha, stats

@@ -1,0 +1,68 @@
+"""Generate the golden fixtures in tests/golden/ by running the UNMODIFIED reference (oracle/_ref/pbrt_ref_keyed,
+built from /root/reference by oracle/ref/Makefile) on small scenes.  Runs only in the authoring container.
+
+    python tests/golden/make_golden.py
+
+Each fixture <name>.npz holds: the scene text, the reference's float film (rgb, alpha: the arguments of
+WriteRGBAImage, i.e. before half quantisation), its ray counts (countaccel plugin) and the kd-tree / triangle-test
+counters printed by StatsPrint.  probe_*.npz hold per-camera-sample records from the probe integrator plugin
+(oracle/ref/probe_integrator.cpp): camera ray, closest hit (t, p, n, u, v), shadow-segment occlusion.
+Fixtures are DATA (inputs + expected outputs); no reference source text is stored."""
+import json, os, sys, tempfile
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as g
+pkg = g.load_package()
+from pbrt_v1_amd import scenes
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+blob = scenes.icosphere((200, 120, 250), 90, 1)
+
+CONFIGS = {
+    # name: cornell_scene kwargs  (all keyed RNG + counted rays)
+    "whitted_point": dict(xres=48, yres=48, integrator="whitted", world_kwargs=dict(point_light=True, area_light=False)),
+    "whitted_area": dict(xres=48, yres=48, integrator="whitted"),
+    "whitted_glass_mirror": dict(xres=48, yres=48, integrator="whitted", world_kwargs=dict(mirror_quad=True, glass_sphere_tris=blob)),
+    "direct_all": dict(xres=48, yres=48, integrator="directlighting"),
+    "direct_all_ns4_spp4": dict(xres=32, yres=32, integrator="directlighting", xsamples=2, ysamples=2, jitter=True,
+                                world_kwargs=dict(light_nsamples=4)),
+    "direct_one_point_and_area": dict(xres=48, yres=48, integrator="directlighting", integrator_params='"string strategy" ["one"]',
+                                      world_kwargs=dict(point_light=True)),
+    "direct_glass": dict(xres=40, yres=40, integrator="directlighting", world_kwargs=dict(glass_sphere_tris=blob)),
+    "path_box_4spp": dict(xres=48, yres=48, integrator="path", xsamples=2, ysamples=2),
+    "path_jitter_mitchell_4spp": dict(xres=40, yres=40, integrator="path", xsamples=2, ysamples=2, jitter=True, pixel_filter="mitchell"),
+    "path_gaussian_depth8": dict(xres=32, yres=32, integrator="path", maxdepth=8, xsamples=2, ysamples=1, jitter=True, pixel_filter="gaussian"),
+    "path_soup2k": dict(xres=48, yres=48, integrator="path", xsamples=2, ysamples=2, soup_tris=2000),
+    "path_glass_mirror": dict(xres=40, yres=40, integrator="path", xsamples=2, ysamples=2, world_kwargs=dict(mirror_quad=True, glass_sphere_tris=blob)),
+    "path_lens_crop": dict(xres=64, yres=64, integrator="path", xsamples=2, ysamples=2, jitter=True, lensradius=6.0, focaldistance=900.0,
+                           crop=(0.25, 0.75, 0.3, 0.8)),
+    "direct_soup5k_seed7": dict(xres=48, yres=48, integrator="directlighting", soup_tris=5000, seed=7, xsamples=2, ysamples=2, jitter=True),
+    "whitted_orennayar_triangle": dict(xres=32, yres=32, integrator="whitted", pixel_filter="triangle",
+                                       world_kwargs=dict(point_light=True)),
+}
+
+def main():
+    for name, kw in CONFIGS.items():
+        text = scenes.cornell_scene(keyed=True, count=True, **kw)
+        if name == "whitted_orennayar_triangle":
+            text = text.replace('Material "matte" "color Kd" [0.73 0.73 0.73]', 'Material "matte" "color Kd" [0.73 0.73 0.73] "float sigma" [35]')
+        rgb, alpha, st = pkg.run_reference(text, keyed=True)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), scene=np.array(text), rgb=rgb, alpha=alpha, stats=np.array(json.dumps(st)))
+        print(name, rgb.shape, "mean", float(rgb.mean()), {k: st[k] for k in ("closest_rays", "any_rays")}, st.get("stats", {}))
+    # probe fixtures: camera rays + hits
+    for name, kw in {"probe_cornell": dict(xres=24, yres=24), "probe_soup3k_jitter": dict(xres=24, yres=24, soup_tris=3000, xsamples=2, ysamples=1, jitter=True),
+                     "probe_lens": dict(xres=16, yres=16, xsamples=2, ysamples=2, jitter=True, lensradius=4.0, focaldistance=700.0)}.items():
+        d = tempfile.mkdtemp()
+        dump = os.path.join(d, "rays.bin")
+        text = scenes.cornell_scene(keyed=True, count=True, integrator="probe",
+                                    integrator_params='"string dump" ["%s"] "point target" [278 540 280]' % dump, **kw)
+        rgb, alpha, st = pkg.run_reference(text, keyed=True, workdir=d)
+        rec = np.fromfile(dump, np.float32).reshape(-1, 20)
+        # the scene stored in the fixture names no dump file (the product ignores the probe integrator's params)
+        text = text.replace(dump, "probe_rays.bin")
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), scene=np.array(text), records=rec, stats=np.array(json.dumps(st)))
+        print(name, rec.shape, "hits", int(rec[:, 8].sum()), "occluded", int(rec[:, 18].sum()))
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,106 @@
+"""Host front end (pbrt-v1_amd/csrc/host): scene parser, ParamSet semantics, API state machine, plugin factory
+defaults.  Reference behaviours cited per test.  CPU only."""
+import numpy as np
+import pytest
+
+BASE = '''LookAt 0 0 -5  0 0 0  0 1 0
+Camera "perspective" "float fov" [45]
+Film "image" "integer xresolution" [16] "integer yresolution" [8]
+%s
+WorldBegin
+%s
+WorldEnd
+'''
+TRI = 'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [-1 -1 0  1 -1 0  0 1 0]\n'
+
+
+def test_defaults_follow_the_reference_factories(pkg):
+    ps = pkg.ParsedScene(text=BASE % ("", 'LightSource "point"\n' + TRI))
+    assert ps.valid and ps.errors == 0
+    # api.cpp:62-71 defaults: mitchell 2x2 (mitchell.cpp:54-57) => extent = res + 4; stratified 2x2 => 4 spp;
+    # directlighting strategy all (directlighting.cpp:198)
+    assert ps.sample_extent == (-2, 18, -2, 10) and ps.spp == 4 and ps.integrator == 1
+    assert (ps.width, ps.height) == (16, 8) and ps.premultiply
+    assert ps.n_tris == 1 and ps.n_lights == 1 and ps.n_materials == 1
+
+
+def test_box_filter_extent_and_crop(pkg):
+    ps = pkg.ParsedScene(text=(BASE % ('PixelFilter "box"\nSampler "stratified" "integer xsamples" [3] "integer ysamples" [1]', TRI))
+                         .replace('[8]', '[8] "float cropwindow" [.25 .75 0 .5]'))
+    # image.cpp:79-86 crop in pixels, :148-156 sample extent = floor(start + .5 -/+ width)
+    assert (ps.width, ps.height) == (8, 4) and ps.sample_extent == (4, 13, 0, 5) and ps.spp == 3
+    assert ps.warnings >= 1          # no lights: scene.cpp:112-114 warning
+
+
+def test_camera_matrices(pkg):
+    ps = pkg.ParsedScene(text=BASE % ("", TRI))
+    r2c, c2w = ps.camera_matrices()
+    # LookAt from (0,0,-5) towards +z: camera-to-world translation column (transform.cpp:113-138)
+    assert np.allclose(c2w[:3, 3], [0, 0, -5]) and np.allclose(c2w[3], [0, 0, 0, 1])
+    assert np.allclose(c2w[:3, :3] @ c2w[:3, :3].T, np.eye(3), atol=1e-6)
+    # raster (8,4) is the image centre: it maps onto the optical axis (x = y = 0 after the w divide)
+    p = r2c @ np.array([8, 4, 0, 1], np.float32)
+    assert abs(p[0] / p[3]) < 1e-6 and abs(p[1] / p[3]) < 1e-6
+
+
+def test_paramset_semantics(pkg):
+    # ints are floats truncated (pbrtparse.y:484-492); a bare string for a colour re-types it as a texture
+    # (pbrtparse.y:476-480) -> unknown texture name -> Error + default (paramset.cpp:434-449)
+    world = 'Material "matte" "color Kd" "nosuchtex"\n' + TRI.replace("[0 1 2]", "[0.9 1.2 2.7]")
+    ps = pkg.ParsedScene(text=BASE % ("", world))
+    assert ps.n_tris == 1 and ps.errors >= 1
+    # misspelt parameter -> "not used" warning (paramset.cpp:242-254), still renders
+    ps2 = pkg.ParsedScene(text=BASE % ('SurfaceIntegrator "path" "integer maxdepht" [3]', 'LightSource "point"\n' + TRI))
+    assert ps2.valid and ps2.warnings >= 1 and ps2.integrator == 2
+
+
+def test_state_machine_errors(pkg):
+    # options inside the world block are rejected and ignored (api.cpp:120-139)
+    ps = pkg.ParsedScene(text=BASE % ("", 'Sampler "stratified" "integer xsamples" [7]\nLightSource "point"\n' + TRI))
+    assert ps.errors >= 1 and ps.spp == 4
+    # unmatched AttributeEnd (api.cpp:282-287)
+    ps = pkg.ParsedScene(text=BASE % ("", "AttributeEnd\nLightSource \"point\"\n" + TRI))
+    assert ps.errors >= 1 and ps.n_tris == 1
+
+
+def test_attribute_stack_and_transforms(pkg):
+    world = ('AttributeBegin\nTranslate 10 0 0\nReverseOrientation\n' + TRI + 'AttributeEnd\n' + TRI + 'LightSource "point"\n')
+    ps = pkg.ParsedScene(text=BASE % ("", world))
+    v = ps.tri_verts()
+    assert np.allclose(v[0, :, 0] - v[1, :, 0], 10) and ps.n_tris == 2
+
+
+def test_primitive_order_is_kdtree_refinement_order(pkg):
+    # FullyRefine pops the last refined triangle first (primitive.cpp:40-53): a 2-triangle mesh comes out reversed
+    world = 'LightSource "point"\nShape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [0 0 0  1 0 0  1 1 0  0 1 0]\n'
+    v = pkg.ParsedScene(text=BASE % ("", world)).tri_verts()
+    assert np.allclose(v[0], [[0, 0, 0], [1, 1, 0], [0, 1, 0]]) and np.allclose(v[1], [[0, 0, 0], [1, 0, 0], [1, 1, 0]])
+
+
+def test_unsupported_plugins_are_errors_not_silent(pkg):
+    ps = pkg.ParsedScene(text=BASE % ("", 'LightSource "point"\nShape "sphere" "float radius" [1]\n' + TRI))
+    assert ps.errors >= 1 and ps.n_tris == 1
+    ps = pkg.ParsedScene(text=BASE % ('Camera "orthographic"', 'LightSource "point"\n' + TRI))
+    assert not ps.valid
+    ps = pkg.ParsedScene(text=BASE % ("", 'Material "plastic"\nLightSource "point"\n' + TRI))
+    assert ps.errors >= 1 and ps.n_materials == 1        # falls back to matte (api.cpp:376-379)
+
+
+def test_include_and_comments(pkg, tmp_path):
+    (tmp_path / "geom.pbrt").write_text("# a comment\n" + TRI)
+    (tmp_path / "main.pbrt").write_text(BASE % ("", 'LightSource "point" # trailing\nInclude "geom.pbrt"\n'))
+    ps = pkg.ParsedScene(path=str(tmp_path / "main.pbrt"))
+    assert ps.valid and ps.n_tris == 1
+
+
+def test_soup_generator_is_deterministic_lcg(scenes):
+    a = scenes.lcg_soup(7)
+    s = 12345
+    vals = []
+    for _ in range(12):
+        s = (s * 1664525 + 1013904223) % (1 << 32)
+        vals.append(np.float32((s >> 8) / float(1 << 24)))
+    c = np.float32(50) + np.array(vals[:3], np.float32) * np.array([450, 400, 450], np.float32)
+    v0 = c + (np.array(vals[3:6], np.float32) * np.float32(8) - np.float32(4))
+    assert np.allclose(a[0, 0], v0) and a.shape == (7, 3, 3)
+    assert a.min() >= 46 and a.max() <= 504

@@ -1,0 +1,66 @@
+"""The N > 1 path on CPU: world_size 2 over gloo.  Each rank renders its round-robin tile shard (the partition the
+host front end hands to rt_render; here evaluated by the CPU oracle) into a full-frame 5-plane film, one
+all-reduce(sum) merges them -- exactly bench.py's step with backend nccl (= RCCL) swapped for gloo.
+The merged film must equal the single-rank film: tile/shard logic and keyed RNG are partition invariant."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, scene_text, tile, out_dir):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as entry
+    import oracle
+    pkg = entry.load_package()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ps = pkg.ParsedScene(text=scene_text)
+    ps.set_shard(rank, world, tile)
+    nodes, refs, bounds, _ = ps.kdtree()
+    _, _, accum, cnt = oracle.render(ps, nodes, refs, bounds)
+    film = torch.from_numpy(accum.copy())
+    dist.all_reduce(film, op=dist.ReduceOp.SUM)
+    rays = torch.tensor([cnt["camera_rays"], cnt["closest_rays"], cnt["any_rays"]], dtype=torch.int64)
+    dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "film.npy"), film.numpy())
+        np.save(os.path.join(out_dir, "rays.npy"), rays.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("tile", [7, 64])
+def test_two_rank_tile_shards_sum_to_the_full_film(pkg, scenes, oracle, tmp_path, tile):
+    import torch.multiprocessing as mp
+    text = scenes.cornell_scene(xres=24, yres=20, integrator="path", xsamples=2, ysamples=2, jitter=True,
+                                pixel_filter="mitchell", keyed=True)
+    ps = pkg.ParsedScene(text=text)
+    nodes, refs, bounds, _ = ps.kdtree()
+    _, _, full, cnt = oracle.render(ps, nodes, refs, bounds)
+    port = 29500 + (os.getpid() + tile) % 2000
+    mp.spawn(_worker, args=(2, port, text, tile, str(tmp_path)), nprocs=2, join=True)
+    merged = np.load(tmp_path / "film.npy")
+    rays = np.load(tmp_path / "rays.npy")
+    assert rays.tolist() == [cnt["camera_rays"], cnt["closest_rays"], cnt["any_rays"]]
+    # every sample is evaluated by exactly one rank with the same key; only the order of float additions into a
+    # pixel differs between (a+b)+(c+d) and ((a+b)+c)+d
+    assert np.allclose(merged, full, rtol=2e-6, atol=1e-6)
+    assert np.array_equal(merged[4] != 0, full[4] != 0)
+
+
+def test_shard_partition_covers_every_sample_once(pkg, scenes, oracle):
+    text = scenes.cornell_scene(xres=17, yres=9, integrator="whitted", xsamples=2, ysamples=1, keyed=True)
+    total = None
+    for world in (1, 3, 5):
+        cams = 0
+        for r in range(world):
+            ps = pkg.ParsedScene(text=text); ps.set_shard(r, world, 4)
+            cams += oracle.render(ps)[3]["camera_rays"]
+        total = cams if total is None else total
+        assert cams == total == 18 * 10 * 2

@@ -1,0 +1,79 @@
+"""The oracle (oracle/pbrt_oracle.cpp, CPU restatement) against the golden vectors produced by the unmodified
+reference (tests/golden/make_golden.py) -- this is what pins the oracle.  CPU only."""
+import numpy as np
+import pytest
+from conftest import golden_names, load_golden, film_metrics, stat_int
+
+FILMS = [n for n in golden_names() if not n.startswith("probe_")]
+
+
+@pytest.mark.parametrize("name", FILMS)
+def test_oracle_film_matches_reference(pkg, oracle, name):
+    g = load_golden(name)
+    ps = pkg.ParsedScene(text=g["scene"])
+    assert ps.valid and ps.errors == 0
+    nodes, refs, bounds, info = ps.kdtree()
+    rgb, alpha, accum, cnt = oracle.render(ps, nodes, refs, bounds)
+    m = film_metrics(rgb, g["rgb"])
+    # same compiler flags, same libm, same draw order: the restatement reproduces the reference film exactly
+    assert m["maxabs"] <= 1e-6, m
+    assert np.abs(alpha - g["alpha"]).max() <= 1e-6
+    st = g["stats"]
+    assert cnt["closest_rays"] == st["closest_rays"]
+    assert cnt["any_rays"] == st["any_rays"]
+    assert cnt["camera_rays"] == int(st["stats"]["Camera Rays Traced"])
+    assert cnt["bad_samples"] == 0
+
+
+@pytest.mark.parametrize("name", FILMS)
+def test_kdtree_shape_matches_reference_statistics(pkg, name):
+    """rt_kdtree_build (host-only ABI) against the node counts KdTreeAccel reports through StatsPrint
+    (kdtree.cpp:41-52,68-69): interior nodes, leaf nodes, total leaf references, max primitives per leaf."""
+    g = load_golden(name)
+    ps = pkg.ParsedScene(text=g["scene"])
+    nodes, refs, bounds, info = ps.kdtree()
+    leaf = (nodes[:, 0] & 3) == 3
+    table = g["stats"]["stats"]
+    for key, mine in (("Interior kd-tree nodes made", int((~leaf).sum())), ("Leaf kd-tree nodes made", int(leaf.sum()))):
+        ref, exact = stat_int(table[key])
+        assert (mine == ref) if exact else abs(mine - ref) <= 0.006 * ref + 50, (key, mine, table[key])
+    nprims = nodes[leaf, 0] >> 2
+    ref_refs, ref_leaves = table["Avg. number of primitives in leaf nodes"].split(":")
+    assert int(nprims.sum()) == int(ref_refs) and int(leaf.sum()) == int(ref_leaves)
+    assert int(nprims.max()) == int(table["Maximum number of primitives in leaf node"])
+    assert len(refs) == int(nprims[nprims > 1].sum())
+
+
+def test_oracle_bruteforce_equals_kdtree(pkg, oracle):
+    """Closest-hit results do not depend on the accelerator: the accelerator-free mode renders the same film."""
+    g = load_golden("whitted_glass_mirror")
+    ps = pkg.ParsedScene(text=g["scene"])
+    nodes, refs, bounds, _ = ps.kdtree()
+    a = oracle.render(ps, nodes, refs, bounds)[0]
+    b = oracle.render(ps)[0]
+    assert np.abs(a - b).max() == 0.0
+
+
+def test_oracle_trace_against_probe_records(pkg, oracle):
+    """Scene::Intersect / IntersectP records dumped by the probe integrator plugin inside the reference."""
+    for name in golden_names("probe_"):
+        g = load_golden(name)
+        ps = pkg.ParsedScene(text=g["scene"].replace('SurfaceIntegrator "probe"', 'SurfaceIntegrator "whitted"'))
+        nodes, refs, bounds, _ = ps.kdtree()
+        rec = g["records"]
+        rays = np.zeros(len(rec), pkg.RAY_DTYPE)
+        rays["o"] = rec[:, 0:3]; rays["d"] = rec[:, 3:6]; rays["mint"] = rec[:, 6]; rays["maxt"] = rec[:, 7]
+        hits, _ = oracle.trace(ps, rays, False, nodes, refs, bounds)
+        hit = rec[:, 8] > 0
+        assert np.array_equal(hits["prim"] >= 0, hit)
+        assert np.array_equal(hits["t"][hit], rec[hit, 9])
+        # u = b1 + b2, v = b2 for the default triangle uvs (trianglemesh.cpp:266-268, :321-326)
+        assert np.array_equal((hits["b1"] + hits["b2"])[hit], rec[hit, 16])
+        assert np.array_equal(hits["b2"][hit], rec[hit, 17])
+        # shadow segments from the hit point to the probe target
+        seg = np.zeros(int(hit.sum()), pkg.RAY_DTYPE)
+        seg["o"] = rec[hit, 10:13]
+        seg["d"] = (np.array([278, 540, 280], np.float32) - rec[hit, 10:13]).astype(np.float32)
+        seg["mint"] = 1e-3; seg["maxt"] = np.float32(1.0) - np.float32(1e-3)
+        occ, _ = oracle.trace(ps, seg, True, nodes, refs, bounds)
+        assert np.array_equal(occ.astype(bool), rec[hit, 18] > 0)
