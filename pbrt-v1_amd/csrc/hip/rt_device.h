@@ -54,6 +54,7 @@ struct DevFrame {
     float fxw, fyw, inv_fxw, inv_fyw;
     const float *filter_table;   // 256 floats in HBM (L1/L2 resident)
     float *accum;                // 5 planes
+    float4 *samples;             // per-shard sample buffer, 2 x float4 per work item
     int shard_index, shard_count, tile_pixels;
     unsigned long long total_work;     // samples this shard renders
     unsigned long long total_pixels;   // pixels in the sample extent

@@ -13,6 +13,7 @@
 #include "rt_integrate.h"
 #include "rt_internal.h"
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -21,9 +22,20 @@
 namespace rt {
 
 // ------------------------------------------------------------------------------------------ kernels
-template <bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void render_kernel(DevScene sc, DevFrame fr) {
+#ifndef RT_MIN_WAVES
+#define RT_MIN_WAVES 1
+#endif
+#ifndef RT_EXIT_THRESH
+#define RT_EXIT_THRESH 0
+#endif
+// Scene and frame descriptors are read through pointers (uniform addresses -> scalar loads on demand) instead of
+// being passed by value: the by-value form pinned >100 SGPRs and spilled them.
+template <bool COUNT, int INTEG>
+__global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void render_kernel(const DevScene *__restrict__ scp,
+                                                                       const DevFrame *__restrict__ frp) {
     __shared__ uint2 lds_stack[RT_STACK_LDS * RT_BLOCK];
+    const DevScene &sc = *scp;
+    const DevFrame &fr = *frp;
     const unsigned gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63;
     Lane ln;
@@ -49,6 +61,7 @@ __global__ __launch_bounds__(RT_BLOCK) void render_kernel(DevScene sc, DevFrame 
                         if (work_to_sample(fr, w, pixel, s)) {
                             Ray ray;
                             setup_sample(sc, fr, ln, pixel, s, ray);
+                            ln.work = uint32_t(w);
                             ln.L = mk3(0.f); ln.thr = mk3(1.f); ln.alpha = 0.f; ln.depth = 0; ln.fsp = 0;
                             ln.specular = false;
                             if (COUNT) ++c_cam;
@@ -59,13 +72,18 @@ __global__ __launch_bounds__(RT_BLOCK) void render_kernel(DevScene sc, DevFrame 
                 }
             }
             if (!ln.has_ray && ln.stage != ST_EXIT && ln.stage != ST_FETCH)
-                advance<COUNT>(sc, fr, ln, gtid, nullptr, &c_cam, &c_closest, &c_any, &c_bad);
+                advance<COUNT, INTEG>(sc, fr, ln, gtid, nullptr, &c_cam, &c_closest, &c_any, &c_bad);
             if (!__any(!ln.has_ray && ln.stage != ST_EXIT)) break;
         }
         if (!__any(ln.has_ray)) break;
-        // ---- extend: one shared traversal loop
-        while (__any(ln.has_ray && ln.tv.active)) {
-            if (ln.has_ray && ln.tv.active) trav_step<COUNT>(ln.tv, sc, lds_stack, fr.spill, fr.n_threads, gtid, tc);
+        // ---- extend: one shared traversal loop.  Leave it early when only a few lanes are still traversing AND some
+        // lane could meanwhile shade / fetch (its traversal state stays in registers + LDS and resumes next round).
+        for (;;) {
+            const bool act = ln.has_ray && ln.tv.active;
+            const unsigned long long am = __ballot(act);
+            if (!am) break;
+            if (RT_EXIT_THRESH > 0 && __popcll(am) <= RT_EXIT_THRESH && __any(!act && ln.stage != ST_EXIT)) break;
+            if (act) trav_step<COUNT>(ln.tv, sc, lds_stack, fr.spill, fr.n_threads, gtid, tc);
         }
         if (ln.has_ray && !ln.tv.active) ln.has_ray = false;
     }
@@ -79,6 +97,50 @@ __global__ __launch_bounds__(RT_BLOCK) void render_kernel(DevScene sc, DevFrame 
             if (lane == 0 && x) atomicAdd(fr.counters + k, x);
         }
     }
+}
+
+// ImageFilm::AddSample (film/image.cpp:103-142) as a gather: one thread per film pixel visits, in the reference's
+// sample order (sample-pixel rows, then columns, then sample-in-pixel), every sample of this shard whose filter
+// footprint can contain the pixel, and accumulates w*L, w*alpha, w on top of what the film already holds.  The
+// footprint test and the filter-table lookup are the reference's own expressions, evaluated per sample.
+__global__ __launch_bounds__(256) void film_gather_kernel(const DevFrame *__restrict__ frp) {
+    const DevFrame &fr = *frp;
+    const int bx = blockIdx.x % ((fr.x_pixel_count + 15) / 16), by = blockIdx.x / ((fr.x_pixel_count + 15) / 16);
+    const int lx = bx * 16 + (threadIdx.x & 15), ly = by * 16 + (threadIdx.x >> 4);
+    if (lx >= fr.x_pixel_count || ly >= fr.y_pixel_count) return;
+    const int x = fr.x_pixel_start + lx, y = fr.y_pixel_start + ly;
+    const size_t plane = size_t(fr.x_pixel_count) * fr.y_pixel_count, px = size_t(ly) * fr.x_pixel_count + lx;
+    float a0 = fr.accum[px], a1 = fr.accum[plane + px], a2 = fr.accum[2 * plane + px], a3 = fr.accum[3 * plane + px],
+          a4 = fr.accum[4 * plane + px];
+    // sample pixels whose samples (imageX in [sx, sx+1]) can reach pixel x: |x - (sx + u - .5)| <= width
+    const int sx0 = max(int(ceilf(x - fr.fxw - 0.5f)), fr.x_start), sx1 = min(int(floorf(x + fr.fxw + 0.5f)), fr.x_end - 1);
+    const int sy0 = max(int(ceilf(y - fr.fyw - 0.5f)), fr.y_start), sy1 = min(int(floorf(y + fr.fyw + 0.5f)), fr.y_end - 1);
+    const int ew = fr.x_end - fr.x_start;
+    const unsigned long long per_tile = (unsigned long long)fr.tile_pixels * fr.spp;
+    const int xlo = fr.x_pixel_start, xhi = fr.x_pixel_start + fr.x_pixel_count - 1;
+    const int ylo = fr.y_pixel_start, yhi = fr.y_pixel_start + fr.y_pixel_count - 1;
+    for (int sy = sy0; sy <= sy1; ++sy)
+        for (int sx = sx0; sx <= sx1; ++sx) {
+            const unsigned long long pixel = (unsigned long long)(sy - fr.y_start) * ew + (sx - fr.x_start);
+            const unsigned long long tile = pixel / fr.tile_pixels;
+            if (int(tile % fr.shard_count) != fr.shard_index) continue;
+            const float4 *rec = fr.samples + ((tile / fr.shard_count) * per_tile + (pixel % fr.tile_pixels) * fr.spp) * 2;
+            for (int s = 0; s < fr.spp; ++s, rec += 2) {
+                const float4 q = rec[1];
+                const float dImageX = q.x - 0.5f, dImageY = q.y - 0.5f;
+                const int x0 = max(int(ceilf(dImageX - fr.fxw)), xlo), x1 = min(int(floorf(dImageX + fr.fxw)), xhi);
+                const int y0 = max(int(ceilf(dImageY - fr.fyw)), ylo), y1 = min(int(floorf(dImageY + fr.fyw)), yhi);
+                if (x < x0 || x > x1 || y < y0 || y > y1) continue;
+                const float fx = fabsf((x - dImageX) * fr.inv_fxw * 16), fy = fabsf((y - dImageY) * fr.inv_fyw * 16);
+                const int ifx = min(int(floorf(fx)), 15), ify = min(int(floorf(fy)), 15);
+                const float wt = fr.filter_table[ify * 16 + ifx];
+                const float4 L = rec[0];
+                a0 += wt * L.x; a1 += wt * L.y; a2 += wt * L.z;       // Spectrum::AddWeighted color.h:116-120
+                a3 += L.w * wt; a4 += wt;
+            }
+        }
+    fr.accum[px] = a0; fr.accum[plane + px] = a1; fr.accum[2 * plane + px] = a2; fr.accum[3 * plane + px] = a3;
+    fr.accum[4 * plane + px] = a4;
 }
 
 __global__ __launch_bounds__(RT_BLOCK) void trace_kernel(DevScene sc, const RtRay *rays, unsigned n, int any,
@@ -143,6 +205,10 @@ struct RtScene {
     uint2 *spill = nullptr; size_t spill_entries = 0;
     float *frames = nullptr; size_t frames_floats = 0;
     unsigned grid = 0, n_threads = 0;
+    unsigned grids[6] = {0, 0, 0, 0, 0, 0};          // resident grid per render_kernel<COUNT, INTEG> instantiation
+    DevScene *dev_scene = nullptr; DevFrame *dev_frame = nullptr;   // descriptors in HBM (read with scalar loads)
+    float4 *samples = nullptr; size_t samples_cap = 0;          // per-shard sample buffer
+    float ms_render = 0.f, ms_gather = 0.f; hipEvent_t ev2 = nullptr;
     int spill_depth = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_timing = false;
@@ -265,11 +331,21 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
     s->dev.cam = d->camera; s->dev.vol = d->volume;
 
     // persistent launch geometry: as many resident blocks as the kernel's registers/LDS admit
-    int per_cu = 0; hipDeviceProp_t prop;
+    hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, s->device));
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<true>, RT_BLOCK, 0));
-    if (per_cu < 1) per_cu = 1;
-    s->grid = unsigned(prop.multiProcessorCount) * unsigned(per_cu);
+    {
+        const void *kernels[6] = {(const void *)render_kernel<false, 0>, (const void *)render_kernel<false, 1>, (const void *)render_kernel<false, 2>,
+                                  (const void *)render_kernel<true, 0>, (const void *)render_kernel<true, 1>, (const void *)render_kernel<true, 2>};
+        unsigned mx = 0;
+        for (int k = 0; k < 6; ++k) {
+            int per_cu = 0;
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernels[k], RT_BLOCK, 0));
+            if (per_cu < 1) per_cu = 1;
+            s->grids[k] = unsigned(prop.multiProcessorCount) * unsigned(per_cu);
+            mx = s->grids[k] > mx ? s->grids[k] : mx;
+        }
+        s->grid = mx;
+    }
     s->n_threads = s->grid * RT_BLOCK;
     s->spill_depth = s->tree.max_depth > RT_STACK_LDS ? s->tree.max_depth - RT_STACK_LDS + 1 : 1;
     HIPCHK(hipMalloc((void **)&s->spill, size_t(s->spill_depth) * s->n_threads * sizeof(uint2)));
@@ -277,6 +353,10 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
     HIPCHK(hipMalloc((void **)&s->counters, 8 * sizeof(unsigned long long)));
     HIPCHK(hipMemset(s->counters, 0, 8 * sizeof(unsigned long long)));
     HIPCHK(hipMalloc((void **)&s->filter_dev, 256 * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&s->dev_scene, sizeof(DevScene)));
+    HIPCHK(hipMalloc((void **)&s->dev_frame, sizeof(DevFrame)));
+    HIPCHK(hipMemcpy(s->dev_scene, &s->dev, sizeof(DevScene), hipMemcpyHostToDevice));
+    HIPCHK(hipEventCreate(&s->ev2));
     *out = s;
     return RT_OK;
 }
@@ -289,6 +369,9 @@ int rt_scene_destroy(RtScene *s) {
     if (s->own_accum && s->accum) hipFree(s->accum);
     hipFree(s->spill); hipFree(s->work_counter); hipFree(s->counters); hipFree(s->filter_dev);
     if (s->frames) hipFree(s->frames);
+    if (s->samples) hipFree(s->samples);
+    hipFree(s->dev_scene); hipFree(s->dev_frame);
+    if (s->ev2) hipEventDestroy(s->ev2);
     if (s->ev0) hipEventDestroy(s->ev0);
     if (s->ev1) hipEventDestroy(s->ev1);
     if (s->own_stream && s->stream) hipStreamDestroy(s->stream);
@@ -424,7 +507,7 @@ static int trace_common(RtScene *s, const RtRay *rays, uint32_t n, int any, RtHi
     hipEventRecord(s->ev0, s->stream);
     hipLaunchKernelGGL(trace_kernel, dim3(s->grid), dim3(RT_BLOCK), 0, s->stream, s->dev, drays, n, any,
                        (RtHit *)(any ? nullptr : dout), (unsigned char *)(any ? dout : nullptr), s->spill, s->n_threads, s->counters);
-    hipEventRecord(s->ev1, s->stream); s->have_timing = true;
+    hipEventRecord(s->ev1, s->stream); hipEventRecord(s->ev2, s->stream); s->have_timing = true;
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s->stream));
     HIPCHK(hipMemcpy(any ? (void *)occ : (void *)hits, dout, out_bytes, hipMemcpyDeviceToHost));
@@ -502,13 +585,35 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
         }
     }
     DevFrame fr; int rc = make_frame(s, rd, fr, true); if (rc) return rc;
+    const bool skip_film = std::getenv("PBRT_HIP_DEBUG_NOFILM") != nullptr;   // perf experiments only
+    if (fr.total_work > s->samples_cap) {
+        if (s->samples) { HIPCHK(hipStreamSynchronize(s->stream)); hipFree(s->samples); s->samples = nullptr; }
+        HIPCHK(hipMalloc((void **)&s->samples, size_t(fr.total_work) * 2 * sizeof(float4)));
+        s->samples_cap = fr.total_work;
+    }
+    fr.samples = s->samples;
+    const int variant = (s->counting ? 3 : 0) + rd->integrator;
     HIPCHK(hipMemcpyAsync(s->filter_dev, rd->filter_table, 256 * sizeof(float), hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(s->dev_frame, &fr, sizeof(DevFrame), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemsetAsync(s->work_counter, 0, sizeof(unsigned long long), s->stream));
     HIPCHK(hipEventRecord(s->ev0, s->stream));
-    if (s->counting) hipLaunchKernelGGL(render_kernel<true>, dim3(s->grid), dim3(RT_BLOCK), 0, s->stream, s->dev, fr);
-    else hipLaunchKernelGGL(render_kernel<false>, dim3(s->grid), dim3(RT_BLOCK), 0, s->stream, s->dev, fr);
+    const dim3 grid(s->grids[variant]), block(RT_BLOCK);
+    switch (variant) {
+    case 0: hipLaunchKernelGGL((render_kernel<false, 0>), grid, block, 0, s->stream, s->dev_scene, s->dev_frame); break;
+    case 1: hipLaunchKernelGGL((render_kernel<false, 1>), grid, block, 0, s->stream, s->dev_scene, s->dev_frame); break;
+    case 2: hipLaunchKernelGGL((render_kernel<false, 2>), grid, block, 0, s->stream, s->dev_scene, s->dev_frame); break;
+    case 3: hipLaunchKernelGGL((render_kernel<true, 0>), grid, block, 0, s->stream, s->dev_scene, s->dev_frame); break;
+    case 4: hipLaunchKernelGGL((render_kernel<true, 1>), grid, block, 0, s->stream, s->dev_scene, s->dev_frame); break;
+    default: hipLaunchKernelGGL((render_kernel<true, 2>), grid, block, 0, s->stream, s->dev_scene, s->dev_frame); break;
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->ev1, s->stream));
+    if (!skip_film) {
+        const unsigned gb = unsigned((fr.x_pixel_count + 15) / 16) * unsigned((fr.y_pixel_count + 15) / 16);
+        hipLaunchKernelGGL(film_gather_kernel, dim3(gb), dim3(256), 0, s->stream, s->dev_frame);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(s->ev2, s->stream));
     s->have_timing = true;
     return RT_OK;
 }
@@ -544,11 +649,12 @@ int rt_set_counting(RtScene *s, int enabled) {
 int rt_last_render_ms(RtScene *s, float *total_ms, float *kernel_ms) {
     if (!s || !s->have_timing) return fail(RT_ESTATE, "no timed launch yet");
     HIPCHK(hipSetDevice(s->device));
-    HIPCHK(hipEventSynchronize(s->ev1));
-    float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
-    if (total_ms) *total_ms = ms;
-    if (kernel_ms) *kernel_ms = ms;
+    HIPCHK(hipEventSynchronize(s->ev2));
+    float k = 0.f, t = 0.f;
+    HIPCHK(hipEventElapsedTime(&k, s->ev0, s->ev1));
+    HIPCHK(hipEventElapsedTime(&t, s->ev0, s->ev2));
+    if (total_ms) *total_ms = t;        // render kernel + film gather
+    if (kernel_ms) *kernel_ms = k;      // rt::render_kernel alone (the dominant kernel)
     return RT_OK;
 }
 

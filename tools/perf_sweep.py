@@ -1,0 +1,48 @@
+"""Build kernel variants (-D knobs) on the GPU box and bench each; prints one JSON line per variant."""
+import json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+HIP = os.path.join(ROOT, "pbrt-v1_amd", "csrc", "hip")
+LIB = os.path.join(ROOT, "pbrt-v1_amd", "lib", "libpbrt_hip.so")
+BASE = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unused-value"]
+
+def run(tag, defs=(), env=None, workload="c2", steps=2, extra=()):
+    cmd = BASE + list(defs) + [os.path.join(HIP, "rt_kernels.hip"), os.path.join(HIP, "kd_build.cpp"), "-o", LIB]
+    subprocess.check_call(cmd)
+    e = dict(os.environ); e.update(env or {})
+    try:
+      r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--steps", str(steps), "--warmup", "1",
+                        "--workload", workload] + list(extra), env=e, capture_output=True, text=True, timeout=240)
+    except subprocess.TimeoutExpired:
+      print(json.dumps(dict(tag=tag, error="timeout"))); return
+    try:
+        j = json.loads(r.stdout.strip().splitlines()[-1])
+        print(json.dumps(dict(tag=tag, workload=workload, Mrays=j["value"], ms=j["ms_per_step"], kernel_ms=j["roofline"]["kernel_ms"],
+                              frac=j["roofline"]["frac"], rays_per_frame=j["config"]["rays_per_frame"])), flush=True)
+    except Exception as ex:
+        print(json.dumps(dict(tag=tag, error=str(ex), stderr=r.stderr[-800:])), flush=True)
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "a"
+    if which == "b":
+        run("base")
+        run("nofilm", env={"PBRT_HIP_DEBUG_NOFILM": "1"})
+        run("waves4_lds12", ["-DRT_MIN_WAVES=4", "-DRT_STACK_LDS=12"])
+        run("waves4_lds16", ["-DRT_MIN_WAVES=4", "-DRT_STACK_LDS=16"])
+        run("waves5_lds12", ["-DRT_MIN_WAVES=5", "-DRT_STACK_LDS=12"])
+        run("waves4_lds12_exit16", ["-DRT_MIN_WAVES=4", "-DRT_STACK_LDS=12", "-DRT_EXIT_THRESH=16"])
+        run("waves4_lds12_exit32", ["-DRT_MIN_WAVES=4", "-DRT_STACK_LDS=12", "-DRT_EXIT_THRESH=32"])
+        run("c3_100k_base", workload="c3_100000")
+        run("c3_100k_w4", ["-DRT_MIN_WAVES=4", "-DRT_STACK_LDS=16"], workload="c3_100000")
+        run("c3_100k_w4_exit24", ["-DRT_MIN_WAVES=4", "-DRT_STACK_LDS=16", "-DRT_EXIT_THRESH=24"], workload="c3_100000")
+    if which == "a":
+        run("base")
+        run("nofilm", env={"PBRT_HIP_DEBUG_NOFILM": "1"})
+        run("waves2", ["-DRT_MIN_WAVES=2"])
+        run("waves3_lds16", ["-DRT_MIN_WAVES=3", "-DRT_STACK_LDS=16"])
+        run("waves4_lds12", ["-DRT_MIN_WAVES=4", "-DRT_STACK_LDS=12"])
+        run("exit16", ["-DRT_EXIT_THRESH=16"])
+        run("exit32", ["-DRT_EXIT_THRESH=32"])
+        run("c3_100k_base", workload="c3_100000")
+        run("c3_100k_exit24", ["-DRT_EXIT_THRESH=24"], workload="c3_100000")
+    run("base_restore")
