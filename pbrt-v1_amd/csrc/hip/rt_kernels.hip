@@ -46,7 +46,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void render_kernel(const De
 
     for (;;) {
         // ---- shade / regenerate: run every lane that is not waiting on a ray until it is (or is out of work)
-        for (;;) {
+        do {
+            advance_pass<COUNT, INTEG>(sc, fr, ln, gtid, &c_closest, &c_any, &c_bad);
             const unsigned long long want = __ballot(!ln.has_ray && ln.stage == ST_FETCH);
             if (want) {                                                   // wave-aggregated work fetch
                 const int leader = __ffsll((long long)want) - 1;
@@ -71,10 +72,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void render_kernel(const De
                     }
                 }
             }
-            if (!ln.has_ray && ln.stage != ST_EXIT && ln.stage != ST_FETCH)
-                advance<COUNT, INTEG>(sc, fr, ln, gtid, nullptr, &c_cam, &c_closest, &c_any, &c_bad);
-            if (!__any(!ln.has_ray && ln.stage != ST_EXIT)) break;
-        }
+        } while (__any(!ln.has_ray && ln.stage != ST_EXIT));
         if (!__any(ln.has_ray)) break;
         // ---- extend: one shared traversal loop.  Leave it early when only a few lanes are still traversing AND some
         // lane could meanwhile shade / fetch (its traversal state stays in registers + LDS and resumes next round).

@@ -24,6 +24,12 @@ def run(tag, defs=(), env=None, workload="c2", steps=2, extra=()):
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "a"
+    if which == "c":
+        run("base")
+        run("nofilm", env={"PBRT_HIP_DEBUG_NOFILM": "1"})
+        run("c3_100k_base", workload="c3_100000")
+        run("c3_100k_exit24", ["-DRT_EXIT_THRESH=24"], workload="c3_100000")
+        run("c1", workload="c1", steps=5)
     if which == "b":
         run("base")
         run("nofilm", env={"PBRT_HIP_DEBUG_NOFILM": "1"})
