@@ -101,15 +101,21 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void render_kernel(const De
 // sample order (sample-pixel rows, then columns, then sample-in-pixel), every sample of this shard whose filter
 // footprint can contain the pixel, and accumulates w*L, w*alpha, w on top of what the film already holds.  The
 // footprint test and the filter-table lookup are the reference's own expressions, evaluated per sample.
-__global__ __launch_bounds__(256) void film_gather_kernel(const DevFrame *__restrict__ frp) {
+// A 16x16-pixel workgroup stages the sample records of one sample-pixel row (chunked by columns) in LDS, so each
+// 32-byte record is fetched from HBM/L2 once per workgroup instead of once per pixel in its footprint (25x for the
+// 2x2 Mitchell filter).  Column blocks are padded by one float4 so that the 16 lanes of a row, which read 16
+// consecutive columns at the same sample slot, hit 16 different 16-byte LDS slots (conflict-free ds_read_b128).
+__global__ __launch_bounds__(256) void film_gather_kernel(const DevFrame *__restrict__ frp, int rx, int ry, int cols_per_chunk) {
+    extern __shared__ __attribute__((aligned(16))) float4 lds_rec[];
     const DevFrame &fr = *frp;
-    const int bx = blockIdx.x % ((fr.x_pixel_count + 15) / 16), by = blockIdx.x / ((fr.x_pixel_count + 15) / 16);
+    const int nbx = (fr.x_pixel_count + 15) / 16;
+    const int bx = blockIdx.x % nbx, by = blockIdx.x / nbx;
     const int lx = bx * 16 + (threadIdx.x & 15), ly = by * 16 + (threadIdx.x >> 4);
-    if (lx >= fr.x_pixel_count || ly >= fr.y_pixel_count) return;
+    const bool live = lx < fr.x_pixel_count && ly < fr.y_pixel_count;
     const int x = fr.x_pixel_start + lx, y = fr.y_pixel_start + ly;
     const size_t plane = size_t(fr.x_pixel_count) * fr.y_pixel_count, px = size_t(ly) * fr.x_pixel_count + lx;
-    float a0 = fr.accum[px], a1 = fr.accum[plane + px], a2 = fr.accum[2 * plane + px], a3 = fr.accum[3 * plane + px],
-          a4 = fr.accum[4 * plane + px];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+    if (live) { a0 = fr.accum[px]; a1 = fr.accum[plane + px]; a2 = fr.accum[2 * plane + px]; a3 = fr.accum[3 * plane + px]; a4 = fr.accum[4 * plane + px]; }
     // sample pixels whose samples (imageX in [sx, sx+1]) can reach pixel x: |x - (sx + u - .5)| <= width
     const int sx0 = max(int(ceilf(x - fr.fxw - 0.5f)), fr.x_start), sx1 = min(int(floorf(x + fr.fxw + 0.5f)), fr.x_end - 1);
     const int sy0 = max(int(ceilf(y - fr.fyw - 0.5f)), fr.y_start), sy1 = min(int(floorf(y + fr.fyw + 0.5f)), fr.y_end - 1);
@@ -117,28 +123,74 @@ __global__ __launch_bounds__(256) void film_gather_kernel(const DevFrame *__rest
     const unsigned long long per_tile = (unsigned long long)fr.tile_pixels * fr.spp;
     const int xlo = fr.x_pixel_start, xhi = fr.x_pixel_start + fr.x_pixel_count - 1;
     const int ylo = fr.y_pixel_start, yhi = fr.y_pixel_start + fr.y_pixel_count - 1;
-    for (int sy = sy0; sy <= sy1; ++sy)
-        for (int sx = sx0; sx <= sx1; ++sx) {
-            const unsigned long long pixel = (unsigned long long)(sy - fr.y_start) * ew + (sx - fr.x_start);
-            const unsigned long long tile = pixel / fr.tile_pixels;
-            if (int(tile % fr.shard_count) != fr.shard_index) continue;
-            const float4 *rec = fr.samples + ((tile / fr.shard_count) * per_tile + (pixel % fr.tile_pixels) * fr.spp) * 2;
-            for (int s = 0; s < fr.spp; ++s, rec += 2) {
-                const float4 q = rec[1];
-                const float dImageX = q.x - 0.5f, dImageY = q.y - 0.5f;
-                const int x0 = max(int(ceilf(dImageX - fr.fxw)), xlo), x1 = min(int(floorf(dImageX + fr.fxw)), xhi);
-                const int y0 = max(int(ceilf(dImageY - fr.fyw)), ylo), y1 = min(int(floorf(dImageY + fr.fyw)), yhi);
-                if (x < x0 || x > x1 || y < y0 || y > y1) continue;
-                const float fx = fabsf((x - dImageX) * fr.inv_fxw * 16), fy = fabsf((y - dImageY) * fr.inv_fyw * 16);
-                const int ifx = min(int(floorf(fx)), 15), ify = min(int(floorf(fy)), 15);
-                const float wt = fr.filter_table[ify * 16 + ifx];
-                const float4 L = rec[0];
-                a0 += wt * L.x; a1 += wt * L.y; a2 += wt * L.z;       // Spectrum::AddWeighted color.h:116-120
-                a3 += L.w * wt; a4 += wt;
+    const int X0 = fr.x_pixel_start + bx * 16, Y0 = fr.y_pixel_start + by * 16;
+    const int bsx0 = max(X0 - rx, fr.x_start), bsx1 = min(X0 + 15 + rx, fr.x_end - 1);
+    const int bsy0 = max(Y0 - ry, fr.y_start), bsy1 = min(Y0 + 15 + ry, fr.y_end - 1);
+    const int col_stride = fr.spp * 2 + 1;                              // float4 units, +1 pad
+    int *owned = reinterpret_cast<int *>(lds_rec + size_t(cols_per_chunk) * col_stride);
+    for (int sy = bsy0; sy <= bsy1; ++sy)
+        for (int cx = bsx0; cx <= bsx1; cx += cols_per_chunk) {
+            const int ncols = min(cols_per_chunk, bsx1 - cx + 1);
+            __syncthreads();
+            const int per_col = fr.spp * 2;
+            for (int i = threadIdx.x; i < ncols * per_col; i += 256) {
+                const int c = i / per_col, k = i - c * per_col;
+                const unsigned long long pixel = (unsigned long long)(sy - fr.y_start) * ew + (cx + c - fr.x_start);
+                const unsigned long long tile = pixel / fr.tile_pixels;
+                const bool mine = int(tile % fr.shard_count) == fr.shard_index;
+                if (k == 0) owned[c] = mine ? 1 : 0;
+                if (mine) lds_rec[c * col_stride + k] = fr.samples[((tile / fr.shard_count) * per_tile + (pixel % fr.tile_pixels) * fr.spp) * 2 + k];
+            }
+            __syncthreads();
+            if (!live || sy < sy0 || sy > sy1) continue;
+            for (int sx = max(cx, sx0); sx <= min(cx + ncols - 1, sx1); ++sx) {
+                const int c = sx - cx;
+                if (!owned[c]) continue;
+                const float4 *rec = lds_rec + c * col_stride;
+                for (int s = 0; s < fr.spp; ++s, rec += 2) {
+                    const float4 q = rec[1];
+                    const float dImageX = q.x - 0.5f, dImageY = q.y - 0.5f;
+                    const int x0 = max(int(ceilf(dImageX - fr.fxw)), xlo), x1 = min(int(floorf(dImageX + fr.fxw)), xhi);
+                    const int y0 = max(int(ceilf(dImageY - fr.fyw)), ylo), y1 = min(int(floorf(dImageY + fr.fyw)), yhi);
+                    if (x < x0 || x > x1 || y < y0 || y > y1) continue;
+                    const float fx = fabsf((x - dImageX) * fr.inv_fxw * 16), fy = fabsf((y - dImageY) * fr.inv_fyw * 16);
+                    const int ifx = min(int(floorf(fx)), 15), ify = min(int(floorf(fy)), 15);
+                    const float wt = fr.filter_table[ify * 16 + ifx];
+                    const float4 L = rec[0];
+                    a0 += wt * L.x; a1 += wt * L.y; a2 += wt * L.z;       // Spectrum::AddWeighted color.h:116-120
+                    a3 += L.w * wt; a4 += wt;
+                }
             }
         }
-    fr.accum[px] = a0; fr.accum[plane + px] = a1; fr.accum[2 * plane + px] = a2; fr.accum[3 * plane + px] = a3;
-    fr.accum[4 * plane + px] = a4;
+    if (live) {
+        fr.accum[px] = a0; fr.accum[plane + px] = a1; fr.accum[2 * plane + px] = a2; fr.accum[3 * plane + px] = a3;
+        fr.accum[4 * plane + px] = a4;
+    }
+}
+
+// ImageFilm::WriteImage (film/image.cpp:157-203) on the device: XYZ round trip (color.h:177-184, color.cpp:35-43),
+// divide by the weight sum, clamps, premultiply.  out = rgb[H][W][3] then alpha[H][W].
+__global__ void film_resolve_kernel(const float *__restrict__ accum, size_t n, int premultiply, float *__restrict__ rgb,
+                                    float *__restrict__ alpha) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float c0 = accum[i], c1 = accum[n + i], c2 = accum[2 * n + i];
+    float xyz0 = 0.f, xyz1 = 0.f, xyz2 = 0.f;
+    xyz0 += 0.412453f * c0; xyz1 += 0.212671f * c0; xyz2 += 0.019334f * c0;
+    xyz0 += 0.357580f * c1; xyz1 += 0.715160f * c1; xyz2 += 0.119193f * c1;
+    xyz0 += 0.180423f * c2; xyz1 += 0.072169f * c2; xyz2 += 0.950227f * c2;
+    float r = 3.240479f * xyz0 + -1.537150f * xyz1 + -0.498535f * xyz2;
+    float g = -0.969256f * xyz0 + 1.875991f * xyz1 + 0.041556f * xyz2;
+    float b = 0.055648f * xyz0 + -0.204043f * xyz1 + 1.057311f * xyz2;
+    float a = accum[3 * n + i];
+    const float ws = accum[4 * n + i];
+    if (ws != 0.f) {
+        const float inv = 1.f / ws;
+        r = clampf(r * inv, 0.f, RT_INF); g = clampf(g * inv, 0.f, RT_INF); b = clampf(b * inv, 0.f, RT_INF);
+        a = clampf(a * inv, 0.f, 1.f);
+    }
+    if (premultiply) { r *= a; g *= a; b *= a; }
+    rgb[3 * i] = r; rgb[3 * i + 1] = g; rgb[3 * i + 2] = b; alpha[i] = a;
 }
 
 __global__ __launch_bounds__(RT_BLOCK) void trace_kernel(DevScene sc, const RtRay *rays, unsigned n, int any,
@@ -207,6 +259,7 @@ struct RtScene {
     DevScene *dev_scene = nullptr; DevFrame *dev_frame = nullptr;   // descriptors in HBM (read with scalar loads)
     float4 *samples = nullptr; size_t samples_cap = 0;          // per-shard sample buffer
     float ms_render = 0.f, ms_gather = 0.f; hipEvent_t ev2 = nullptr;
+    float *resolve_buf = nullptr; size_t resolve_cap = 0;
     int spill_depth = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_timing = false;
@@ -368,6 +421,7 @@ int rt_scene_destroy(RtScene *s) {
     hipFree(s->spill); hipFree(s->work_counter); hipFree(s->counters); hipFree(s->filter_dev);
     if (s->frames) hipFree(s->frames);
     if (s->samples) hipFree(s->samples);
+    if (s->resolve_buf) hipFree(s->resolve_buf);
     hipFree(s->dev_scene); hipFree(s->dev_frame);
     if (s->ev2) hipEventDestroy(s->ev2);
     if (s->ev0) hipEventDestroy(s->ev0);
@@ -544,30 +598,19 @@ int rt_film_read(RtScene *s, float *host_accum) {
 // ImageFilm::WriteImage film/image.cpp:157-203; Spectrum::XYZ color.h:177-184, weights color.cpp:35-43
 int rt_film_resolve(RtScene *s, int premultiply, float *rgb_out, float *alpha_out) {
     if (!s || !rgb_out || !alpha_out) return fail(RT_EINVAL, "null argument");
+    if (!s->accum) return fail(RT_ESTATE, "no film bound");
+    HIPCHK(hipSetDevice(s->device));
     const size_t n = size_t(s->film_w) * s->film_h;
-    std::vector<float> acc(5 * n);
-    int rc = rt_film_read(s, acc.data()); if (rc) return rc;
-    const float XW[3] = {0.412453f, 0.357580f, 0.180423f}, YW[3] = {0.212671f, 0.715160f, 0.072169f},
-                ZW[3] = {0.019334f, 0.119193f, 0.950227f};
-    for (size_t i = 0; i < n; ++i) {
-        const float c[3] = {acc[i], acc[n + i], acc[2 * n + i]};
-        float xyz[3] = {0.f, 0.f, 0.f};
-        for (int k = 0; k < 3; ++k) { xyz[0] += XW[k] * c[k]; xyz[1] += YW[k] * c[k]; xyz[2] += ZW[k] * c[k]; }
-        float r = 3.240479f * xyz[0] + -1.537150f * xyz[1] + -0.498535f * xyz[2];
-        float g = -0.969256f * xyz[0] + 1.875991f * xyz[1] + 0.041556f * xyz[2];
-        float b = 0.055648f * xyz[0] + -0.204043f * xyz[1] + 1.057311f * xyz[2];
-        float a = acc[3 * n + i];
-        const float ws = acc[4 * n + i];
-        if (ws != 0.f) {
-            const float inv = 1.f / ws;
-            r = r * inv; r = r < 0.f ? 0.f : r;
-            g = g * inv; g = g < 0.f ? 0.f : g;
-            b = b * inv; b = b < 0.f ? 0.f : b;
-            a = a * inv; a = a < 0.f ? 0.f : (a > 1.f ? 1.f : a);
-        }
-        if (premultiply) { r *= a; g *= a; b *= a; }
-        rgb_out[3 * i] = r; rgb_out[3 * i + 1] = g; rgb_out[3 * i + 2] = b; alpha_out[i] = a;
+    if (s->resolve_cap < n) {
+        if (s->resolve_buf) hipFree(s->resolve_buf);
+        HIPCHK(hipMalloc((void **)&s->resolve_buf, n * 4 * sizeof(float))); s->resolve_cap = n;
     }
+    hipLaunchKernelGGL(film_resolve_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s->stream, s->accum, n, premultiply,
+                       s->resolve_buf, s->resolve_buf + 3 * n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(rgb_out, s->resolve_buf, 3 * n * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(alpha_out, s->resolve_buf + 3 * n, n * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
     return RT_OK;
 }
 
@@ -608,7 +651,13 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
     HIPCHK(hipEventRecord(s->ev1, s->stream));
     if (!skip_film) {
         const unsigned gb = unsigned((fr.x_pixel_count + 15) / 16) * unsigned((fr.y_pixel_count + 15) / 16);
-        hipLaunchKernelGGL(film_gather_kernel, dim3(gb), dim3(256), 0, s->stream, s->dev_frame);
+        const int grx = int(std::floor(fr.fxw + 0.5f)), gry = int(std::floor(fr.fyw + 0.5f));   // reach of a sample pixel: |x - sx| <= w + .5
+        const size_t col_bytes = size_t(fr.spp * 2 + 1) * sizeof(float4);
+        int cols = int((size_t(60) << 10) / col_bytes);
+        if (cols < 1) return fail(RT_EINVAL, "rt_render: more samples per pixel than the film gather stages in LDS (max ~1900)");
+        if (cols > 16 + 2 * grx) cols = 16 + 2 * grx;
+        const size_t lds_bytes = size_t(cols) * col_bytes + size_t(cols) * sizeof(int) + 16;
+        hipLaunchKernelGGL(film_gather_kernel, dim3(gb), dim3(256), lds_bytes, s->stream, s->dev_frame, grx, gry, cols);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(s->ev2, s->stream));
