@@ -1,0 +1,17 @@
+#!/bin/bash
+# Profile the bench command with rocprofv3 (GPU box).  usage: tools/profile_r.sh <tag> [bench args...]
+# Pass 1: --kernel-trace --stats (per-kernel time).  Passes 2-4: PMC counters, each in its own run.
+set -u
+TAG=${1:-r01}; shift || true
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+CMD="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline $*"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o t -- $CMD > $OUT/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o t -- $CMD > $OUT/pmc_write.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD --output-format csv -d $OUT/pmc_sq -o t -- $CMD > $OUT/pmc_sq.log 2>&1
+timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_l2 -o t -- $CMD > $OUT/pmc_l2.log 2>&1
+find $OUT -name "*.csv" | head -30
+for f in $(find $OUT/trace -name "*kernel_stats.csv"); do echo "== $f"; head -12 $f; done
+python $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT
