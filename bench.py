@@ -181,6 +181,16 @@ def main():
                          "nodes_per_ray": round(cnt["nodes_visited"] / max(rays_local, 1), 2),
                          "tri_tests_per_ray": round(cnt["tri_tests"] / max(rays_local, 1), 2)},
         }
+        # HBM traffic of the same kernel from the PMC passes of tools/profile_r.sh (separate rocprofv3 runs of this very
+        # command; counters and corrections as MI355X_MICROARCH.md prescribes), committed under profiles/
+        prof = os.path.join(ROOT, "profiles", "latest_%s_render_kernel.json" % args.workload)
+        if world == 1 and os.path.exists(prof):
+            pj = json.load(open(prof))
+            out["roofline"]["traffic"] = int(pj["hbm_bytes_per_launch_fetch_doubled"])
+            out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(os.path.realpath(prof)) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per launch)"
+            out["roofline"]["note"] = ("this workload's 23-node tree and 14 triangles are L1/L2 resident: measured HBM traffic is ~1% of the "
+                                       "algorithmic bytes, so the HBM roofline is not the binding limit here; VALU issue under divergence is "
+                                       "(VALUBusy %.0f%%, %.0f%% of lanes active)" % (pj["derived"]["VALUBusy_percent"], pj["derived"]["VALUUtilization_percent_active_lanes"]))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, args.workload, crop)
             if out["cpu_baseline"].get("value"):
