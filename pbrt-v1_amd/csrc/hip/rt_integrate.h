@@ -76,6 +76,55 @@ RT_DEV float lhs_value(const Lane &ln, const DimReq &r, int j, int d) {
     return (pos + rng_f32(ln.rng.base, fb + pos * r.dims + d)) * delta;
 }
 
+// (0,2)-sequence generators of core/sampling.h:137-151
+RT_DEV float van_der_corput(uint32_t n, uint32_t scramble) {
+    n = (n << 16) | (n >> 16);
+    n = ((n & 0x00ff00ffu) << 8) | ((n & 0xff00ff00u) >> 8);
+    n = ((n & 0x0f0f0f0fu) << 4) | ((n & 0xf0f0f0f0u) >> 4);
+    n = ((n & 0x33333333u) << 2) | ((n & 0xccccccccu) >> 2);
+    n = ((n & 0x55555555u) << 1) | ((n & 0xaaaaaaaau) >> 1);
+    n ^= scramble;
+    return (float)n / (float)0x100000000LL;
+}
+RT_DEV float sobol2(uint32_t n, uint32_t scramble) {
+    for (uint32_t v = 1u << 31; n != 0; n >>= 1, v ^= v >> 1)
+        if (n & 0x1) scramble ^= v;
+    return (float)scramble / (float)0x100000000LL;
+}
+// Shuffle(samp, count, dims) (sampling.cpp:91-97) replayed backwards: which original element ends at `pos`.
+// Its `count` RandomUInt() draws sit at counters off .. off+count-1 of the stream `base`.
+RT_DEV int shuffle_origin(uint32_t base, uint32_t off, int count, int pos) {
+    for (int k = count - 1; k >= 0; --k) {
+        const int other = int(rng_u32(base, off + k) % uint32_t(count));
+        if (pos == k) pos = other; else if (pos == other) pos = k;
+    }
+    return pos;
+}
+// key under which a pixel's sample set is generated: the key of its first sample (the keyed wrapper re-keys on
+// every GetNextSample), except pixel 0 of the stratified / random samplers, whose constructor draws it.
+RT_DEV uint32_t pixel_stream(const DevFrame &fr, const Lane &ln) {
+    const uint32_t n0 = ln.sample_index - (ln.work % uint32_t(fr.spp));
+    if (n0 == 0 && fr.sampler != RT_SAMPLER_LOWDISCREPANCY) return rng_base(0xFFFFFFFFu, fr.seed);
+    return rng_base(n0, fr.seed);
+}
+// Value j, dimension d of one Sample::oneD/twoD request for the current camera sample, for the three samplers:
+//   stratified      LatinHypercube per sample (sampling.cpp:98-113)                        -> lhs_value
+//   random          one RandomFloat() per value, in request order (random.cpp:107-112)
+//   lowdiscrepancy  per-pixel scrambled (0,2)-sequence tables, shuffled within each sample's block and then across
+//                   the pixel's samples (lowdiscrepancy.cpp:93-104, sampling.h:152-174); every draw addressable
+RT_DEV float dim_value(const DevFrame &fr, const Lane &ln, const DimReq &r, int j, int d) {
+    if (fr.sampler == RT_SAMPLER_STRATIFIED) return lhs_value(ln, r, j, d);
+    if (fr.sampler == RT_SAMPLER_RANDOM) return rng_f32(ln.rng.base, ln.dim_base + r.f_base + j * r.dims + d);
+    const uint32_t pb = pixel_stream(fr, ln);
+    const int P = fr.spp, n = r.n, s = int(ln.work % uint32_t(P));
+    const uint32_t nscr = r.dims;                                    // 1 or 2 scramble words lead the block
+    const int blk = shuffle_origin(pb, r.f_base + nscr + uint32_t(n) * P, P, s);
+    const int jb = (n == 1) ? 0 : shuffle_origin(pb, r.f_base + nscr + uint32_t(blk) * n, n, j);
+    const uint32_t idx = uint32_t(blk) * n + jb;
+    if (r.dims == 1) return van_der_corput(idx, rng_u32(pb, r.f_base));
+    return d == 0 ? van_der_corput(idx, rng_u32(pb, r.f_base)) : sobol2(idx, rng_u32(pb, r.f_base + 1));
+}
+
 // ---- Scene::Render's radiance sanity check (scene.cpp:60-74); the sample's value is parked in the per-shard
 // sample buffer (32 B: L.rgb, alpha, imageX, imageY) and splatted by film_gather_kernel, which replays
 // ImageFilm::AddSample (image.cpp:103-142) per pixel in the reference's sample order.  Compared with
@@ -160,12 +209,33 @@ RT_DEV void setup_sample(const DevScene &sc, const DevFrame &fr, Lane &ln, unsig
     ln.sample_index = n0 + uint32_t(s);
     ln.rng.base = rng_base(ln.sample_index, fr.seed);
     // the first pixel's strata are drawn by the sampler's constructor, before any sample key exists
-    const uint32_t pix_base = (pixel == 0) ? rng_base(0xFFFFFFFFu, fr.seed) : rng_base(n0, fr.seed);
-    ln.dim_base = (s == 0 && pixel != 0) ? fr.pixgen_draws : 0u;
-    ln.rng.ctr = ln.dim_base + fr.lhs_total;
-    float lu, lv;
-    stratified_camera_sample(fr, uint32_t(pixel), s, px, py, pix_base, ln.image_x, ln.image_y, lu, lv,
-                             sc.cam.lens_radius > 0.f);
+    float lu = 0.5f, lv = 0.5f;
+    const bool need_lens = sc.cam.lens_radius > 0.f;
+    if (fr.sampler == RT_SAMPLER_STRATIFIED) {
+        // the first pixel's strata are drawn by the sampler's constructor, before any sample key exists
+        const uint32_t pix_base = (pixel == 0) ? rng_base(0xFFFFFFFFu, fr.seed) : rng_base(n0, fr.seed);
+        ln.dim_base = (s == 0 && pixel != 0) ? fr.pixgen_draws : 0u;
+        stratified_camera_sample(fr, uint32_t(pixel), s, px, py, pix_base, ln.image_x, ln.image_y, lu, lv, need_lens);
+    } else if (fr.sampler == RT_SAMPLER_RANDOM) {                       // random.cpp:45-106
+        const uint32_t pix_base = (pixel == 0) ? rng_base(0xFFFFFFFFu, fr.seed) : rng_base(n0, fr.seed);
+        ln.dim_base = (s == 0 && pixel != 0) ? fr.pixgen_draws : 0u;
+        ln.image_x = rng_f32(pix_base, 2 * s); ln.image_y = rng_f32(pix_base, 2 * s + 1);
+        ln.image_x += px; ln.image_y += py;
+        if (need_lens) { lu = rng_f32(pix_base, 2 * fr.spp + 2 * s); lv = rng_f32(pix_base, 2 * fr.spp + 2 * s + 1); }
+    } else {                                                            // lowdiscrepancy.cpp:76-128
+        const uint32_t pix_base = rng_base(n0, fr.seed);
+        const uint32_t P = uint32_t(fr.spp);
+        ln.dim_base = (s == 0) ? fr.pixgen_draws : 0u;                  // every pixel is generated inside GetNextSample
+        const int pos = shuffle_origin(pix_base, 2 + P, int(P), s);     // image block: 2 scrambles, P no-op draws, P-shuffle
+        ln.image_x = px + van_der_corput(uint32_t(pos), rng_u32(pix_base, 0));
+        ln.image_y = py + sobol2(uint32_t(pos), rng_u32(pix_base, 1));
+        if (need_lens) {
+            const uint32_t lb = 2 + 2 * P;
+            const int lp = shuffle_origin(pix_base, lb + 2 + P, int(P), s);
+            lu = van_der_corput(uint32_t(lp), rng_u32(pix_base, lb)); lv = sobol2(uint32_t(lp), rng_u32(pix_base, lb + 1));
+        }
+    }
+    ln.rng.ctr = ln.dim_base + ((fr.sampler == RT_SAMPLER_LOWDISCREPANCY) ? 0u : fr.lhs_total);
     ray = camera_ray(sc.cam, ln.image_x, ln.image_y, lu, lv);
 }
 
@@ -314,10 +384,10 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
             if (from_sampler) {
                 const int i1 = (INTEG == RT_INTEGRATOR_PATH) ? 3 * k : 0;
                 const int i2 = (INTEG == RT_INTEGRATOR_PATH) ? 3 * k : 0;
-                un = lhs_value(ln, fr.one_d[i1], 0, 0);
-                ls1 = lhs_value(ln, fr.two_d[i2], 0, 0); ls2 = lhs_value(ln, fr.two_d[i2], 0, 1);
-                ln.bs1 = lhs_value(ln, fr.two_d[i2 + 1], 0, 0); ln.bs2 = lhs_value(ln, fr.two_d[i2 + 1], 0, 1);
-                ln.bcs = lhs_value(ln, fr.one_d[i1 + 1], 0, 0);
+                un = dim_value(fr, ln, fr.one_d[i1], 0, 0);
+                ls1 = dim_value(fr, ln, fr.two_d[i2], 0, 0); ls2 = dim_value(fr, ln, fr.two_d[i2], 0, 1);
+                ln.bs1 = dim_value(fr, ln, fr.two_d[i2 + 1], 0, 0); ln.bs2 = dim_value(fr, ln, fr.two_d[i2 + 1], 0, 1);
+                ln.bcs = dim_value(fr, ln, fr.one_d[i1 + 1], 0, 0);
             } else {
                 un = ln.rng.next_float();
                 ls1 = ln.rng.next_float(); ls2 = ln.rng.next_float();           // transport.cpp:141-145
@@ -332,9 +402,9 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
             if (ln.li >= nLights) { ln.L = ln.L + ln.L_all; ln.stage = ST_SPECULAR; return; }
             const DimReq &rl = fr.two_d[2 * ln.li], &rb = fr.two_d[2 * ln.li + 1], &rc = fr.one_d[ln.li];
             if (ln.lj == 0) ln.Ld_light = mk3(0.f);
-            const float ls1 = lhs_value(ln, rl, ln.lj, 0), ls2 = lhs_value(ln, rl, ln.lj, 1);
-            ln.bs1 = lhs_value(ln, rb, ln.lj, 0); ln.bs2 = lhs_value(ln, rb, ln.lj, 1);
-            ln.bcs = lhs_value(ln, rc, ln.lj, 0);
+            const float ls1 = dim_value(fr, ln, rl, ln.lj, 0), ls2 = dim_value(fr, ln, rl, ln.lj, 1);
+            ln.bs1 = dim_value(fr, ln, rb, ln.lj, 0); ln.bs2 = dim_value(fr, ln, rb, ln.lj, 1);
+            ln.bcs = dim_value(fr, ln, rc, ln.lj, 0);
             estimate_direct_begin(sc, ln, ln.li, ls1, ls2);
             return;
         }
@@ -422,8 +492,8 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
         const int k = ln.depth;
         float bs1, bs2, bcs;
         if (k < 3) {
-            bs1 = lhs_value(ln, fr.two_d[3 * k + 2], 0, 0); bs2 = lhs_value(ln, fr.two_d[3 * k + 2], 0, 1);
-            bcs = lhs_value(ln, fr.one_d[3 * k + 2], 0, 0);
+            bs1 = dim_value(fr, ln, fr.two_d[3 * k + 2], 0, 0); bs2 = dim_value(fr, ln, fr.two_d[3 * k + 2], 0, 1);
+            bcs = dim_value(fr, ln, fr.one_d[3 * k + 2], 0, 0);
         } else { bs1 = ln.rng.next_float(); bs2 = ln.rng.next_float(); bcs = ln.rng.next_float(); }
         V3 wi; float pdf; int flags;
         V3 f = bsdf_sample_f(m, ln.v, ln.v.wo, wi, bs1, bs2, bcs, pdf, BX_ALL, flags);

@@ -483,13 +483,16 @@ int rt_kdtree_destroy(RtKdTree *t) { delete t; return RT_OK; }
 // (Sample::Sample sampling.cpp:41-70; RequestSamples of directlighting.cpp:39-66, path.cpp:47-57,
 // emission.cpp:42-46 / single.cpp:43-47; LatinHypercube draw counts sampling.cpp:98-113).
 static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool need_film) {
-    if (rd->sampler != RT_SAMPLER_STRATIFIED) return fail(RT_EINVAL, "only the stratified sampler is implemented in this version");
-    if (rd->x_samples < 1 || rd->y_samples < 1) return fail(RT_EINVAL, "bad xsamples/ysamples");
+    auto round_up_pow2 = [](unsigned v) { v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; return v + 1; };   // pbrt.h:590-598
+    if (rd->sampler < RT_SAMPLER_STRATIFIED || rd->sampler > RT_SAMPLER_RANDOM) return fail(RT_EINVAL, "unknown sampler");
+    if (rd->sampler == RT_SAMPLER_LOWDISCREPANCY) { if (rd->pixel_samples < 1) return fail(RT_EINVAL, "bad pixelsamples"); }
+    else if (rd->x_samples < 1 || rd->y_samples < 1) return fail(RT_EINVAL, "bad xsamples/ysamples");
     std::memset(&fr, 0, sizeof fr);
     fr.integrator = rd->integrator; fr.max_depth = rd->max_depth; fr.strategy = rd->strategy;
     fr.volume_integrator = rd->volume_integrator; fr.step_size = rd->step_size;
     fr.sampler = rd->sampler; fr.xs = rd->x_samples; fr.ys = rd->y_samples; fr.jitter = rd->jitter;
-    fr.spp = rd->x_samples * rd->y_samples; fr.seed = rd->seed;
+    fr.spp = rd->sampler == RT_SAMPLER_LOWDISCREPANCY ? int(round_up_pow2(unsigned(rd->pixel_samples))) : rd->x_samples * rd->y_samples;
+    fr.seed = rd->seed;
     fr.x_pixel_start = rd->x_pixel_start; fr.y_pixel_start = rd->y_pixel_start;
     fr.x_pixel_count = rd->x_pixel_count; fr.y_pixel_count = rd->y_pixel_count;
     fr.x_start = rd->x_start; fr.x_end = rd->x_end; fr.y_start = rd->y_start; fr.y_end = rd->y_end;
@@ -513,7 +516,8 @@ static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool nee
     if (rd->integrator == RT_INTEGRATOR_DIRECT && rd->strategy == RT_STRATEGY_ALL) {
         std::vector<DevLight> lights(nl);
         if (nl) HIPCHK(hipMemcpy(lights.data(), s->dev.lights, nl * sizeof(DevLight), hipMemcpyDeviceToHost));
-        for (int i = 0; i < nl; ++i) { int ns = lights[i].n_samples; n2.push_back(ns); n2.push_back(ns); n1.push_back(ns); }
+        for (int i = 0; i < nl; ++i) { int ns = lights[i].n_samples; if (rd->sampler == RT_SAMPLER_LOWDISCREPANCY) ns = int(round_up_pow2(unsigned(ns)));   // Sampler::RoundSize
+            n2.push_back(ns); n2.push_back(ns); n1.push_back(ns); }
     } else if (rd->integrator == RT_INTEGRATOR_DIRECT) { n2 = {1, 1}; n1 = {1, 1}; }
     else if (rd->integrator == RT_INTEGRATOR_PATH) { n1.assign(9, 1); n2.assign(9, 1); }
     else if (rd->integrator != RT_INTEGRATOR_WHITTED) return fail(RT_EINVAL, "unknown integrator");
@@ -521,10 +525,24 @@ static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool nee
     if (n1.size() > RT_MAX_DIM_REQ || n2.size() > RT_MAX_DIM_REQ) return fail(RT_EINVAL, "too many lights for the sample table");
     unsigned c = 0;
     fr.n1d = int(n1.size()); fr.n2d = int(n2.size());
-    for (size_t i = 0; i < n1.size(); ++i) { fr.one_d[i] = DimReq{c, c + unsigned(n1[i]), (unsigned short)n1[i], 1}; c += 2u * n1[i]; }
-    for (size_t i = 0; i < n2.size(); ++i) { fr.two_d[i] = DimReq{c, c + 2u * n2[i], (unsigned short)n2[i], 2}; c += 4u * n2[i]; }
-    fr.lhs_total = c;
-    fr.pixgen_draws = fr.jitter ? 7u * fr.spp : 2u * fr.spp;
+    const unsigned P = unsigned(fr.spp);
+    if (rd->sampler == RT_SAMPLER_STRATIFIED) {             // LatinHypercube: n*d floats then n*d shuffles per request
+        for (size_t i = 0; i < n1.size(); ++i) { fr.one_d[i] = DimReq{c, c + unsigned(n1[i]), (unsigned short)n1[i], 1}; c += 2u * n1[i]; }
+        for (size_t i = 0; i < n2.size(); ++i) { fr.two_d[i] = DimReq{c, c + 2u * n2[i], (unsigned short)n2[i], 2}; c += 4u * n2[i]; }
+        fr.lhs_total = c;
+        fr.pixgen_draws = fr.jitter ? 7u * P : 2u * P;      // stratified.cpp:99-117
+    } else if (rd->sampler == RT_SAMPLER_RANDOM) {          // one float per value (random.cpp:107-112)
+        for (size_t i = 0; i < n1.size(); ++i) { fr.one_d[i] = DimReq{c, 0, (unsigned short)n1[i], 1}; c += unsigned(n1[i]); }
+        for (size_t i = 0; i < n2.size(); ++i) { fr.two_d[i] = DimReq{c, 0, (unsigned short)n2[i], 2}; c += 2u * n2[i]; }
+        fr.lhs_total = c;
+        fr.pixgen_draws = 5u * P;                           // random.cpp:88-92
+    } else {                                                // per-pixel tables (lowdiscrepancy.cpp:93-104, sampling.h:152-174)
+        c = (2 + 2 * P) + (2 + 2 * P) + (1 + 2 * P);        // image, lens, time blocks
+        for (size_t i = 0; i < n1.size(); ++i) { fr.one_d[i] = DimReq{c, 0, (unsigned short)n1[i], 1}; c += 1u + unsigned(n1[i]) * P + P; }
+        for (size_t i = 0; i < n2.size(); ++i) { fr.two_d[i] = DimReq{c, 0, (unsigned short)n2[i], 2}; c += 2u + unsigned(n2[i]) * P + P; }
+        fr.lhs_total = 0;
+        fr.pixgen_draws = c;
+    }
     fr.work_counter = s->work_counter; fr.counters = s->counters; fr.spill = s->spill; fr.n_threads = s->n_threads;
     fr.frames = s->frames;
     if (need_film && !s->accum) return fail(RT_ESTATE, "rt_render: no film bound (call rt_film_bind first)");

@@ -136,6 +136,7 @@ Sampler MakeSampler(const std::string &nameIn, const ParamSet &ps, const Film &,
         s.xsamples = ps.FindOneInt("xsamples", 2); s.ysamples = ps.FindOneInt("ysamples", 2);
     } else if (name == "lowdiscrepancy") {                                          // lowdiscrepancy.cpp:129-136
         s.kind = RT_SAMPLER_LOWDISCREPANCY; s.pixelsamples = ps.FindOneInt("pixelsamples", 4);
+        if (s.pixelsamples & (s.pixelsamples - 1)) Warning("Pixel samples being rounded up to power of 2");
     } else if (name == "random") {                                                  // random.cpp:118-126
         s.kind = RT_SAMPLER_RANDOM; s.xsamples = ps.FindOneInt("xsamples", 2); s.ysamples = ps.FindOneInt("ysamples", 2);
     } else { Error("Unable to load plugin \"%s\" (sampler)", name.c_str()); *ok = false; s.kind = RT_SAMPLER_STRATIFIED; }
@@ -526,7 +527,10 @@ void pbrt_host_set_shard(RtRenderDesc *r, int index, int count, int tile_pixels)
 void pbrt_host_set_seed(RtRenderDesc *r, unsigned seed) { r->seed = seed; }
 void pbrt_host_film_dims(const RtRenderDesc *r, int *out8) {
     out8[0] = r->x_pixel_count; out8[1] = r->y_pixel_count; out8[2] = r->x_start; out8[3] = r->x_end;
-    out8[4] = r->y_start; out8[5] = r->y_end; out8[6] = r->x_samples * r->y_samples; out8[7] = r->integrator;
+    out8[4] = r->y_start; out8[5] = r->y_end; out8[7] = r->integrator;
+    if (r->sampler == RT_SAMPLER_LOWDISCREPANCY) {          // LDSampler rounds up to a power of two (lowdiscrepancy.cpp:57-66)
+        unsigned v = unsigned(r->pixel_samples); v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; out8[6] = int(v + 1);
+    } else out8[6] = r->x_samples * r->y_samples;
 }
 void pbrt_host_scene_counts(const RtSceneDesc *s, unsigned *out4) { out4[0] = s->n_tris; out4[1] = s->n_materials; out4[2] = s->n_lights; out4[3] = s->n_light_tris; }
 const float *pbrt_host_camera(const RtSceneDesc *s) { return s->camera.raster_to_camera; }

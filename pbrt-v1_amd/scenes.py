@@ -151,7 +151,9 @@ def options_block(xres=512, yres=512, integrator="whitted", integrator_params=""
     if crop is not None:
         film += ' "float cropwindow" [%s]' % _fmt([float(c) for c in crop])
     out.append(film + "\n")
-    if sampler == "stratified":
+    if sampler == "random":
+        sp = '"integer xsamples" [%d] "integer ysamples" [%d]' % (xsamples, ysamples)
+    elif sampler == "stratified":
         sp = '"integer xsamples" [%d] "integer ysamples" [%d] "bool jitter" ["%s"]' % (xsamples, ysamples, "true" if jitter else "false")
     else:
         sp = '"integer pixelsamples" [%d]' % (pixelsamples if pixelsamples is not None else xsamples * ysamples)

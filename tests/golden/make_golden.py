@@ -38,6 +38,12 @@ CONFIGS = {
     "path_lens_crop": dict(xres=64, yres=64, integrator="path", xsamples=2, ysamples=2, jitter=True, lensradius=6.0, focaldistance=900.0,
                            crop=(0.25, 0.75, 0.3, 0.8)),
     "direct_soup5k_seed7": dict(xres=48, yres=48, integrator="directlighting", soup_tris=5000, seed=7, xsamples=2, ysamples=2, jitter=True),
+    "ld_path_mitchell": dict(xres=32, yres=32, integrator="path", sampler="lowdiscrepancy", pixelsamples=4, pixel_filter="mitchell"),
+    "ld_direct_ns3_soup": dict(xres=32, yres=32, integrator="directlighting", sampler="lowdiscrepancy", pixelsamples=3, soup_tris=800,
+                               world_kwargs=dict(light_nsamples=3)),
+    "ld_whitted_lens": dict(xres=32, yres=32, integrator="whitted", sampler="lowdiscrepancy", pixelsamples=8, lensradius=5.0, focaldistance=800.0),
+    "random_path": dict(xres=32, yres=32, integrator="path", sampler="random", xsamples=2, ysamples=2),
+    "random_whitted_lens": dict(xres=32, yres=32, integrator="whitted", sampler="random", xsamples=2, ysamples=1, lensradius=5.0, focaldistance=800.0),
     "whitted_orennayar_triangle": dict(xres=32, yres=32, integrator="whitted", pixel_filter="triangle",
                                        world_kwargs=dict(point_light=True)),
 }

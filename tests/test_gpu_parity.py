@@ -200,8 +200,13 @@ def test_full_size_properties(pkg, scenes):
 
 def test_errors_are_loud(pkg, scenes):
     need_gpu(pkg)
-    ps = pkg.ParsedScene(text=scenes.cornell_scene(xres=8, yres=8, sampler="lowdiscrepancy"))
+    ps = pkg.ParsedScene(text=scenes.cornell_scene(xres=8, yres=8))
     ds = pkg.DeviceScene(ps)
-    with pytest.raises(pkg.RtError):
+    import ctypes as C
+    assert pkg.hip_lib().rt_film_bind(ds._s, None, 4, 4) == 0          # a film of the wrong size
+    ds._film_bound = True
+    with pytest.raises(pkg.RtError) as e:
         ds.render()
+    assert "film size" in str(e.value)
+    assert pkg.hip_lib().rt_render(ds._s, None) < 0 and pkg.hip_lib().rt_render(None, ps.render_desc) < 0
     ds.close()
