@@ -145,9 +145,12 @@ typedef struct RtCounters {
 typedef struct RtRay { float o[3], d[3], mint, maxt; } RtRay;             /* geometry.h:204-217 */
 typedef struct RtHit { int32_t prim; float t, b1, b2; } RtHit;            /* prim < 0 : miss      */
 typedef struct RtAccelInfo {
-    uint32_t n_nodes, n_leaf_refs, max_depth, n_tris;
+    uint32_t n_nodes, n_leaf_refs, max_depth, n_tris; /* grid: n_nodes = voxels, n_leaf_refs = voxel list entries */
     float bounds[6];
     double build_seconds;
+    int32_t kind;                                       /* RT_ACCEL_KDTREE / RT_ACCEL_GRID */
+    int32_t grid_nvoxels[3];                            /* GridAccel::NVoxels (grid.cpp:146-152) */
+    float grid_width[3], grid_inv_width[3];             /* GridAccel::Width / InvWidth (grid.cpp:154-158) */
 } RtAccelInfo;
 
 const char *rt_last_error(void);
@@ -165,6 +168,13 @@ int rt_scene_accel_copy(const RtScene *s, uint32_t *nodes, uint32_t *leaf_refs);
 
 /* The accelerator build alone, host-only (no device needed): KdTreeAccel's constructor,
  * accelerators/kdtree.cpp:141-312.  rt_scene_create runs exactly this. */
+/* Either accelerator, host-only: kd-tree as above, or GridAccel's constructor in its "refineimmediately" form
+ * (accelerators/grid.cpp:122-210).  nodes = [n_nodes][2] u32: kd nodes, or per-voxel {offset, count}. */
+typedef struct RtKdTree RtAccel;
+int rt_accel_build(const float *tri_verts, uint32_t n_tris, const RtAccelParams *params, RtAccel **out);
+int rt_accel_info(const RtAccel *t, RtAccelInfo *info);
+int rt_accel_copy(const RtAccel *t, uint32_t *nodes, uint32_t *leaf_refs);
+int rt_accel_destroy(RtAccel *t);
 typedef struct RtKdTree RtKdTree;
 int rt_kdtree_build(const float *tri_verts, uint32_t n_tris, const RtAccelParams *params, RtKdTree **out);
 int rt_kdtree_info(const RtKdTree *t, RtAccelInfo *info);

@@ -19,10 +19,10 @@ def lib():
             subprocess.check_call(["make", "-s", "-C", _HERE])
         L = C.CDLL(LIB)
         L.oracle_render.restype = C.c_int
-        L.oracle_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_trace.restype = C.c_int
         L.oracle_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int,
-                                   C.c_void_p, C.c_void_p, C.c_void_p]
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_resolve.restype = None
         L.oracle_resolve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         _lib = L
@@ -32,7 +32,7 @@ def lib():
 COUNTER_NAMES = ("camera_rays", "closest_rays", "any_rays", "nodes_visited", "leaf_refs", "tri_tests", "bad_samples", "stack_overflows")
 
 
-def render(parsed, nodes=None, leaf_refs=None, bounds=None, premultiply=None):
+def render(parsed, nodes=None, leaf_refs=None, bounds=None, premultiply=None, info=None):
     """Render `parsed` (a pbrt_v1_amd.ParsedScene: flat RtSceneDesc/RtRenderDesc) on one CPU thread.
     nodes/leaf_refs/bounds: a flattened kd-tree (e.g. from pbrt_v1_amd.build_kdtree); None = brute force.
     Returns (rgb, alpha, accum, counters)."""
@@ -46,7 +46,7 @@ def render(parsed, nodes=None, leaf_refs=None, bounds=None, premultiply=None):
     bd = None if bounds is None else np.ascontiguousarray(bounds, np.float32)
     rc = L.oracle_render(parsed.scene_desc, parsed.render_desc, None if nd is None else nd.ctypes.data, n_nodes,
                          None if lr is None else lr.ctypes.data, None if bd is None else bd.ctypes.data,
-                         accum.ctypes.data, cnt.ctypes.data)
+                         accum.ctypes.data, cnt.ctypes.data, C.byref(info) if info is not None else None)
     if rc != 0:
         raise RuntimeError("oracle_render failed: %d" % rc)
     rgb = np.zeros((h, w, 3), np.float32)
@@ -65,7 +65,7 @@ def resolve(accum, premultiply=True):
     return rgb, alpha
 
 
-def trace(parsed, rays, any_hit=False, nodes=None, leaf_refs=None, bounds=None):
+def trace(parsed, rays, any_hit=False, nodes=None, leaf_refs=None, bounds=None, info=None):
     L = lib()
     rays = np.ascontiguousarray(rays)
     n = len(rays)
@@ -78,7 +78,7 @@ def trace(parsed, rays, any_hit=False, nodes=None, leaf_refs=None, bounds=None):
     bd = None if bounds is None else np.ascontiguousarray(bounds, np.float32)
     rc = L.oracle_trace(parsed.scene_desc, None if nd is None else nd.ctypes.data, n_nodes, None if lr is None else lr.ctypes.data,
                         None if bd is None else bd.ctypes.data, rays.ctypes.data, n, int(any_hit), hits.ctypes.data, occ.ctypes.data,
-                        cnt.ctypes.data)
+                        cnt.ctypes.data, C.byref(info) if info is not None else None)
     if rc != 0:
         raise RuntimeError("oracle_trace failed")
     return (occ if any_hit else hits), dict(zip(COUNTER_NAMES, (int(c) for c in cnt)))

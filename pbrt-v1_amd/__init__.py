@@ -29,7 +29,7 @@ HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-msse2", "-mfpmath=sse"]
 def build(force: bool = False, verbose: bool = False) -> None:
     """Compile both shared libraries in-tree (hipcc cross-compiles gfx950 without a GPU)."""
     os.makedirs(LIB_DIR, exist_ok=True)
-    hip_src = [os.path.join(CSRC, "hip", f) for f in ("rt_kernels.hip", "kd_build.cpp")]
+    hip_src = [os.path.join(CSRC, "hip", f) for f in ("rt_kernels.hip", "kd_build.cpp", "grid_build.cpp")]
     hip_dep = [os.path.join(CSRC, "hip", f) for f in os.listdir(os.path.join(CSRC, "hip"))] + \
               [os.path.join(_HERE, "..", "include", "pbrt_hip.h")]
     host_src = [os.path.join(CSRC, "host", "scene_api.cpp")]
@@ -62,7 +62,8 @@ class RtCounters(C.Structure):
 
 class RtAccelInfo(C.Structure):
     _fields_ = [("n_nodes", C.c_uint32), ("n_leaf_refs", C.c_uint32), ("max_depth", C.c_uint32), ("n_tris", C.c_uint32),
-                ("bounds", C.c_float * 6), ("build_seconds", C.c_double)]
+                ("bounds", C.c_float * 6), ("build_seconds", C.c_double), ("kind", C.c_int32),
+                ("grid_nvoxels", C.c_int32 * 3), ("grid_width", C.c_float * 3), ("grid_inv_width", C.c_float * 3)]
 
 
 RAY_DTYPE = np.dtype([("o", np.float32, 3), ("d", np.float32, 3), ("mint", np.float32), ("maxt", np.float32)])
@@ -83,7 +84,8 @@ def hip_lib():
                      "rt_scene_accel_copy", "rt_camera_rays", "rt_trace_closest", "rt_trace_any", "rt_film_bind",
                      "rt_film_clear", "rt_film_read", "rt_film_resolve", "rt_render", "rt_sync", "rt_counters",
                      "rt_counters_reset", "rt_last_render_ms", "rt_device_count", "rt_set_counting",
-                     "rt_kdtree_build", "rt_kdtree_info", "rt_kdtree_copy", "rt_kdtree_destroy"):
+                     "rt_kdtree_build", "rt_kdtree_info", "rt_kdtree_copy", "rt_kdtree_destroy",
+                     "rt_accel_build", "rt_accel_info", "rt_accel_copy", "rt_accel_destroy"):
             getattr(L, name).restype = C.c_int
         L.rt_scene_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
         L.rt_scene_destroy.argtypes = [C.c_void_p]
@@ -108,6 +110,10 @@ def hip_lib():
         L.rt_kdtree_info.argtypes = [C.c_void_p, C.POINTER(RtAccelInfo)]
         L.rt_kdtree_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.rt_kdtree_destroy.argtypes = [C.c_void_p]
+        L.rt_accel_build.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.rt_accel_info.argtypes = [C.c_void_p, C.POINTER(RtAccelInfo)]
+        L.rt_accel_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rt_accel_destroy.argtypes = [C.c_void_p]
         _hip = L
     return _hip
 
@@ -165,13 +171,13 @@ def build_kdtree(tri_verts: np.ndarray, accel_params_ptr=None):
     """Host-only kd-tree build (rt_kdtree_build).  Returns (nodes[n,2] u32, leaf_refs u32, bounds[6], info)."""
     tv = np.ascontiguousarray(tri_verts, np.float32).reshape(-1, 9)
     t = C.c_void_p()
-    _chk(hip_lib().rt_kdtree_build(tv.ctypes.data, len(tv), accel_params_ptr, C.byref(t)))
+    _chk(hip_lib().rt_accel_build(tv.ctypes.data, len(tv), accel_params_ptr, C.byref(t)))
     info = RtAccelInfo()
-    _chk(hip_lib().rt_kdtree_info(t, C.byref(info)))
+    _chk(hip_lib().rt_accel_info(t, C.byref(info)))
     nodes = np.zeros((info.n_nodes, 2), np.uint32)
     refs = np.zeros(max(info.n_leaf_refs, 1), np.uint32)
-    _chk(hip_lib().rt_kdtree_copy(t, nodes.ctypes.data, refs.ctypes.data))
-    hip_lib().rt_kdtree_destroy(t)
+    _chk(hip_lib().rt_accel_copy(t, nodes.ctypes.data, refs.ctypes.data))
+    hip_lib().rt_accel_destroy(t)
     return nodes, refs[:info.n_leaf_refs], np.array(list(info.bounds), np.float32), info
 
 

@@ -40,6 +40,10 @@ struct DevScene {
     const float *light_tris;   // [n][12]: 9 vertex floats, per-triangle area, area CDF, pad
     unsigned n_tris, n_lights;
     float bounds[6];
+    // uniform grid (RT_ACCEL_GRID): `nodes` holds one {offset,count} voxel per cell, `leaf_refs` the primitive lists
+    int accel_kind;
+    int nvox[3];
+    float gwidth[3], ginv_width[3];
     RtCamera cam;
     RtVolume vol;
 };

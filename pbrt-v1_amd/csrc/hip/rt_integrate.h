@@ -275,7 +275,7 @@ RT_DEV int frame_pop(const DevFrame &fr, Lane &ln, unsigned gtid, V3 child) {
 
 RT_DEV void launch_ray(Lane &ln, const DevScene &sc, V3 o, V3 d, float mint, float maxt, bool any, int next_stage) {
     Ray r; r.o = o; r.d = d; r.mint = mint; r.maxt = maxt;
-    trav_begin(ln.tv, sc, r, any);
+    if (sc.accel_kind == RT_ACCEL_GRID) grid_begin(ln.tv, sc, r, any); else trav_begin(ln.tv, sc, r, any);
     ln.has_ray = true;
     ln.stage = next_stage;
 }

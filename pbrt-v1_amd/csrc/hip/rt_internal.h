@@ -16,6 +16,15 @@ struct KdTree {
     double build_seconds = 0;
 };
 
+struct GridAccelData {
+    std::vector<Node> voxels;         // {offset, count} per voxel, x fastest
+    std::vector<uint32_t> refs;
+    int nvox[3];
+    float width[3], inv_width[3], bounds[6];
+    double build_seconds = 0;
+};
+void build_grid(const float *tri_verts, uint32_t n_tris, GridAccelData &out);
+
 void build_kdtree(const float *tri_verts, uint32_t n_tris, const RtAccelParams &params, KdTree &out);
 
 }  // namespace rt

@@ -30,7 +30,7 @@ namespace rt {
 #endif
 // Scene and frame descriptors are read through pointers (uniform addresses -> scalar loads on demand) instead of
 // being passed by value: the by-value form pinned >100 SGPRs and spilled them.
-template <bool COUNT, int INTEG>
+template <bool COUNT, int INTEG, int ACCEL>
 __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void render_kernel(const DevScene *__restrict__ scp,
                                                                        const DevFrame *__restrict__ frp) {
     __shared__ uint2 lds_stack[RT_STACK_LDS * RT_BLOCK];
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void render_kernel(const De
                             ln.L = mk3(0.f); ln.thr = mk3(1.f); ln.alpha = 0.f; ln.depth = 0; ln.fsp = 0;
                             ln.specular = false;
                             if (COUNT) ++c_cam;
-                            trav_begin(ln.tv, sc, ray, false);
+                            accel_begin<ACCEL>(ln.tv, sc, ray, false);
                             ln.has_ray = true; ln.stage = ST_VERTEX;
                         }
                     }
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void render_kernel(const De
             const unsigned long long am = __ballot(act);
             if (!am) break;
             if (RT_EXIT_THRESH > 0 && __popcll(am) <= RT_EXIT_THRESH && __any(!act && ln.stage != ST_EXIT)) break;
-            if (act) trav_step<COUNT>(ln.tv, sc, lds_stack, fr.spill, fr.n_threads, gtid, tc);
+            if (act) accel_step<COUNT, ACCEL>(ln.tv, sc, lds_stack, fr.spill, fr.n_threads, gtid, tc);
         }
         if (ln.has_ray && !ln.tv.active) ln.has_ray = false;
     }
@@ -202,8 +202,9 @@ __global__ __launch_bounds__(RT_BLOCK) void trace_kernel(DevScene sc, const RtRa
     for (unsigned i = gtid; i < n; i += n_threads) {
         Ray r; r.o = mk3(rays[i].o[0], rays[i].o[1], rays[i].o[2]); r.d = mk3(rays[i].d[0], rays[i].d[1], rays[i].d[2]);
         r.mint = rays[i].mint; r.maxt = rays[i].maxt;
-        Trav tv; trav_begin(tv, sc, r, any != 0);
-        while (tv.active) trav_step<true>(tv, sc, lds_stack, spill, n_threads, gtid, tc);
+        Trav tv;
+        if (sc.accel_kind == RT_ACCEL_GRID) { grid_begin(tv, sc, r, any != 0); while (tv.active) grid_step<true>(tv, sc, tc); }
+        else { trav_begin(tv, sc, r, any != 0); while (tv.active) trav_step<true>(tv, sc, lds_stack, spill, n_threads, gtid, tc); }
         if (any) occ[i] = tv.hit_prim >= 0 ? 1 : 0;
         else { hits[i].prim = tv.hit_prim; hits[i].t = tv.hit_prim >= 0 ? tv.maxt : 0.f; hits[i].b1 = tv.b1; hits[i].b2 = tv.b2; }
     }
@@ -245,6 +246,8 @@ struct RtScene {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     KdTree tree;
+    GridAccelData gridacc;
+    int accel_kind = RT_ACCEL_KDTREE;
     DevScene dev{};
     std::vector<void *> allocs;
     // film
@@ -255,7 +258,7 @@ struct RtScene {
     uint2 *spill = nullptr; size_t spill_entries = 0;
     float *frames = nullptr; size_t frames_floats = 0;
     unsigned grid = 0, n_threads = 0;
-    unsigned grids[6] = {0, 0, 0, 0, 0, 0};          // resident grid per render_kernel<COUNT, INTEG> instantiation
+    unsigned grids[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};          // resident grid per render_kernel<COUNT, INTEG> instantiation
     DevScene *dev_scene = nullptr; DevFrame *dev_frame = nullptr;   // descriptors in HBM (read with scalar loads)
     float4 *samples = nullptr; size_t samples_cap = 0;          // per-shard sample buffer
     float ms_render = 0.f, ms_gather = 0.f; hipEvent_t ev2 = nullptr;
@@ -278,6 +281,8 @@ static int upload(RtScene *s, const T *host, size_t n, const T **dev) {
     return RT_OK;
 }
 
+static void fill_info(const KdTree &tree, const GridAccelData &g, int kind, uint32_t n_tris, RtAccelInfo *info);
+
 extern "C" {
 
 const char *rt_last_error(void) { return g_err.c_str(); }
@@ -294,7 +299,7 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
     if (!d || !out) return fail(RT_EINVAL, "rt_scene_create: null argument");
     if (d->n_tris && (!d->tri_verts || !d->tri_material || !d->tri_light || !d->tri_flags))
         return fail(RT_EINVAL, "rt_scene_create: missing triangle arrays");
-    if (d->accel.kind != RT_ACCEL_KDTREE) return fail(RT_EINVAL, "rt_scene_create: only the kd-tree accelerator is built by this version");
+    if (d->accel.kind != RT_ACCEL_KDTREE && d->accel.kind != RT_ACCEL_GRID) return fail(RT_EINVAL, "rt_scene_create: unknown accelerator kind");
     for (uint32_t i = 0; i < d->n_tris; ++i)
         if (d->tri_material[i] >= d->n_materials) return fail(RT_EINVAL, "rt_scene_create: material index out of range");
     int ndev = 0;
@@ -307,7 +312,12 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
     HIPCHK(hipEventCreate(&s->ev0)); HIPCHK(hipEventCreate(&s->ev1));
     s->n_tris = d->n_tris;
 
-    build_kdtree(d->tri_verts, d->n_tris, d->accel, s->tree);
+    s->accel_kind = d->accel.kind;
+    if (s->accel_kind == RT_ACCEL_GRID) {
+        build_grid(d->tri_verts, d->n_tris, s->gridacc);
+        s->tree.nodes = s->gridacc.voxels; s->tree.leaf_refs = s->gridacc.refs; s->tree.max_depth = 0;
+        std::memcpy(s->tree.bounds, s->gridacc.bounds, sizeof s->tree.bounds); s->tree.build_seconds = s->gridacc.build_seconds;
+    } else build_kdtree(d->tri_verts, d->n_tris, d->accel, s->tree);
 
     // triangles -> 48-byte records
     std::vector<DevTri> tris(d->n_tris);
@@ -378,6 +388,8 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
     if ((rc = upload(s, ltris.data(), ltris.size(), &s->dev.light_tris))) return rc;
 
     s->dev.n_tris = d->n_tris; s->dev.n_lights = d->n_lights;
+    s->dev.accel_kind = s->accel_kind;
+    for (int a = 0; a < 3; ++a) { s->dev.nvox[a] = s->gridacc.nvox[a]; s->dev.gwidth[a] = s->gridacc.width[a]; s->dev.ginv_width[a] = s->gridacc.inv_width[a]; }
     std::memcpy(s->dev.bounds, s->tree.bounds, sizeof s->dev.bounds);
     s->dev.cam = d->camera; s->dev.vol = d->volume;
 
@@ -385,10 +397,13 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, s->device));
     {
-        const void *kernels[6] = {(const void *)render_kernel<false, 0>, (const void *)render_kernel<false, 1>, (const void *)render_kernel<false, 2>,
-                                  (const void *)render_kernel<true, 0>, (const void *)render_kernel<true, 1>, (const void *)render_kernel<true, 2>};
+        const void *kernels[12] = {
+            (const void *)render_kernel<false, 0, 0>, (const void *)render_kernel<false, 1, 0>, (const void *)render_kernel<false, 2, 0>,
+            (const void *)render_kernel<true, 0, 0>, (const void *)render_kernel<true, 1, 0>, (const void *)render_kernel<true, 2, 0>,
+            (const void *)render_kernel<false, 0, 1>, (const void *)render_kernel<false, 1, 1>, (const void *)render_kernel<false, 2, 1>,
+            (const void *)render_kernel<true, 0, 1>, (const void *)render_kernel<true, 1, 1>, (const void *)render_kernel<true, 2, 1>};
         unsigned mx = 0;
-        for (int k = 0; k < 6; ++k) {
+        for (int k = 0; k < 12; ++k) {
             int per_cu = 0;
             HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernels[k], RT_BLOCK, 0));
             if (per_cu < 1) per_cu = 1;
@@ -440,10 +455,7 @@ int rt_scene_set_stream(RtScene *s, void *hip_stream) {
 
 int rt_scene_accel_info(const RtScene *s, RtAccelInfo *info) {
     if (!s || !info) return fail(RT_EINVAL, "null argument");
-    info->n_nodes = uint32_t(s->tree.nodes.size()); info->n_leaf_refs = uint32_t(s->tree.leaf_refs.size());
-    info->max_depth = uint32_t(s->tree.max_depth); info->n_tris = s->n_tris;
-    std::memcpy(info->bounds, s->tree.bounds, sizeof info->bounds);
-    info->build_seconds = s->tree.build_seconds;
+    fill_info(s->tree, s->gridacc, s->accel_kind, s->n_tris, info);
     return RT_OK;
 }
 
@@ -454,30 +466,50 @@ int rt_scene_accel_copy(const RtScene *s, uint32_t *nodes, uint32_t *leaf_refs) 
     return RT_OK;
 }
 
-struct RtKdTree { KdTree tree; uint32_t n_tris; };
-int rt_kdtree_build(const float *tri_verts, uint32_t n_tris, const RtAccelParams *params, RtKdTree **out) {
-    if (!out || (n_tris && !tri_verts)) return fail(RT_EINVAL, "rt_kdtree_build: null argument");
+struct RtKdTree { KdTree tree; GridAccelData grid; int kind = RT_ACCEL_KDTREE; uint32_t n_tris = 0; };
+static void fill_info(const KdTree &tree, const GridAccelData &g, int kind, uint32_t n_tris, RtAccelInfo *info) {
+    info->n_nodes = uint32_t(tree.nodes.size()); info->n_leaf_refs = uint32_t(tree.leaf_refs.size());
+    info->max_depth = uint32_t(tree.max_depth); info->n_tris = n_tris;
+    std::memcpy(info->bounds, tree.bounds, sizeof info->bounds); info->build_seconds = tree.build_seconds;
+    info->kind = kind;
+    for (int a = 0; a < 3; ++a) {
+        info->grid_nvoxels[a] = kind == RT_ACCEL_GRID ? g.nvox[a] : 0;
+        info->grid_width[a] = kind == RT_ACCEL_GRID ? g.width[a] : 0.f;
+        info->grid_inv_width[a] = kind == RT_ACCEL_GRID ? g.inv_width[a] : 0.f;
+    }
+}
+int rt_accel_build(const float *tri_verts, uint32_t n_tris, const RtAccelParams *params, RtAccel **out) {
+    if (!out || (n_tris && !tri_verts)) return fail(RT_EINVAL, "rt_accel_build: null argument");
     RtAccelParams p; std::memset(&p, 0, sizeof p);
     if (params) p = *params;
-    if (p.kind != RT_ACCEL_KDTREE) return fail(RT_EINVAL, "rt_kdtree_build: not a kd-tree description");
-    RtKdTree *t = new RtKdTree(); t->n_tris = n_tris;
-    build_kdtree(tri_verts, n_tris, p, t->tree);
+    RtKdTree *t = new RtKdTree(); t->n_tris = n_tris; t->kind = p.kind;
+    if (p.kind == RT_ACCEL_GRID) {
+        build_grid(tri_verts, n_tris, t->grid);
+        t->tree.nodes = t->grid.voxels; t->tree.leaf_refs = t->grid.refs; t->tree.max_depth = 0;
+        std::memcpy(t->tree.bounds, t->grid.bounds, sizeof t->tree.bounds); t->tree.build_seconds = t->grid.build_seconds;
+    } else if (p.kind == RT_ACCEL_KDTREE) build_kdtree(tri_verts, n_tris, p, t->tree);
+    else { delete t; return fail(RT_EINVAL, "rt_accel_build: unknown accelerator kind"); }
     *out = t; return RT_OK;
 }
-int rt_kdtree_info(const RtKdTree *t, RtAccelInfo *info) {
+int rt_accel_info(const RtAccel *t, RtAccelInfo *info) {
     if (!t || !info) return fail(RT_EINVAL, "null argument");
-    info->n_nodes = uint32_t(t->tree.nodes.size()); info->n_leaf_refs = uint32_t(t->tree.leaf_refs.size());
-    info->max_depth = uint32_t(t->tree.max_depth); info->n_tris = t->n_tris;
-    std::memcpy(info->bounds, t->tree.bounds, sizeof info->bounds); info->build_seconds = t->tree.build_seconds;
+    fill_info(t->tree, t->grid, t->kind, t->n_tris, info);
     return RT_OK;
 }
-int rt_kdtree_copy(const RtKdTree *t, uint32_t *nodes, uint32_t *leaf_refs) {
-    if (!t) return fail(RT_EINVAL, "null tree");
+int rt_accel_copy(const RtAccel *t, uint32_t *nodes, uint32_t *leaf_refs) {
+    if (!t) return fail(RT_EINVAL, "null accelerator");
     if (nodes) std::memcpy(nodes, t->tree.nodes.data(), t->tree.nodes.size() * sizeof(Node));
     if (leaf_refs) std::memcpy(leaf_refs, t->tree.leaf_refs.data(), t->tree.leaf_refs.size() * sizeof(uint32_t));
     return RT_OK;
 }
-int rt_kdtree_destroy(RtKdTree *t) { delete t; return RT_OK; }
+int rt_accel_destroy(RtAccel *t) { delete t; return RT_OK; }
+int rt_kdtree_build(const float *tri_verts, uint32_t n_tris, const RtAccelParams *params, RtKdTree **out) {
+    if (params && params->kind != RT_ACCEL_KDTREE) return fail(RT_EINVAL, "rt_kdtree_build: not a kd-tree description");
+    return rt_accel_build(tri_verts, n_tris, params, out);
+}
+int rt_kdtree_info(const RtKdTree *t, RtAccelInfo *info) { return rt_accel_info(t, info); }
+int rt_kdtree_copy(const RtKdTree *t, uint32_t *nodes, uint32_t *leaf_refs) { return rt_accel_copy(t, nodes, leaf_refs); }
+int rt_kdtree_destroy(RtKdTree *t) { return rt_accel_destroy(t); }
 
 // Build the per-frame device descriptor: film geometry + the Sample layout the integrators request
 // (Sample::Sample sampling.cpp:41-70; RequestSamples of directlighting.cpp:39-66, path.cpp:47-57,
@@ -651,20 +683,20 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
         s->samples_cap = fr.total_work;
     }
     fr.samples = s->samples;
-    const int variant = (s->counting ? 3 : 0) + rd->integrator;
+    const int variant = (s->accel_kind == RT_ACCEL_GRID ? 6 : 0) + (s->counting ? 3 : 0) + rd->integrator;
     HIPCHK(hipMemcpyAsync(s->filter_dev, rd->filter_table, 256 * sizeof(float), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemcpyAsync(s->dev_frame, &fr, sizeof(DevFrame), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemsetAsync(s->work_counter, 0, sizeof(unsigned long long), s->stream));
     HIPCHK(hipEventRecord(s->ev0, s->stream));
     const dim3 grid(s->grids[variant]), block(RT_BLOCK);
+#define RT_LAUNCH(C, I, A) hipLaunchKernelGGL((render_kernel<C, I, A>), grid, block, 0, s->stream, s->dev_scene, s->dev_frame)
     switch (variant) {
-    case 0: hipLaunchKernelGGL((render_kernel<false, 0>), grid, block, 0, s->stream, s->dev_scene, s->dev_frame); break;
-    case 1: hipLaunchKernelGGL((render_kernel<false, 1>), grid, block, 0, s->stream, s->dev_scene, s->dev_frame); break;
-    case 2: hipLaunchKernelGGL((render_kernel<false, 2>), grid, block, 0, s->stream, s->dev_scene, s->dev_frame); break;
-    case 3: hipLaunchKernelGGL((render_kernel<true, 0>), grid, block, 0, s->stream, s->dev_scene, s->dev_frame); break;
-    case 4: hipLaunchKernelGGL((render_kernel<true, 1>), grid, block, 0, s->stream, s->dev_scene, s->dev_frame); break;
-    default: hipLaunchKernelGGL((render_kernel<true, 2>), grid, block, 0, s->stream, s->dev_scene, s->dev_frame); break;
+    case 0: RT_LAUNCH(false, 0, 0); break; case 1: RT_LAUNCH(false, 1, 0); break; case 2: RT_LAUNCH(false, 2, 0); break;
+    case 3: RT_LAUNCH(true, 0, 0); break;  case 4: RT_LAUNCH(true, 1, 0); break;  case 5: RT_LAUNCH(true, 2, 0); break;
+    case 6: RT_LAUNCH(false, 0, 1); break; case 7: RT_LAUNCH(false, 1, 1); break; case 8: RT_LAUNCH(false, 2, 1); break;
+    case 9: RT_LAUNCH(true, 0, 1); break;  case 10: RT_LAUNCH(true, 1, 1); break; default: RT_LAUNCH(true, 2, 1); break;
     }
+#undef RT_LAUNCH
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->ev1, s->stream));
     if (!skip_film) {

@@ -36,6 +36,9 @@ struct Trav {
     unsigned node;
     float tmin, tmax;
     int sp;
+    // grid 3D-DDA cursor (grid.cpp:238-260): voxel position and the ray parameter of the next crossing per axis
+    int gpos[3];
+    float gnext[3];
     // result
     int hit_prim;       // closest: primitive index or -1; any: 0/-1
     float b1, b2;
@@ -140,6 +143,89 @@ RT_DEV void trav_step(Trav &tv, const DevScene &sc, uint2 *lds_stack, uint2 *spi
         tv.tmin = tv.tmax;
         tv.tmax = __uint_as_float(e.y);
     } else tv.active = false;
+}
+
+
+// ---- uniform grid: GridAccel::Intersect / IntersectP (reference accelerators/grid.cpp:224-286, :331-390) -------
+RT_DEV float arr3(const float *a, int i) { return i == 0 ? a[0] : (i == 1 ? a[1] : a[2]); }
+RT_DEV int arr3i(const int *a, int i) { return i == 0 ? a[0] : (i == 1 ? a[1] : a[2]); }
+RT_DEV void grid_begin(Trav &tv, const DevScene &sc, const Ray &r, bool any) {
+    tv.o = r.o; tv.d = r.d; tv.mint = r.mint; tv.maxt = r.maxt; tv.any = any;
+    tv.hit_prim = -1; tv.b1 = 0.f; tv.b2 = 0.f; tv.sp = 0; tv.node = 0;
+    tv.inv = mk3(0.f); tv.tmin = tv.tmax = 0.f;
+    float rayT;
+    const V3 pm = r.o + r.d * r.mint;                                        // bounds.Inside(ray(ray.mint))
+    const bool inside = pm.x >= sc.bounds[0] && pm.x <= sc.bounds[3] && pm.y >= sc.bounds[1] && pm.y <= sc.bounds[4] &&
+                        pm.z >= sc.bounds[2] && pm.z <= sc.bounds[5];
+    bool ok = true;
+    if (inside) rayT = r.mint;
+    else {                                                                    // bounds.IntersectP(ray, &rayT)
+        float t0 = r.mint, t1 = r.maxt;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float invRayDir = 1.f / comp(r.d, i);
+            float tNear = (sc.bounds[i] - comp(r.o, i)) * invRayDir;
+            float tFar = (sc.bounds[3 + i] - comp(r.o, i)) * invRayDir;
+            if (tNear > tFar) { float tmp = tNear; tNear = tFar; tFar = tmp; }
+            t0 = tNear > t0 ? tNear : t0;
+            t1 = tFar < t1 ? tFar : t1;
+            if (t0 > t1) ok = false;
+        }
+        rayT = t0;
+    }
+    const V3 gi = r.o + r.d * rayT;
+#pragma unroll
+    for (int axis = 0; axis < 3; ++axis) {
+        const float lo = sc.bounds[axis], w = sc.gwidth[axis], da = comp(r.d, axis), ga = comp(gi, axis);
+        int v = int((ga - lo) * sc.ginv_width[axis]);                         // PosToVoxel: Float2Int then Clamp
+        v = v < 0 ? 0 : (v > sc.nvox[axis] - 1 ? sc.nvox[axis] - 1 : v);
+        tv.gpos[axis] = v;
+        if (da >= 0) tv.gnext[axis] = rayT + ((lo + (v + 1) * w) - ga) / da;  // VoxelToPos(Pos+1)
+        else tv.gnext[axis] = rayT + ((lo + v * w) - ga) / da;
+    }
+    tv.active = ok && sc.n_tris > 0;
+}
+
+// one voxel visit
+template <bool COUNT>
+RT_DEV void grid_step(Trav &tv, const DevScene &sc, TravCounters &cnt) {
+    const uint2 vx = sc.nodes[(size_t(tv.gpos[2]) * sc.nvox[1] + tv.gpos[1]) * sc.nvox[0] + tv.gpos[0]];
+    if (COUNT) ++cnt.nodes;
+    for (unsigned i = 0; i < vx.y; ++i) {
+        const unsigned prim = sc.leaf_refs[vx.x + i];
+        if (COUNT) { ++cnt.tris; ++cnt.leaf_refs; }
+        V3 p1, p2, p3; unsigned bits; int light;
+        tri_verts(sc.tris, prim, p1, p2, p3, bits, light);
+        float t, b1, b2;
+        if (tri_test(p1, p2, p3, tv.o, tv.d, tv.mint, tv.maxt, t, b1, b2)) {
+            if (tv.any) { tv.hit_prim = 0; tv.active = false; return; }
+            tv.maxt = t; tv.hit_prim = int(prim); tv.b1 = b1; tv.b2 = b2;
+        }
+    }
+    // advance to the next voxel (grid.cpp:273-283)
+    const int bits = ((tv.gnext[0] < tv.gnext[1]) << 2) + ((tv.gnext[0] < tv.gnext[2]) << 1) + ((tv.gnext[1] < tv.gnext[2]));
+    const int stepAxis = (0x00221212 >> (4 * bits)) & 3;                      // cmpToAxis[8] = {2,1,2,1,2,2,0,0}
+    const float nx = arr3(tv.gnext, stepAxis);
+    if (tv.maxt < nx) { tv.active = false; return; }
+    const float da = comp(tv.d, stepAxis);
+    const int step = da >= 0 ? 1 : -1, out = da >= 0 ? arr3i(sc.nvox, stepAxis) : -1;
+    const int np = arr3i(tv.gpos, stepAxis) + step;
+    if (np == out) { tv.active = false; return; }
+    const float delta = (da >= 0 ? arr3(sc.gwidth, stepAxis) : -arr3(sc.gwidth, stepAxis)) / da;   // DeltaT
+    if (stepAxis == 0) { tv.gpos[0] = np; tv.gnext[0] = nx + delta; }
+    else if (stepAxis == 1) { tv.gpos[1] = np; tv.gnext[1] = nx + delta; }
+    else { tv.gpos[2] = np; tv.gnext[2] = nx + delta; }
+}
+
+// accelerator dispatch (compile-time)
+template <int ACCEL>
+RT_DEV void accel_begin(Trav &tv, const DevScene &sc, const Ray &r, bool any) {
+    if (ACCEL == RT_ACCEL_GRID) grid_begin(tv, sc, r, any); else trav_begin(tv, sc, r, any);
+}
+template <bool COUNT, int ACCEL>
+RT_DEV void accel_step(Trav &tv, const DevScene &sc, uint2 *lds_stack, uint2 *spill, unsigned n_threads, unsigned gtid,
+                       TravCounters &cnt) {
+    if (ACCEL == RT_ACCEL_GRID) grid_step<COUNT>(tv, sc, cnt); else trav_step<COUNT>(tv, sc, lds_stack, spill, n_threads, gtid, cnt);
 }
 
 }  // namespace rt

@@ -44,6 +44,11 @@ CONFIGS = {
     "ld_whitted_lens": dict(xres=32, yres=32, integrator="whitted", sampler="lowdiscrepancy", pixelsamples=8, lensradius=5.0, focaldistance=800.0),
     "random_path": dict(xres=32, yres=32, integrator="path", sampler="random", xsamples=2, ysamples=2),
     "random_whitted_lens": dict(xres=32, yres=32, integrator="whitted", sampler="random", xsamples=2, ysamples=1, lensradius=5.0, focaldistance=800.0),
+    "grid_whitted_lazy": dict(xres=48, yres=48, integrator="whitted", accelerator="grid"),
+    "grid_path_soup3k_eager": dict(xres=48, yres=48, integrator="path", xsamples=2, ysamples=2, soup_tris=3000, accelerator="grid",
+                                   accel_params='"bool refineimmediately" ["true"]'),
+    "grid_direct_glass_lazy": dict(xres=40, yres=40, integrator="directlighting", accelerator="grid",
+                                   world_kwargs=dict(mirror_quad=True, glass_sphere_tris=blob)),
     "whitted_orennayar_triangle": dict(xres=32, yres=32, integrator="whitted", pixel_filter="triangle",
                                        world_kwargs=dict(point_light=True)),
 }

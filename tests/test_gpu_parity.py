@@ -124,6 +124,8 @@ def test_trace_matches_oracle_on_random_rays_and_edge_cases(pkg, scenes, oracle)
     dict(xres=160, yres=120, integrator="path", xsamples=2, ysamples=2, jitter=True, pixel_filter="mitchell", soup_tris=20000),
     dict(xres=200, yres=200, integrator="directlighting", xsamples=2, ysamples=2, jitter=True, soup_tris=50000),
     dict(xres=256, yres=256, integrator="whitted", soup_tris=3000, soup_materials=True),
+    dict(xres=160, yres=160, integrator="directlighting", soup_tris=30000, accelerator="grid"),
+    dict(xres=128, yres=128, integrator="path", sampler="lowdiscrepancy", pixelsamples=8, soup_tris=5000, accelerator="grid"),
 ])
 def test_device_matches_oracle_on_larger_seeded_scenes(pkg, scenes, oracle, cfg):
     need_gpu(pkg)
@@ -133,9 +135,10 @@ def test_device_matches_oracle_on_larger_seeded_scenes(pkg, scenes, oracle, cfg)
     rgb, alpha = ds.film()
     cnt = ds.counters()
     nodes, refs = ds.accel_arrays()
-    bounds = np.array(list(ds.accel_info().bounds), np.float32)
+    info = ds.accel_info()
+    bounds = np.array(list(info.bounds), np.float32)
     ds.close()
-    orgb, oalpha, _, ocnt = oracle.render(ps, nodes, refs, bounds)
+    orgb, oalpha, _, ocnt = oracle.render(ps, nodes, refs, bounds, info=info)
     check_film(str(cfg), rgb, alpha, orgb, oalpha, ps.integrator)
     if ps.integrator != 2:
         # same rays, same tree, same order: identical work counters (the basis of the roofline's algorithmic bytes)

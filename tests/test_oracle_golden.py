@@ -13,7 +13,7 @@ def test_oracle_film_matches_reference(pkg, oracle, name):
     ps = pkg.ParsedScene(text=g["scene"])
     assert ps.valid and ps.errors == 0
     nodes, refs, bounds, info = ps.kdtree()
-    rgb, alpha, accum, cnt = oracle.render(ps, nodes, refs, bounds)
+    rgb, alpha, accum, cnt = oracle.render(ps, nodes, refs, bounds, info=info)
     m = film_metrics(rgb, g["rgb"])
     # same compiler flags, same libm, same draw order: the restatement reproduces the reference film exactly
     assert m["maxabs"] <= 1e-6, m
@@ -25,7 +25,22 @@ def test_oracle_film_matches_reference(pkg, oracle, name):
     assert cnt["bad_samples"] == 0
 
 
-@pytest.mark.parametrize("name", FILMS)
+def test_grid_shape_matches_reference_statistics(pkg):
+    """rt_accel_build(kind=grid) against GridAccel's own statistics for the eager ("refineimmediately") grid
+    (grid.cpp:184-209): voxel count, non-empty voxels, total voxel-list entries, largest voxel."""
+    g = load_golden("grid_path_soup3k_eager")
+    ps = pkg.ParsedScene(text=g["scene"])
+    voxels, refs, bounds, info = ps.kdtree()
+    table = g["stats"]["stats"]
+    assert info.kind == 1 and len(voxels) == info.grid_nvoxels[0] * info.grid_nvoxels[1] * info.grid_nvoxels[2]
+    covered, nprims = table["Voxels covered vs # / primitives"].split(":")
+    assert len(refs) == int(covered) and ps.n_tris == int(nprims)
+    assert int(voxels[:, 1].max()) == int(table["Max # of primitives in a grid voxel"])
+    empty, total = (stat_int(x)[0] for x in table["Empty voxels"].split(":"))
+    assert abs(int((voxels[:, 1] == 0).sum()) - empty) <= 60 and abs(len(voxels) - total) <= 60      # printed as "64.4k:79.5k"
+
+
+@pytest.mark.parametrize("name", [n for n in FILMS if not n.startswith("grid_")])
 def test_kdtree_shape_matches_reference_statistics(pkg, name):
     """rt_kdtree_build (host-only ABI) against the node counts KdTreeAccel reports through StatsPrint
     (kdtree.cpp:41-52,68-69): interior nodes, leaf nodes, total leaf references, max primitives per leaf."""
