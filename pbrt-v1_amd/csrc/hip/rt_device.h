@@ -73,6 +73,8 @@ struct DevFrame {
     unsigned long long *counters;   // RtCounters as 8 u64
     uint2 *spill;                   // traversal-stack overflow  [entry][thread]
     float *frames;                  // specular recursion frames [frame][field][thread]
+    float *vol_rays, *vol_state, *vol_samp;   // volume scratch (rt_integrate.h), null without a volume
+    int vol_nmax;
     unsigned n_threads;
 };
 

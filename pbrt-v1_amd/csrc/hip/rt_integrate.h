@@ -18,7 +18,7 @@ namespace rt {
 
 enum Stage {
     ST_FETCH = 0, ST_VERTEX, ST_DIRECT_NEXT, ST_SHADOW_DONE, ST_MIS_DONE, ST_ED_BSDF, ST_ED_DONE,
-    ST_BOUNCE, ST_SPECULAR, ST_SPEC_TRANS, ST_RETURN, ST_FINISH, ST_EXIT
+    ST_BOUNCE, ST_SPECULAR, ST_SPEC_TRANS, ST_RETURN, ST_VOL_BEGIN, ST_VOL_STEP, ST_POP, ST_FINISH, ST_EXIT
 };
 
 struct Rng {
@@ -280,6 +280,55 @@ RT_DEV void launch_ray(Lane &ln, const DevScene &sc, V3 o, V3 d, float mint, flo
     ln.stage = next_stage;
 }
 
+// ---- participating medium: HomogeneousVolume (volumes/homogeneous.cpp:27-74) and the volume integrators --------
+// Per-thread scratch in HBM (only allocated / touched when the scene has a volume):
+//   vol_rays [level][8][thread]   the ray of the Scene::Li invocation at recursion level `fsp` (o, d, mint, maxt)
+//   vol_state[13][thread]         suspended ray-march state of SingleScattering::Li while a shadow ray is traced
+//   vol_samp [3*Nmax][thread]     its LatinHypercube(samp, N, 3) table (single.cpp:76-77)
+RT_DEV float *vol_ray_ptr(const DevFrame &fr, int level, unsigned gtid) { return fr.vol_rays + size_t(level) * 8 * fr.n_threads + gtid; }
+RT_DEV void vol_store_ray(const DevFrame &fr, int level, unsigned gtid, const Ray &r) {
+    float *q = vol_ray_ptr(fr, level, gtid); const size_t st = fr.n_threads;
+    q[0] = r.o.x; q[st] = r.o.y; q[2 * st] = r.o.z; q[3 * st] = r.d.x; q[4 * st] = r.d.y; q[5 * st] = r.d.z; q[6 * st] = r.mint; q[7 * st] = r.maxt;
+}
+RT_DEV Ray vol_load_ray(const DevFrame &fr, int level, unsigned gtid) {
+    const float *q = vol_ray_ptr(fr, level, gtid); const size_t st = fr.n_threads;
+    Ray r; r.o = mk3(q[0], q[st], q[2 * st]); r.d = mk3(q[3 * st], q[4 * st], q[5 * st]); r.mint = q[6 * st]; r.maxt = q[7 * st];
+    return r;
+}
+// HomogeneousVolume::IntersectP :43-46 (BBox::IntersectP on the volume-space ray)
+RT_DEV bool vol_intersect(const RtVolume &v, V3 o, V3 d, float mint, float maxt, float &t0, float &t1) {
+    const V3 vo = xform_point(v.world_to_volume, o), vd = xform_vector(v.world_to_volume, d);
+    float a = mint, b = maxt; bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float invRayDir = 1.f / comp(vd, i);
+        float tNear = (v.p0[i] - comp(vo, i)) * invRayDir, tFar = (v.p1[i] - comp(vo, i)) * invRayDir;
+        if (tNear > tFar) { float tmp = tNear; tNear = tFar; tFar = tmp; }
+        a = tNear > a ? tNear : a; b = tFar < b ? tFar : b;
+        if (a > b) ok = false;
+    }
+    t0 = a; t1 = b; return ok;
+}
+RT_DEV bool vol_inside(const RtVolume &v, V3 p) {
+    const V3 q = xform_point(v.world_to_volume, p);
+    return q.x >= v.p0[0] && q.x <= v.p1[0] && q.y >= v.p0[1] && q.y <= v.p1[1] && q.z >= v.p0[2] && q.z <= v.p1[2];
+}
+// exp(-Tau(ray)) with Tau = Distance(ray(t0), ray(t1)) * (sigma_a + sigma_s)   (homogeneous.cpp:63-67, emission.cpp:47-59)
+RT_DEV V3 vol_transmittance(const RtVolume &v, V3 o, V3 d, float mint, float maxt) {
+    float t0, t1;
+    if (!vol_intersect(v, o, d, mint, maxt, t0, t1)) return mk3(1.f);
+    const float dist = len3((o + d * t0) - (o + d * t1));
+    const V3 tau = (mat_color(v.sigma_a) + mat_color(v.sigma_s)) * dist;
+    return mk3(expf(-tau.x), expf(-tau.y), expf(-tau.z));
+}
+// Scene::Transmittance(ray) (scene.cpp:127-129): sample == NULL => one RandomFloat() for the (unused) offset
+template <bool VOL>
+RT_DEV V3 scene_transmittance(const DevScene &sc, Lane &ln, V3 o, V3 d, float mint, float maxt) {
+    if (!VOL) return mk3(1.f);
+    (void)ln.rng.next_float();
+    return vol_transmittance(sc.vol, o, d, mint, maxt);
+}
+
 // ---- EstimateDirect (core/transport.cpp:123-194), split at its two ray casts ------------------------------
 // BSDF-sampling half; returns with either a MIS ray in flight (ST_MIS_DONE) or ST_ED_DONE.
 RT_DEV void estimate_direct_bsdf(const DevScene &sc, Lane &ln) {
@@ -342,7 +391,7 @@ RT_DEV void estimate_direct_begin(const DevScene &sc, Lane &ln, int light, float
 }
 
 // The body of ONE stage.  Returns when the lane has a ray in flight or has changed stage.
-template <bool COUNT, int INTEG, int STAGE>
+template <bool COUNT, int INTEG, bool VOL, int STAGE>
 RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigned gtid,
                        unsigned *c_closest, unsigned *c_any, unsigned *c_bad) {
     if constexpr (STAGE == ST_VERTEX) {
@@ -351,10 +400,11 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
         if (INTEG == RT_INTEGRATOR_PATH) {
             if (!hit) {                                                         // path.cpp:68-83: point/area lights have Le(ray)=0
                 if (ln.depth == 0) ln.alpha = (ln.L.x != 0.f || ln.L.y != 0.f || ln.L.z != 0.f) ? 1.f : 0.f;
-                ln.stage = ST_FINISH; return;
+                ln.stage = ST_RETURN; return;
             }
             make_vertex(sc, ln.tv, ln.v);
-            if (ln.depth == 0) ln.alpha = 1.f;
+            if (ln.depth == 0) { ln.alpha = 1.f; if (VOL) vol_ray_ptr(fr, 0, gtid)[7 * size_t(fr.n_threads)] = ln.tv.maxt; }   // r.maxt = ray.maxt
+            else if (VOL) ln.thr = ln.thr * scene_transmittance<VOL>(sc, ln, ln.tv.o, ln.tv.d, ln.tv.mint, ln.tv.maxt);           // path.cpp:89
             if ((ln.depth == 0 || ln.specular) && ln.v.light >= 0)              // path.cpp:91-92
                 ln.L = ln.L + ln.thr * area_L(sc.lights[ln.v.light], ln.v.nn, ln.v.wo);
         } else {
@@ -365,6 +415,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
             }
             make_vertex(sc, ln.tv, ln.v);
             if (ln.depth == 0) ln.alpha = 1.f;
+            if (VOL) vol_ray_ptr(fr, ln.fsp, gtid)[7 * size_t(fr.n_threads)] = ln.tv.maxt;       // the hit shortens this level's ray
             ln.L = mk3(0.f);
             if (ln.v.light >= 0) ln.L = ln.L + area_L(sc.lights[ln.v.light], ln.v.nn, ln.v.wo);
         }
@@ -443,11 +494,11 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
         if (COUNT) ++*c_any;
         const bool occluded = ln.tv.hit_prim >= 0;
         if (INTEG == RT_INTEGRATOR_WHITTED) {
-            if (!occluded) ln.L = ln.L + ln.pend;
+            if (!occluded) ln.L = ln.L + ln.pend * scene_transmittance<VOL>(sc, ln, ln.tv.o, ln.tv.d, ln.tv.mint, ln.tv.maxt);   // whitted.cpp:80
             ln.stage = ST_DIRECT_NEXT;
             return;
         }
-        if (!occluded) ln.Ld = ln.Ld + ln.pend;
+        if (!occluded) ln.Ld = ln.Ld + ln.pend * scene_transmittance<VOL>(sc, ln, ln.tv.o, ln.tv.d, ln.tv.mint, ln.tv.maxt);       // transport.cpp:155
         ln.stage = ST_ED_BSDF;
         return;
     }
@@ -462,7 +513,8 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
             tri_verts(sc.tris, unsigned(ln.tv.hit_prim), p1, p2, p3, bits, light);
             if (light == ln.cur_light) {
                 V3 nh, dpdu; tri_frame(p1, p2, p3, (bits >> 16) & 1u, nh, dpdu);
-                if (dot3(nh, -ln.tv.d) > 0) ln.Ld = ln.Ld + ln.pend;           // isect.Le(-wi) non-black
+                if (dot3(nh, -ln.tv.d) > 0)                                    // isect.Le(-wi) non-black; transport.cpp:188-190
+                    ln.Ld = ln.Ld + ln.pend * scene_transmittance<VOL>(sc, ln, ln.tv.o, ln.tv.d, ln.tv.mint, ln.tv.maxt);
             }
         }
         ln.stage = ST_ED_DONE;
@@ -497,14 +549,14 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
         } else { bs1 = ln.rng.next_float(); bs2 = ln.rng.next_float(); bcs = ln.rng.next_float(); }
         V3 wi; float pdf; int flags;
         V3 f = bsdf_sample_f(m, ln.v, ln.v.wo, wi, bs1, bs2, bcs, pdf, BX_ALL, flags);
-        if (is_black(f) || pdf == 0.f) { ln.stage = ST_FINISH; return; }
+        if (is_black(f) || pdf == 0.f) { ln.stage = ST_RETURN; return; }
         ln.specular = (flags & BX_SPECULAR) != 0;
         ln.thr = ln.thr * div_s(f * absdot3(wi, ln.v.nn), pdf);
         if (k > 3) {
-            if (ln.rng.next_float() > .5f) { ln.stage = ST_FINISH; return; }
+            if (ln.rng.next_float() > .5f) { ln.stage = ST_RETURN; return; }
             ln.thr = div_s(ln.thr, .5f);
         }
-        if (k == fr.max_depth) { ln.stage = ST_FINISH; return; }
+        if (k == fr.max_depth) { ln.stage = ST_RETURN; return; }
         ++ln.depth;
         launch_ray(ln, sc, ln.v.p, wi, RT_RAY_EPSILON, RT_INF, false, ST_VERTEX);
         return;
@@ -521,6 +573,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
             frame_push(fr, ln, gtid, f, ad, ST_SPEC_TRANS);
             ++ln.depth;
             launch_ray(ln, sc, ln.v.p, wi, RT_RAY_EPSILON, RT_INF, false, ST_VERTEX);
+            if (VOL) { Ray cr; cr.o = ln.v.p; cr.d = wi; cr.mint = RT_RAY_EPSILON; cr.maxt = RT_INF; vol_store_ray(fr, ln.fsp, gtid, cr); }
             return;
         }
         ln.stage = ST_SPEC_TRANS;
@@ -534,15 +587,104 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
         if (!is_black(f) && pdf > 0.f) f = div_s(f, pdf);
         const float ad = absdot3(wi, ln.v.nn);
         if (!is_black(f) && ad > 0.f) {
-            frame_push(fr, ln, gtid, f, ad, ST_RETURN);
+            frame_push(fr, ln, gtid, f, ad, ST_POP);
             ++ln.depth;
             launch_ray(ln, sc, ln.v.p, wi, RT_RAY_EPSILON, RT_INF, false, ST_VERTEX);
+            if (VOL) { Ray cr; cr.o = ln.v.p; cr.d = wi; cr.mint = RT_RAY_EPSILON; cr.maxt = RT_INF; vol_store_ray(fr, ln.fsp, gtid, cr); }
             return;
         }
         ln.stage = ST_RETURN;
         return;
     }
-    if constexpr (STAGE == ST_RETURN) {
+    if constexpr (STAGE == ST_RETURN) {          // the surface integrator's Li for the current level is complete in ln.L
+        ln.stage = VOL ? ST_VOL_BEGIN : ST_POP;
+        return;
+    }
+    if constexpr (VOL && (STAGE == ST_VOL_BEGIN || STAGE == ST_VOL_STEP)) {
+        // Scene::Li = T * Lo + Lv (scene.cpp:120-126): EmissionIntegrator::Li emission.cpp:60-95 /
+        // SingleScattering::Li single.cpp:57-116 along this level's ray, then its Transmittance (emission.cpp:47-59)
+        const RtVolume &vol = sc.vol;
+        const Ray ray = vol_load_ray(fr, ln.fsp, gtid);
+        const bool single = fr.volume_integrator == RT_VOLUME_SINGLE;
+        const size_t st = fr.n_threads;
+        float *vs = fr.vol_state + gtid;
+        float *samp = fr.vol_samp + gtid;
+        int i, N; float t0, step; V3 Tr, p, Lv;
+        const V3 w = -ray.d;
+        bool marching = true;
+        if (STAGE == ST_VOL_BEGIN) {
+            float t1;
+            if (!vol_intersect(vol, ray.o, ray.d, ray.mint, ray.maxt, t0, t1) || (t1 - t0) == 0.f) { marching = false; Lv = mk3(0.f); N = 0; i = 0; step = 0.f; Tr = mk3(1.f); p = ray.o; }
+            else {
+                N = int(ceilf((t1 - t0) / fr.step_size));
+                step = (t1 - t0) / N;
+                Tr = mk3(1.f); p = ray.o + ray.d * t0; Lv = mk3(0.f); i = 0;
+                t0 += dim_value(fr, ln, fr.one_d[fr.n1d - 1], 0, 0) * step;          // scatterSampleOffset
+                if (single) {                                                      // LatinHypercube(samp, N, 3), sampling.cpp:98-113
+                    if (N > fr.vol_nmax) { N = fr.vol_nmax; }                       // cannot happen: vol_nmax bounds the box diagonal
+                    const float delta = 1.f / N;
+                    for (int a = 0; a < N; ++a) for (int b = 0; b < 3; ++b) samp[size_t(3 * a + b) * st] = (a + ln.rng.next_float()) * delta;
+                    for (int b = 0; b < 3; ++b) for (int a = 0; a < N; ++a) {
+                        const int other = int(ln.rng.next_u32() % uint32_t(N));
+                        const float tmp = samp[size_t(3 * a + b) * st]; samp[size_t(3 * a + b) * st] = samp[size_t(3 * other + b) * st]; samp[size_t(3 * other + b) * st] = tmp;
+                    }
+                }
+            }
+        } else {                                                                   // resume after the step's shadow ray
+            if (COUNT) ++*c_any;
+            i = __float_as_int(vs[0]); N = __float_as_int(vs[st]); t0 = vs[2 * st]; step = vs[3 * st];
+            Tr = mk3(vs[4 * st], vs[5 * st], vs[6 * st]); p = mk3(vs[7 * st], vs[8 * st], vs[9 * st]); Lv = mk3(vs[10 * st], vs[11 * st], vs[12 * st]);
+            if (ln.tv.hit_prim < 0)                                                // vis.Unoccluded: Ld = L * vis.Transmittance(scene)
+                Lv = Lv + ln.pend * scene_transmittance<VOL>(sc, ln, ln.tv.o, ln.tv.d, ln.tv.mint, ln.tv.maxt);
+            ++i; t0 += step;
+        }
+        while (marching && i < N) {
+            const V3 pPrev = p; p = ray.o + ray.d * t0;
+            (void)ln.rng.next_float();                                             // Tau's offset argument
+            const V3 stepT = vol_transmittance(vol, pPrev, p - pPrev, 0.f, 1.f);
+            Tr = Tr * stepT;
+            if (lum_y(Tr) < 1e-3) {
+                if (ln.rng.next_float() > .5f) break;
+                Tr = div_s(Tr, .5f);
+            }
+            const bool in = vol_inside(vol, p);
+            Lv = Lv + Tr * (in ? mat_color(vol.le) : mk3(0.f));
+            if (single) {
+                const V3 ss = in ? mat_color(vol.sigma_s) : mk3(0.f);
+                const int nLights = int(sc.n_lights);
+                if (!is_black(ss) && nLights > 0) {
+                    const int lightNum = min(int(floorf(samp[size_t(3 * i) * st] * nLights)), nLights - 1);
+                    const float u1 = samp[size_t(3 * i + 1) * st], u2 = samp[size_t(3 * i + 2) * st];
+                    const DevLight &Lt = sc.lights[lightNum];
+                    V3 wo, L, pseg; float pdf;
+                    if (Lt.type == RT_LIGHT_POINT) {
+                        V3 lp = mat_color(Lt.pos); wo = normalize3(lp - p); pdf = 1.f;
+                        V3 dd = lp - p; L = div_s(mat_color(Lt.color), dd.x * dd.x + dd.y * dd.y + dd.z * dd.z); pseg = lp;
+                    } else {
+                        V3 ns; V3 ps = area_sample_point(sc, Lt, u1, u2, ln.rng, ns);
+                        wo = normalize3(ps - p); pdf = area_light_pdf(sc, Lt, p, wo); L = area_L(Lt, ns, -wo); pseg = ps;
+                    }
+                    if (!is_black(L) && pdf > 0.f) {
+                        const float costheta = dot3(w, -wo);                       // PhaseHG volume.cpp:44-48
+                        const float phase = in ? 1.f / (4.f * RT_PI) * (1.f - vol.g * vol.g) / powf(1.f + vol.g * vol.g - 2.f * vol.g * costheta, 1.5f) : 0.f;
+                        ln.pend = div_s((((Tr * ss) * phase) * L) * float(nLights), pdf);
+                        vs[0] = __int_as_float(i); vs[st] = __int_as_float(N); vs[2 * st] = t0; vs[3 * st] = step;
+                        vs[4 * st] = Tr.x; vs[5 * st] = Tr.y; vs[6 * st] = Tr.z; vs[7 * st] = p.x; vs[8 * st] = p.y; vs[9 * st] = p.z;
+                        vs[10 * st] = Lv.x; vs[11 * st] = Lv.y; vs[12 * st] = Lv.z;
+                        launch_ray(ln, sc, p, pseg - p, RT_RAY_EPSILON, 1.f - RT_RAY_EPSILON, true, ST_VOL_STEP);
+                        return;
+                    }
+                }
+            }
+            ++i; t0 += step;
+        }
+        Lv = Lv * step;
+        const V3 T = vol_transmittance(vol, ray.o, ray.d, ray.mint, ray.maxt);      // sample != NULL: no draw
+        ln.L = T * ln.L + Lv;
+        ln.stage = ST_POP;
+        return;
+    }
+    if constexpr (STAGE == ST_POP) {
         if (ln.fsp == 0) { ln.stage = ST_FINISH; return; }
         ln.stage = frame_pop(fr, ln, gtid, ln.L);
         return;
@@ -561,17 +703,20 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
 // shadow ray, from a MIS ray or straight from a vertex.  (A switch executed once per transition would run every
 // stage body once per lane phase: ~8x lower SIMD utilisation with 64 lanes at random phases.)  Backward edges
 // (next light of the all-lights loop, popping a recursion frame) simply take another pass.
-template <bool COUNT, int INTEG>
+template <bool COUNT, int INTEG, bool VOL>
 RT_DEV void advance_pass(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigned gtid,
                          unsigned *c_closest, unsigned *c_any, unsigned *c_bad) {
-#define RT_RUN(S) if (!ln.has_ray && ln.stage == S) stage_body<COUNT, INTEG, S>(sc, fr, ln, gtid, c_closest, c_any, c_bad)
+#define RT_RUN(S) if (!ln.has_ray && ln.stage == S) stage_body<COUNT, INTEG, VOL, S>(sc, fr, ln, gtid, c_closest, c_any, c_bad)
     RT_RUN(ST_MIS_DONE);
     RT_RUN(ST_SHADOW_DONE);
     RT_RUN(ST_VERTEX);
     RT_RUN(ST_DIRECT_NEXT);
     if (INTEG != RT_INTEGRATOR_WHITTED) { RT_RUN(ST_ED_BSDF); RT_RUN(ST_ED_DONE); }
     if (INTEG == RT_INTEGRATOR_PATH) { RT_RUN(ST_BOUNCE); }
-    else { RT_RUN(ST_SPECULAR); RT_RUN(ST_SPEC_TRANS); RT_RUN(ST_RETURN); }
+    else { RT_RUN(ST_SPECULAR); RT_RUN(ST_SPEC_TRANS); }
+    RT_RUN(ST_RETURN);
+    if (VOL) { RT_RUN(ST_VOL_STEP); RT_RUN(ST_VOL_BEGIN); }
+    RT_RUN(ST_POP);
     RT_RUN(ST_FINISH);
 #undef RT_RUN
 }

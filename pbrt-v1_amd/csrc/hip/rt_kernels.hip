@@ -30,7 +30,7 @@ namespace rt {
 #endif
 // Scene and frame descriptors are read through pointers (uniform addresses -> scalar loads on demand) instead of
 // being passed by value: the by-value form pinned >100 SGPRs and spilled them.
-template <bool COUNT, int INTEG, int ACCEL>
+template <bool COUNT, int INTEG, int ACCEL, bool VOL>
 __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void render_kernel(const DevScene *__restrict__ scp,
                                                                        const DevFrame *__restrict__ frp) {
     __shared__ uint2 lds_stack[RT_STACK_LDS * RT_BLOCK];
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void render_kernel(const De
     for (;;) {
         // ---- shade / regenerate: run every lane that is not waiting on a ray until it is (or is out of work)
         do {
-            advance_pass<COUNT, INTEG>(sc, fr, ln, gtid, &c_closest, &c_any, &c_bad);
+            advance_pass<COUNT, INTEG, VOL>(sc, fr, ln, gtid, &c_closest, &c_any, &c_bad);
             const unsigned long long want = __ballot(!ln.has_ray && ln.stage == ST_FETCH);
             if (want) {                                                   // wave-aggregated work fetch
                 const int leader = __ffsll((long long)want) - 1;
@@ -67,6 +67,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void render_kernel(const De
                             ln.specular = false;
                             if (COUNT) ++c_cam;
                             accel_begin<ACCEL>(ln.tv, sc, ray, false);
+                            if (VOL) vol_store_ray(fr, 0, gtid, ray);
                             ln.has_ray = true; ln.stage = ST_VERTEX;
                         }
                     }
@@ -232,6 +233,14 @@ __global__ void camera_kernel(DevScene sc, DevFrame fr, unsigned long long first
 // ------------------------------------------------------------------------------------------ host side
 using namespace rt;
 
+// render_kernel instantiations, index = ((VOL*2 + ACCEL)*2 + COUNT)*3 + INTEG
+typedef void (*RenderKernelFn)(const DevScene *, const DevFrame *);
+#define RT_K3(C, A, V) render_kernel<C, 0, A, V>, render_kernel<C, 1, A, V>, render_kernel<C, 2, A, V>
+static const RenderKernelFn g_render_kernels[24] = {
+    RT_K3(false, 0, false), RT_K3(true, 0, false), RT_K3(false, 1, false), RT_K3(true, 1, false),
+    RT_K3(false, 0, true),  RT_K3(true, 0, true),  RT_K3(false, 1, true),  RT_K3(true, 1, true)};
+#undef RT_K3
+
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #define HIPCHK(expr)                                                                                   \
@@ -258,11 +267,13 @@ struct RtScene {
     uint2 *spill = nullptr; size_t spill_entries = 0;
     float *frames = nullptr; size_t frames_floats = 0;
     unsigned grid = 0, n_threads = 0;
-    unsigned grids[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};          // resident grid per render_kernel<COUNT, INTEG> instantiation
+    unsigned grids[24] = {0};          // resident grid per render_kernel<COUNT, INTEG> instantiation
     DevScene *dev_scene = nullptr; DevFrame *dev_frame = nullptr;   // descriptors in HBM (read with scalar loads)
     float4 *samples = nullptr; size_t samples_cap = 0;          // per-shard sample buffer
     float ms_render = 0.f, ms_gather = 0.f; hipEvent_t ev2 = nullptr;
     float *resolve_buf = nullptr; size_t resolve_cap = 0;
+    float *vol_buf = nullptr; size_t vol_cap = 0;          // volume scratch: rays | state | samp
+    RtVolume volume{};
     int spill_depth = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_timing = false;
@@ -391,21 +402,16 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
     s->dev.accel_kind = s->accel_kind;
     for (int a = 0; a < 3; ++a) { s->dev.nvox[a] = s->gridacc.nvox[a]; s->dev.gwidth[a] = s->gridacc.width[a]; s->dev.ginv_width[a] = s->gridacc.inv_width[a]; }
     std::memcpy(s->dev.bounds, s->tree.bounds, sizeof s->dev.bounds);
-    s->dev.cam = d->camera; s->dev.vol = d->volume;
+    s->dev.cam = d->camera; s->dev.vol = d->volume; s->volume = d->volume;
 
     // persistent launch geometry: as many resident blocks as the kernel's registers/LDS admit
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, s->device));
     {
-        const void *kernels[12] = {
-            (const void *)render_kernel<false, 0, 0>, (const void *)render_kernel<false, 1, 0>, (const void *)render_kernel<false, 2, 0>,
-            (const void *)render_kernel<true, 0, 0>, (const void *)render_kernel<true, 1, 0>, (const void *)render_kernel<true, 2, 0>,
-            (const void *)render_kernel<false, 0, 1>, (const void *)render_kernel<false, 1, 1>, (const void *)render_kernel<false, 2, 1>,
-            (const void *)render_kernel<true, 0, 1>, (const void *)render_kernel<true, 1, 1>, (const void *)render_kernel<true, 2, 1>};
         unsigned mx = 0;
-        for (int k = 0; k < 12; ++k) {
+        for (int k = 0; k < 24; ++k) {
             int per_cu = 0;
-            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernels[k], RT_BLOCK, 0));
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)g_render_kernels[k], RT_BLOCK, 0));
             if (per_cu < 1) per_cu = 1;
             s->grids[k] = unsigned(prop.multiProcessorCount) * unsigned(per_cu);
             mx = s->grids[k] > mx ? s->grids[k] : mx;
@@ -437,6 +443,7 @@ int rt_scene_destroy(RtScene *s) {
     if (s->frames) hipFree(s->frames);
     if (s->samples) hipFree(s->samples);
     if (s->resolve_buf) hipFree(s->resolve_buf);
+    if (s->vol_buf) hipFree(s->vol_buf);
     hipFree(s->dev_scene); hipFree(s->dev_frame);
     if (s->ev2) hipEventDestroy(s->ev2);
     if (s->ev0) hipEventDestroy(s->ev0);
@@ -653,6 +660,7 @@ int rt_film_resolve(RtScene *s, int premultiply, float *rgb_out, float *alpha_ou
     const size_t n = size_t(s->film_w) * s->film_h;
     if (s->resolve_cap < n) {
         if (s->resolve_buf) hipFree(s->resolve_buf);
+    if (s->vol_buf) hipFree(s->vol_buf);
         HIPCHK(hipMalloc((void **)&s->resolve_buf, n * 4 * sizeof(float))); s->resolve_cap = n;
     }
     hipLaunchKernelGGL(film_resolve_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s->stream, s->accum, n, premultiply,
@@ -676,6 +684,24 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
         }
     }
     DevFrame fr; int rc = make_frame(s, rd, fr, true); if (rc) return rc;
+    if (s->volume.present) {
+        if (!(rd->step_size > 0.f)) return fail(RT_EINVAL, "rt_render: volume integrator stepsize must be positive");
+        if (rd->volume_integrator != RT_VOLUME_EMISSION && rd->volume_integrator != RT_VOLUME_SINGLE) return fail(RT_EINVAL, "rt_render: unknown volume integrator");
+        const float ex = s->volume.p1[0] - s->volume.p0[0], ey = s->volume.p1[1] - s->volume.p0[1], ez = s->volume.p1[2] - s->volume.p0[2];
+        const double diag = std::sqrt(double(ex) * ex + double(ey) * ey + double(ez) * ez);
+        const double nsteps = std::ceil(diag / rd->step_size) + 2;
+        if (nsteps > 65536) return fail(RT_EINVAL, "rt_render: stepsize too small for the medium (more than 65536 march steps)");
+        const int nmax = int(nsteps);
+        const int levels = (rd->integrator == RT_INTEGRATOR_PATH) ? 1 : rd->max_depth + 2;
+        const size_t samp_words = rd->volume_integrator == RT_VOLUME_SINGLE ? size_t(3) * nmax : 0;
+        const size_t need = (size_t(levels) * 8 + 13 + samp_words) * s->n_threads;
+        if (need > s->vol_cap) {
+            if (s->vol_buf) { HIPCHK(hipStreamSynchronize(s->stream)); hipFree(s->vol_buf); s->vol_buf = nullptr; }
+            HIPCHK(hipMalloc((void **)&s->vol_buf, need * sizeof(float))); s->vol_cap = need;
+        }
+        fr.vol_rays = s->vol_buf; fr.vol_state = s->vol_buf + size_t(levels) * 8 * s->n_threads;
+        fr.vol_samp = fr.vol_state + size_t(13) * s->n_threads; fr.vol_nmax = nmax;
+    }
     const bool skip_film = std::getenv("PBRT_HIP_DEBUG_NOFILM") != nullptr;   // perf experiments only
     if (fr.total_work > s->samples_cap) {
         if (s->samples) { HIPCHK(hipStreamSynchronize(s->stream)); hipFree(s->samples); s->samples = nullptr; }
@@ -683,20 +709,13 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
         s->samples_cap = fr.total_work;
     }
     fr.samples = s->samples;
-    const int variant = (s->accel_kind == RT_ACCEL_GRID ? 6 : 0) + (s->counting ? 3 : 0) + rd->integrator;
+    const int variant = (((s->volume.present ? 1 : 0) * 2 + (s->accel_kind == RT_ACCEL_GRID ? 1 : 0)) * 2 + (s->counting ? 1 : 0)) * 3 + rd->integrator;
     HIPCHK(hipMemcpyAsync(s->filter_dev, rd->filter_table, 256 * sizeof(float), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemcpyAsync(s->dev_frame, &fr, sizeof(DevFrame), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemsetAsync(s->work_counter, 0, sizeof(unsigned long long), s->stream));
     HIPCHK(hipEventRecord(s->ev0, s->stream));
-    const dim3 grid(s->grids[variant]), block(RT_BLOCK);
-#define RT_LAUNCH(C, I, A) hipLaunchKernelGGL((render_kernel<C, I, A>), grid, block, 0, s->stream, s->dev_scene, s->dev_frame)
-    switch (variant) {
-    case 0: RT_LAUNCH(false, 0, 0); break; case 1: RT_LAUNCH(false, 1, 0); break; case 2: RT_LAUNCH(false, 2, 0); break;
-    case 3: RT_LAUNCH(true, 0, 0); break;  case 4: RT_LAUNCH(true, 1, 0); break;  case 5: RT_LAUNCH(true, 2, 0); break;
-    case 6: RT_LAUNCH(false, 0, 1); break; case 7: RT_LAUNCH(false, 1, 1); break; case 8: RT_LAUNCH(false, 2, 1); break;
-    case 9: RT_LAUNCH(true, 0, 1); break;  case 10: RT_LAUNCH(true, 1, 1); break; default: RT_LAUNCH(true, 2, 1); break;
-    }
-#undef RT_LAUNCH
+    hipLaunchKernelGGL(g_render_kernels[variant], dim3(s->grids[variant]), dim3(RT_BLOCK), 0, s->stream,
+                       (const DevScene *)s->dev_scene, (const DevFrame *)s->dev_frame);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->ev1, s->stream));
     if (!skip_film) {

@@ -49,6 +49,13 @@ CONFIGS = {
                                    accel_params='"bool refineimmediately" ["true"]'),
     "grid_direct_glass_lazy": dict(xres=40, yres=40, integrator="directlighting", accelerator="grid",
                                    world_kwargs=dict(mirror_quad=True, glass_sphere_tris=blob)),
+    "vol_emission_path": dict(xres=32, yres=32, integrator="path", xsamples=2, ysamples=1, volume_integrator='"emission" "float stepsize" [40]',
+                              world_kwargs=dict(volume='"color Le" [.002 .003 .004]')),
+    "vol_single_whitted": dict(xres=32, yres=32, integrator="whitted", volume_integrator='"single" "float stepsize" [60]', world_kwargs=dict(volume=' ')),
+    "vol_single_direct_glass": dict(xres=32, yres=32, integrator="directlighting", volume_integrator='"single" "float stepsize" [80]',
+                                    world_kwargs=dict(volume='"float g" [.3]', glass_sphere_tris=blob, point_light=True)),
+    "vol_single_path_grid": dict(xres=24, yres=24, integrator="path", xsamples=2, ysamples=2, jitter=True, accelerator="grid",
+                                 volume_integrator='"single" "float stepsize" [50]', world_kwargs=dict(volume='"color Le" [.001 .001 .001]')),
     "whitted_orennayar_triangle": dict(xres=32, yres=32, integrator="whitted", pixel_filter="triangle",
                                        world_kwargs=dict(point_light=True)),
 }
