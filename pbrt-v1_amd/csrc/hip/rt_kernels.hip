@@ -250,6 +250,11 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
             return fail(RT_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));                \
     } while (0)
 
+static void hip_warn(hipError_t e, const char *what) {
+    if (e != hipSuccess) std::fprintf(stderr, "libpbrt_hip: %s failed: %s\n", what, hipGetErrorString(e));
+}
+#define HIPWARN(expr) hip_warn((expr), #expr)
+
 struct RtScene {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -435,27 +440,27 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
 
 int rt_scene_destroy(RtScene *s) {
     if (!s) return RT_OK;
-    hipSetDevice(s->device);
+    HIPWARN(hipSetDevice(s->device));
     hipStreamSynchronize(s->stream);
-    for (void *p : s->allocs) hipFree(p);
-    if (s->own_accum && s->accum) hipFree(s->accum);
-    hipFree(s->spill); hipFree(s->work_counter); hipFree(s->counters); hipFree(s->filter_dev);
-    if (s->frames) hipFree(s->frames);
-    if (s->samples) hipFree(s->samples);
-    if (s->resolve_buf) hipFree(s->resolve_buf);
-    if (s->vol_buf) hipFree(s->vol_buf);
-    hipFree(s->dev_scene); hipFree(s->dev_frame);
-    if (s->ev2) hipEventDestroy(s->ev2);
-    if (s->ev0) hipEventDestroy(s->ev0);
-    if (s->ev1) hipEventDestroy(s->ev1);
-    if (s->own_stream && s->stream) hipStreamDestroy(s->stream);
+    for (void *p : s->allocs) HIPWARN(hipFree(p));
+    if (s->own_accum && s->accum) HIPWARN(hipFree(s->accum));
+    HIPWARN(hipFree(s->spill)); HIPWARN(hipFree(s->work_counter)); HIPWARN(hipFree(s->counters)); HIPWARN(hipFree(s->filter_dev));
+    if (s->frames) HIPWARN(hipFree(s->frames));
+    if (s->samples) HIPWARN(hipFree(s->samples));
+    if (s->resolve_buf) HIPWARN(hipFree(s->resolve_buf));
+    if (s->vol_buf) HIPWARN(hipFree(s->vol_buf));
+    HIPWARN(hipFree(s->dev_scene)); HIPWARN(hipFree(s->dev_frame));
+    if (s->ev2) HIPWARN(hipEventDestroy(s->ev2));
+    if (s->ev0) HIPWARN(hipEventDestroy(s->ev0));
+    if (s->ev1) HIPWARN(hipEventDestroy(s->ev1));
+    if (s->own_stream && s->stream) HIPWARN(hipStreamDestroy(s->stream));
     delete s;
     return RT_OK;
 }
 
 int rt_scene_set_stream(RtScene *s, void *hip_stream) {
     if (!s) return fail(RT_EINVAL, "null scene");
-    if (s->own_stream && s->stream) { hipStreamSynchronize(s->stream); hipStreamDestroy(s->stream); }
+    if (s->own_stream && s->stream) { HIPWARN(hipStreamSynchronize(s->stream)); HIPWARN(hipStreamDestroy(s->stream)); }
     s->stream = static_cast<hipStream_t>(hip_stream); s->own_stream = false;
     return RT_OK;
 }
@@ -601,7 +606,7 @@ int rt_camera_rays(RtScene *s, const RtRenderDesc *rd, uint64_t first, uint32_t 
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s->stream));
     HIPCHK(hipMemcpy(rays_out, dev, size_t(count) * sizeof(RtRay), hipMemcpyDeviceToHost));
-    hipFree(dev);
+    HIPWARN(hipFree(dev));
     return RT_OK;
 }
 
@@ -613,14 +618,14 @@ static int trace_common(RtScene *s, const RtRay *rays, uint32_t n, int any, RtHi
     HIPCHK(hipMalloc((void **)&drays, size_t(n ? n : 1) * sizeof(RtRay)));
     HIPCHK(hipMalloc(&dout, out_bytes ? out_bytes : 1));
     HIPCHK(hipMemcpy(drays, rays, size_t(n) * sizeof(RtRay), hipMemcpyHostToDevice));
-    hipEventRecord(s->ev0, s->stream);
+    HIPWARN(hipEventRecord(s->ev0, s->stream));
     hipLaunchKernelGGL(trace_kernel, dim3(s->grid), dim3(RT_BLOCK), 0, s->stream, s->dev, drays, n, any,
                        (RtHit *)(any ? nullptr : dout), (unsigned char *)(any ? dout : nullptr), s->spill, s->n_threads, s->counters);
-    hipEventRecord(s->ev1, s->stream); hipEventRecord(s->ev2, s->stream); s->have_timing = true;
+    HIPWARN(hipEventRecord(s->ev1, s->stream)); HIPWARN(hipEventRecord(s->ev2, s->stream)); s->have_timing = true;
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s->stream));
     HIPCHK(hipMemcpy(any ? (void *)occ : (void *)hits, dout, out_bytes, hipMemcpyDeviceToHost));
-    hipFree(drays); hipFree(dout);
+    HIPWARN(hipFree(drays)); HIPWARN(hipFree(dout));
     return RT_OK;
 }
 int rt_trace_closest(RtScene *s, const RtRay *rays, uint32_t n, RtHit *hits_out) { return trace_common(s, rays, n, 0, hits_out, nullptr); }
@@ -629,7 +634,7 @@ int rt_trace_any(RtScene *s, const RtRay *rays, uint32_t n, uint8_t *occluded_ou
 int rt_film_bind(RtScene *s, void *device_accum, int32_t w, int32_t h) {
     if (!s || w < 1 || h < 1) return fail(RT_EINVAL, "rt_film_bind: bad argument");
     HIPCHK(hipSetDevice(s->device));
-    if (s->own_accum && s->accum) { hipFree(s->accum); s->accum = nullptr; }
+    if (s->own_accum && s->accum) { HIPWARN(hipFree(s->accum)); s->accum = nullptr; }
     s->film_w = w; s->film_h = h;
     if (device_accum) { s->accum = static_cast<float *>(device_accum); s->own_accum = false; }
     else {
@@ -659,8 +664,7 @@ int rt_film_resolve(RtScene *s, int premultiply, float *rgb_out, float *alpha_ou
     HIPCHK(hipSetDevice(s->device));
     const size_t n = size_t(s->film_w) * s->film_h;
     if (s->resolve_cap < n) {
-        if (s->resolve_buf) hipFree(s->resolve_buf);
-    if (s->vol_buf) hipFree(s->vol_buf);
+        if (s->resolve_buf) HIPWARN(hipFree(s->resolve_buf));
         HIPCHK(hipMalloc((void **)&s->resolve_buf, n * 4 * sizeof(float))); s->resolve_cap = n;
     }
     hipLaunchKernelGGL(film_resolve_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s->stream, s->accum, n, premultiply,
@@ -679,7 +683,7 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
     if (rd->integrator != RT_INTEGRATOR_PATH) {
         const size_t need = size_t(rd->max_depth + 2) * RT_FRAME_WORDS * s->n_threads;
         if (need > s->frames_floats) {
-            if (s->frames) { HIPCHK(hipStreamSynchronize(s->stream)); hipFree(s->frames); s->frames = nullptr; }
+            if (s->frames) { HIPCHK(hipStreamSynchronize(s->stream)); HIPWARN(hipFree(s->frames)); s->frames = nullptr; }
             HIPCHK(hipMalloc((void **)&s->frames, need * sizeof(float))); s->frames_floats = need;
         }
     }
@@ -696,7 +700,7 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
         const size_t samp_words = rd->volume_integrator == RT_VOLUME_SINGLE ? size_t(3) * nmax : 0;
         const size_t need = (size_t(levels) * 8 + 13 + samp_words) * s->n_threads;
         if (need > s->vol_cap) {
-            if (s->vol_buf) { HIPCHK(hipStreamSynchronize(s->stream)); hipFree(s->vol_buf); s->vol_buf = nullptr; }
+            if (s->vol_buf) { HIPCHK(hipStreamSynchronize(s->stream)); HIPWARN(hipFree(s->vol_buf)); s->vol_buf = nullptr; }
             HIPCHK(hipMalloc((void **)&s->vol_buf, need * sizeof(float))); s->vol_cap = need;
         }
         fr.vol_rays = s->vol_buf; fr.vol_state = s->vol_buf + size_t(levels) * 8 * s->n_threads;
@@ -704,7 +708,7 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
     }
     const bool skip_film = std::getenv("PBRT_HIP_DEBUG_NOFILM") != nullptr;   // perf experiments only
     if (fr.total_work > s->samples_cap) {
-        if (s->samples) { HIPCHK(hipStreamSynchronize(s->stream)); hipFree(s->samples); s->samples = nullptr; }
+        if (s->samples) { HIPCHK(hipStreamSynchronize(s->stream)); HIPWARN(hipFree(s->samples)); s->samples = nullptr; }
         HIPCHK(hipMalloc((void **)&s->samples, size_t(fr.total_work) * 2 * sizeof(float4)));
         s->samples_cap = fr.total_work;
     }
@@ -714,6 +718,8 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
     HIPCHK(hipMemcpyAsync(s->dev_frame, &fr, sizeof(DevFrame), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemsetAsync(s->work_counter, 0, sizeof(unsigned long long), s->stream));
     HIPCHK(hipEventRecord(s->ev0, s->stream));
+    { hipError_t pre = hipGetLastError(); if (pre != hipSuccess) return fail(RT_EDEVICE, std::string("pending HIP error before launch: ") + hipGetErrorString(pre)); }
+    if (s->grids[variant] == 0) return fail(RT_ESTATE, "render kernel variant has no resident grid");
     hipLaunchKernelGGL(g_render_kernels[variant], dim3(s->grids[variant]), dim3(RT_BLOCK), 0, s->stream,
                        (const DevScene *)s->dev_scene, (const DevFrame *)s->dev_frame);
     HIPCHK(hipGetLastError());
