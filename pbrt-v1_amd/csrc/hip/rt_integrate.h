@@ -587,7 +587,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
         if (!is_black(f) && pdf > 0.f) f = div_s(f, pdf);
         const float ad = absdot3(wi, ln.v.nn);
         if (!is_black(f) && ad > 0.f) {
-            frame_push(fr, ln, gtid, f, ad, ST_POP);
+            frame_push(fr, ln, gtid, f, ad, ST_RETURN);
             ++ln.depth;
             launch_ray(ln, sc, ln.v.p, wi, RT_RAY_EPSILON, RT_INF, false, ST_VERTEX);
             if (VOL) { Ray cr; cr.o = ln.v.p; cr.d = wi; cr.mint = RT_RAY_EPSILON; cr.maxt = RT_INF; vol_store_ray(fr, ln.fsp, gtid, cr); }
