@@ -188,7 +188,7 @@ def main():
             pj = json.load(open(prof))
             out["roofline"]["traffic"] = int(pj["hbm_bytes_per_launch_fetch_doubled"])
             out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(os.path.realpath(prof)) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per launch)"
-            out["roofline"]["note"] = ("this workload's 23-node tree and 14 triangles are L1/L2 resident: measured HBM traffic is ~1% of the "
+            out["roofline"]["note"] = ("this workload's 23-node tree and 14 triangles are L1/L2 resident: measured HBM traffic is ~1%% of the "
                                        "algorithmic bytes, so the HBM roofline is not the binding limit here; VALU issue under divergence is "
                                        "(VALUBusy %.0f%%, %.0f%% of lanes active)" % (pj["derived"]["VALUBusy_percent"], pj["derived"]["VALUUtilization_percent_active_lanes"]))
         if world == 1 and not args.no_cpu_baseline:
