@@ -28,6 +28,9 @@ namespace rt {
 #ifndef RT_EXIT_THRESH
 #define RT_EXIT_THRESH 0
 #endif
+#ifndef RT_LOCKSTEP
+#define RT_LOCKSTEP 1
+#endif
 // Scene and frame descriptors are read through pointers (uniform addresses -> scalar loads on demand) instead of
 // being passed by value: the by-value form pinned >100 SGPRs and spilled them.
 template <bool COUNT, int INTEG, int ACCEL, bool VOL>
@@ -82,7 +85,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void render_kernel(const De
             const unsigned long long am = __ballot(act);
             if (!am) break;
             if (RT_EXIT_THRESH > 0 && __popcll(am) <= RT_EXIT_THRESH && __any(!act && ln.stage != ST_EXIT)) break;
+#if RT_LOCKSTEP
+            accel_round<COUNT, ACCEL>(ln.tv, ln.has_ray, sc, lds_stack, fr.spill, fr.n_threads, gtid, tc);
+#else
             if (act) accel_step<COUNT, ACCEL>(ln.tv, sc, lds_stack, fr.spill, fr.n_threads, gtid, tc);
+#endif
         }
         if (ln.has_ray && !ln.tv.active) ln.has_ray = false;
     }

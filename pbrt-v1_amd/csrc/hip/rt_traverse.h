@@ -36,6 +36,9 @@ struct Trav {
     unsigned node;
     float tmin, tmax;
     int sp;
+    // leaf / voxel primitive-list cursor for the lock-step ("while-while") traversal: at_leaf => test prims [li, ln)
+    unsigned li, ln_, ly;
+    bool at_leaf;
     // grid 3D-DDA cursor (grid.cpp:238-260): voxel position and the ray parameter of the next crossing per axis
     int gpos[3];
     float gnext[3];
@@ -77,7 +80,7 @@ RT_DEV bool tri_test(V3 p1, V3 p2, V3 p3, V3 o, V3 d, float mint, float maxt, fl
 // start a traversal: slab-clip against the tree bounds (geometry.cpp:51-68, NaN-preserving ternaries)
 RT_DEV void trav_begin(Trav &tv, const DevScene &sc, const Ray &r, bool any) {
     tv.o = r.o; tv.d = r.d; tv.mint = r.mint; tv.maxt = r.maxt; tv.any = any;
-    tv.hit_prim = -1; tv.b1 = 0.f; tv.b2 = 0.f; tv.sp = 0; tv.node = 0;
+    tv.hit_prim = -1; tv.b1 = 0.f; tv.b2 = 0.f; tv.sp = 0; tv.node = 0; tv.at_leaf = false; tv.li = tv.ln_ = tv.ly = 0;
     float t0 = r.mint, t1 = r.maxt;
     bool ok = true;
 #pragma unroll
@@ -151,7 +154,7 @@ RT_DEV float arr3(const float *a, int i) { return i == 0 ? a[0] : (i == 1 ? a[1]
 RT_DEV int arr3i(const int *a, int i) { return i == 0 ? a[0] : (i == 1 ? a[1] : a[2]); }
 RT_DEV void grid_begin(Trav &tv, const DevScene &sc, const Ray &r, bool any) {
     tv.o = r.o; tv.d = r.d; tv.mint = r.mint; tv.maxt = r.maxt; tv.any = any;
-    tv.hit_prim = -1; tv.b1 = 0.f; tv.b2 = 0.f; tv.sp = 0; tv.node = 0;
+    tv.hit_prim = -1; tv.b1 = 0.f; tv.b2 = 0.f; tv.sp = 0; tv.node = 0; tv.at_leaf = false; tv.li = tv.ln_ = tv.ly = 0;
     tv.inv = mk3(0.f); tv.tmin = tv.tmax = 0.f;
     float rayT;
     const V3 pm = r.o + r.d * r.mint;                                        // bounds.Inside(ray(ray.mint))
@@ -215,6 +218,98 @@ RT_DEV void grid_step(Trav &tv, const DevScene &sc, TravCounters &cnt) {
     if (stepAxis == 0) { tv.gpos[0] = np; tv.gnext[0] = nx + delta; }
     else if (stepAxis == 1) { tv.gpos[1] = np; tv.gnext[1] = nx + delta; }
     else { tv.gpos[2] = np; tv.gnext[2] = nx + delta; }
+}
+
+// ---- lock-step ("while-while") form of the same traversals ---------------------------------------------------
+// The per-lane order of node visits and triangle tests is exactly that of trav_step / grid_step (so hits, ties and
+// counters are unchanged); what changes is how the 64 lanes are interleaved: all lanes first walk interior nodes
+// (cheap) until each sits at a leaf, then the expensive ray-triangle tests run with every lane that has a primitive
+// left -- instead of one lane's 8-triangle leaf serialising against 63 lanes doing 20-instruction plane tests.
+template <bool COUNT>
+RT_DEV void kd_descend(Trav &tv, const DevScene &sc, uint2 *lds_stack, uint2 *spill, unsigned n_threads, unsigned gtid, TravCounters &cnt) {
+    if (!tv.any && tv.maxt < tv.tmin) { tv.active = false; return; }      // kdtree.cpp:330
+    const uint2 nd = sc.nodes[tv.node];
+    if (COUNT) ++cnt.nodes;
+    if ((nd.x & 3u) == 3u) { tv.at_leaf = true; tv.li = 0; tv.ln_ = nd.x >> 2; tv.ly = nd.y; return; }
+    const int axis = int(nd.x & 3u);
+    const float split = __uint_as_float(nd.x);
+    const float oa = comp(tv.o, axis), da = comp(tv.d, axis);
+    const float tplane = (split - oa) * comp(tv.inv, axis);
+    const bool belowFirst = (oa < split) || (oa == split && da >= 0.f);
+    const unsigned first = belowFirst ? tv.node + 1 : nd.y;
+    const unsigned second = belowFirst ? nd.y : tv.node + 1;
+    if (tplane > tv.tmax || tplane <= 0.f) tv.node = first;
+    else if (tplane < tv.tmin) tv.node = second;
+    else {
+        const uint2 e = make_uint2(second, __float_as_uint(tv.tmax));
+        if (tv.sp < RT_STACK_LDS) lds_stack[tv.sp * RT_BLOCK + threadIdx.x] = e;
+        else { spill[size_t(tv.sp - RT_STACK_LDS) * n_threads + gtid] = e; if (COUNT) ++cnt.spills; }
+        ++tv.sp;
+        tv.node = first;
+        tv.tmax = tplane;
+    }
+}
+// one primitive of the current leaf / voxel list
+template <bool COUNT, bool GRID>
+RT_DEV void leaf_test_one(Trav &tv, const DevScene &sc, TravCounters &cnt) {
+    const bool single = !GRID && tv.ln_ == 1;
+    const unsigned prim = single ? tv.ly : sc.leaf_refs[tv.ly + tv.li];
+    ++tv.li;
+    if (COUNT) { ++cnt.tris; if (!single) ++cnt.leaf_refs; }
+    V3 p1, p2, p3; unsigned bits; int light;
+    tri_verts(sc.tris, prim, p1, p2, p3, bits, light);
+    float t, b1, b2;
+    if (tri_test(p1, p2, p3, tv.o, tv.d, tv.mint, tv.maxt, t, b1, b2)) {
+        if (tv.any) { tv.hit_prim = 0; tv.active = false; return; }
+        tv.maxt = t; tv.hit_prim = int(prim); tv.b1 = b1; tv.b2 = b2;
+    }
+}
+RT_DEV void kd_leaf_done(Trav &tv, const uint2 *lds_stack, const uint2 *spill, unsigned n_threads, unsigned gtid) {
+    tv.at_leaf = false;
+    if (tv.sp > 0) {
+        --tv.sp;
+        const uint2 e = (tv.sp < RT_STACK_LDS) ? lds_stack[tv.sp * RT_BLOCK + threadIdx.x]
+                                                : spill[size_t(tv.sp - RT_STACK_LDS) * n_threads + gtid];
+        tv.node = e.x; tv.tmin = tv.tmax; tv.tmax = __uint_as_float(e.y);
+    } else tv.active = false;
+}
+template <bool COUNT>
+RT_DEV void grid_enter_voxel(Trav &tv, const DevScene &sc, TravCounters &cnt) {
+    const uint2 vx = sc.nodes[(size_t(tv.gpos[2]) * sc.nvox[1] + tv.gpos[1]) * sc.nvox[0] + tv.gpos[0]];
+    if (COUNT) ++cnt.nodes;
+    tv.at_leaf = true; tv.li = 0; tv.ln_ = vx.y; tv.ly = vx.x;
+}
+RT_DEV void grid_voxel_done(Trav &tv, const DevScene &sc) {               // grid.cpp:273-283
+    tv.at_leaf = false;
+    const int bits = ((tv.gnext[0] < tv.gnext[1]) << 2) + ((tv.gnext[0] < tv.gnext[2]) << 1) + ((tv.gnext[1] < tv.gnext[2]));
+    const int stepAxis = (0x00221212 >> (4 * bits)) & 3;
+    const float nx = arr3(tv.gnext, stepAxis);
+    if (tv.maxt < nx) { tv.active = false; return; }
+    const float da = comp(tv.d, stepAxis);
+    const int step = da >= 0 ? 1 : -1, out = da >= 0 ? arr3i(sc.nvox, stepAxis) : -1;
+    const int np = arr3i(tv.gpos, stepAxis) + step;
+    if (np == out) { tv.active = false; return; }
+    const float delta = (da >= 0 ? arr3(sc.gwidth, stepAxis) : -arr3(sc.gwidth, stepAxis)) / da;
+    if (stepAxis == 0) { tv.gpos[0] = np; tv.gnext[0] = nx + delta; }
+    else if (stepAxis == 1) { tv.gpos[1] = np; tv.gnext[1] = nx + delta; }
+    else { tv.gpos[2] = np; tv.gnext[2] = nx + delta; }
+}
+
+// One lock-step round for the whole wave: descend -> test -> pop.  `mine` = this lane carries a live traversal.
+template <bool COUNT, int ACCEL>
+RT_DEV void accel_round(Trav &tv, bool mine, const DevScene &sc, uint2 *lds_stack, uint2 *spill, unsigned n_threads,
+                        unsigned gtid, TravCounters &cnt) {
+    if (ACCEL == RT_ACCEL_GRID) {
+        if (mine && tv.active && !tv.at_leaf) grid_enter_voxel<COUNT>(tv, sc, cnt);
+    } else {
+        while (__any(mine && tv.active && !tv.at_leaf))
+            if (mine && tv.active && !tv.at_leaf) kd_descend<COUNT>(tv, sc, lds_stack, spill, n_threads, gtid, cnt);
+    }
+    while (__any(mine && tv.active && tv.at_leaf && tv.li < tv.ln_))
+        if (mine && tv.active && tv.at_leaf && tv.li < tv.ln_) leaf_test_one<COUNT, ACCEL == RT_ACCEL_GRID>(tv, sc, cnt);
+    if (mine && tv.active && tv.at_leaf) {
+        if (ACCEL == RT_ACCEL_GRID) grid_voxel_done(tv, sc); else kd_leaf_done(tv, lds_stack, spill, n_threads, gtid);
+    }
 }
 
 // accelerator dispatch (compile-time)

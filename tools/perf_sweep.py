@@ -24,6 +24,13 @@ def run(tag, defs=(), env=None, workload="c2", steps=2, extra=()):
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "a"
+    if which == "d":
+        run("lockstep")
+        run("stepwise", ["-DRT_LOCKSTEP=0"])
+        run("lockstep_c3_100k", workload="c3_100000")
+        run("stepwise_c3_100k", ["-DRT_LOCKSTEP=0"], workload="c3_100000")
+        run("lockstep_c3_100k_exit24", ["-DRT_EXIT_THRESH=24"], workload="c3_100000")
+        run("lockstep_lds16", ["-DRT_STACK_LDS=16"])
     if which == "c":
         run("base")
         run("nofilm", env={"PBRT_HIP_DEBUG_NOFILM": "1"})
