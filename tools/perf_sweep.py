@@ -7,7 +7,7 @@ LIB = os.path.join(ROOT, "pbrt-v1_amd", "lib", "libpbrt_hip.so")
 BASE = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unused-value"]
 
 def run(tag, defs=(), env=None, workload="c2", steps=2, extra=()):
-    cmd = BASE + list(defs) + [os.path.join(HIP, "rt_kernels.hip"), os.path.join(HIP, "kd_build.cpp"), "-o", LIB]
+    cmd = BASE + list(defs) + [os.path.join(HIP, "rt_kernels.hip"), os.path.join(HIP, "kd_build.cpp"), os.path.join(HIP, "grid_build.cpp"), "-o", LIB]
     subprocess.check_call(cmd)
     e = dict(os.environ); e.update(env or {})
     try:
@@ -20,7 +20,7 @@ def run(tag, defs=(), env=None, workload="c2", steps=2, extra=()):
         print(json.dumps(dict(tag=tag, workload=workload, Mrays=j["value"], ms=j["ms_per_step"], kernel_ms=j["roofline"]["kernel_ms"],
                               frac=j["roofline"]["frac"], rays_per_frame=j["config"]["rays_per_frame"])), flush=True)
     except Exception as ex:
-        print(json.dumps(dict(tag=tag, error=str(ex), stderr=r.stderr[-800:])), flush=True)
+        print(json.dumps(dict(tag=tag, error=str(ex), stderr=r.stderr[-300:])), flush=True)
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "a"
