@@ -85,7 +85,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void render_kernel(const De
             const unsigned long long am = __ballot(act);
             if (!am) break;
             if (RT_EXIT_THRESH > 0 && __popcll(am) <= RT_EXIT_THRESH && __any(!act && ln.stage != ST_EXIT)) break;
-#if RT_LOCKSTEP
+#if RT_LOCKSTEP == 2
+            accel_round_batched<COUNT, ACCEL>(ln.tv, ln.has_ray, sc, lds_stack, fr.spill, fr.n_threads, gtid, tc);
+#elif RT_LOCKSTEP == 1
             accel_round<COUNT, ACCEL>(ln.tv, ln.has_ray, sc, lds_stack, fr.spill, fr.n_threads, gtid, tc);
 #else
             if (act) accel_step<COUNT, ACCEL>(ln.tv, sc, lds_stack, fr.spill, fr.n_threads, gtid, tc);

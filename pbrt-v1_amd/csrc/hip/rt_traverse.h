@@ -312,6 +312,32 @@ RT_DEV void accel_round(Trav &tv, bool mine, const DevScene &sc, uint2 *lds_stac
     }
 }
 
+// Batched form: every round each descending lane takes ONE interior step; lanes parked at a leaf wait until at least
+// RT_BATCH_K lanes have a primitive to test (or nobody is descending any more), then one ray-triangle test is issued
+// for all of them together.  Adapts between the tiny-tree regime (many primitives per leaf: behaves like lock-step)
+// and the big-tree regime (long interior chains, ~1 primitive per leaf: lanes are not held hostage by one another).
+#ifndef RT_BATCH_K
+#define RT_BATCH_K 16
+#endif
+template <bool COUNT, int ACCEL>
+RT_DEV void accel_round_batched(Trav &tv, bool mine, const DevScene &sc, uint2 *lds_stack, uint2 *spill, unsigned n_threads,
+                                unsigned gtid, TravCounters &cnt) {
+    const bool act = mine && tv.active;
+    const bool desc = act && !tv.at_leaf;
+    const bool leafw = act && tv.at_leaf && tv.li < tv.ln_;
+    const int nd = __popcll(__ballot(desc)), nl = __popcll(__ballot(leafw));
+    if (desc) {
+        if (ACCEL == RT_ACCEL_GRID) grid_enter_voxel<COUNT>(tv, sc, cnt);
+        else kd_descend<COUNT>(tv, sc, lds_stack, spill, n_threads, gtid, cnt);
+    }
+    if (nl && (nl >= RT_BATCH_K || nd == 0)) {
+        if (leafw) leaf_test_one<COUNT, ACCEL == RT_ACCEL_GRID>(tv, sc, cnt);
+    }
+    if (mine && tv.active && tv.at_leaf && tv.li >= tv.ln_) {
+        if (ACCEL == RT_ACCEL_GRID) grid_voxel_done(tv, sc); else kd_leaf_done(tv, lds_stack, spill, n_threads, gtid);
+    }
+}
+
 // accelerator dispatch (compile-time)
 template <int ACCEL>
 RT_DEV void accel_begin(Trav &tv, const DevScene &sc, const Ray &r, bool any) {

@@ -24,6 +24,11 @@ def run(tag, defs=(), env=None, workload="c2", steps=2, extra=()):
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "a"
+    if which == "e":
+        for k in (8, 16, 32, 48):
+            run("batched_k%d" % k, ["-DRT_LOCKSTEP=2", "-DRT_BATCH_K=%d" % k])
+            run("batched_k%d_c3_100k" % k, ["-DRT_LOCKSTEP=2", "-DRT_BATCH_K=%d" % k], workload="c3_100000")
+        run("batched_k16_c3_100k_exit24", ["-DRT_LOCKSTEP=2", "-DRT_BATCH_K=16", "-DRT_EXIT_THRESH=24"], workload="c3_100000")
     if which == "d":
         run("lockstep")
         run("stepwise", ["-DRT_LOCKSTEP=0"])
