@@ -60,6 +60,8 @@ struct DevFrame {
     float *accum;                // 5 planes
     float4 *samples;             // per-shard sample buffer, 2 x float4 per work item
     int shard_index, shard_count, tile_pixels;
+    int exit_thresh;             // leave the shared traversal loop when <= this many lanes still traverse (0 = never)
+    int trav_mode;               // 0 = one node per lane per round, 1 = lock-step (descend all, then test), 2 = batched
     unsigned long long total_work;     // samples this shard renders
     unsigned long long total_pixels;   // pixels in the sample extent
     // sampler dimension table (Sample::oneD/twoD, sampling.cpp:41-70)

@@ -84,14 +84,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void render_kernel(const De
             const bool act = ln.has_ray && ln.tv.active;
             const unsigned long long am = __ballot(act);
             if (!am) break;
-            if (RT_EXIT_THRESH > 0 && __popcll(am) <= RT_EXIT_THRESH && __any(!act && ln.stage != ST_EXIT)) break;
-#if RT_LOCKSTEP == 2
-            accel_round_batched<COUNT, ACCEL>(ln.tv, ln.has_ray, sc, lds_stack, fr.spill, fr.n_threads, gtid, tc);
-#elif RT_LOCKSTEP == 1
-            accel_round<COUNT, ACCEL>(ln.tv, ln.has_ray, sc, lds_stack, fr.spill, fr.n_threads, gtid, tc);
-#else
-            if (act) accel_step<COUNT, ACCEL>(ln.tv, sc, lds_stack, fr.spill, fr.n_threads, gtid, tc);
-#endif
+            if (fr.exit_thresh > 0 && __popcll(am) <= fr.exit_thresh && __any(!act && ln.stage != ST_EXIT)) break;
+            if (fr.trav_mode == 1) accel_round<COUNT, ACCEL>(ln.tv, ln.has_ray, sc, lds_stack, fr.spill, fr.n_threads, gtid, tc);
+            else if (fr.trav_mode == 2) accel_round_batched<COUNT, ACCEL>(ln.tv, ln.has_ray, sc, lds_stack, fr.spill, fr.n_threads, gtid, tc);
+            else if (act) accel_step<COUNT, ACCEL>(ln.tv, sc, lds_stack, fr.spill, fr.n_threads, gtid, tc);
         }
         if (ln.has_ray && !ln.tv.active) ln.has_ray = false;
     }
@@ -595,6 +591,18 @@ static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool nee
         for (size_t i = 0; i < n2.size(); ++i) { fr.two_d[i] = DimReq{c, 0, (unsigned short)n2[i], 2}; c += 2u + unsigned(n2[i]) * P + P; }
         fr.lhs_total = 0;
         fr.pixgen_draws = c;
+    }
+    // traversal scheduling knobs (performance only; results and counters do not depend on them)
+    {
+        const size_t nn = s->tree.nodes.size();
+        size_t leaves = 0, refs = 0;
+        if (s->accel_kind == RT_ACCEL_KDTREE) for (const Node &n : s->tree.nodes) if ((n.x & 3u) == 3u && (n.x >> 2)) { ++leaves; refs += n.x >> 2; }
+        const double per_leaf = leaves ? double(refs) / double(leaves) : 1.0;
+        const bool tiny = nn <= 4096 && per_leaf >= 1.5;       // few fat leaves: triangle tests dominate -> lock-step rounds
+        fr.trav_mode = tiny ? 1 : 0;
+        fr.exit_thresh = tiny ? 0 : 24;                        // long divergent rays: let finished lanes refill early
+        if (const char *e = std::getenv("PBRT_HIP_TRAV_MODE")) fr.trav_mode = std::atoi(e);
+        if (const char *e = std::getenv("PBRT_HIP_EXIT_THRESH")) fr.exit_thresh = std::atoi(e);
     }
     fr.work_counter = s->work_counter; fr.counters = s->counters; fr.spill = s->spill; fr.n_threads = s->n_threads;
     fr.frames = s->frames;

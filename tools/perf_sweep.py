@@ -22,8 +22,17 @@ def run(tag, defs=(), env=None, workload="c2", steps=2, extra=()):
     except Exception as ex:
         print(json.dumps(dict(tag=tag, error=str(ex), stderr=r.stderr[-300:])), flush=True)
 
-if __name__ == "__main__":
+def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "a"
+    if which == "f":
+        run("auto_c2")
+        run("auto_c3_100k", workload="c3_100000")
+        for mode in (0, 2):
+            for ex in (16, 32, 40, 48, 56):
+                run("c3_100k_mode%d_exit%d" % (mode, ex), env={"PBRT_HIP_TRAV_MODE": str(mode), "PBRT_HIP_EXIT_THRESH": str(ex)}, workload="c3_100000")
+        run("c2_mode1_exit8", env={"PBRT_HIP_TRAV_MODE": "1", "PBRT_HIP_EXIT_THRESH": "8"})
+        run("c2_mode1_exit16", env={"PBRT_HIP_TRAV_MODE": "1", "PBRT_HIP_EXIT_THRESH": "16"})
+        return
     if which == "e":
         for k in (8, 16, 32, 48):
             run("batched_k%d" % k, ["-DRT_LOCKSTEP=2", "-DRT_BATCH_K=%d" % k])
@@ -64,3 +73,6 @@ if __name__ == "__main__":
         run("c3_100k_base", workload="c3_100000")
         run("c3_100k_exit24", ["-DRT_EXIT_THRESH=24"], workload="c3_100000")
     run("base_restore")
+
+if __name__ == "__main__":
+    main()
