@@ -47,6 +47,12 @@ def workload(name: str):
                                     jitter=True, pixel_filter="mitchell", soup_tris=ntri)
         label = "Cornell + %d-triangle LCG soup, DirectLighting(all), 1920x1080 @ 16 spp, mitchell, kd-tree" % ntri
         crop = (0.47, 0.53, 0.47, 0.53)
+    elif name.startswith("p"):              # p1000000: Cornell + N-triangle soup, path tracing (the north-star's 1M-triangle case)
+        ntri = int(name[1:])
+        text = scenes.cornell_scene(xres=1024, yres=1024, integrator="path", maxdepth=5, xsamples=4, ysamples=4,
+                                    jitter=True, pixel_filter="mitchell", soup_tris=ntri)
+        label = "Cornell + %d-triangle LCG soup, PathIntegrator maxdepth=5, 1024x1024 @ 16 spp, mitchell, kd-tree" % ntri
+        crop = (0.48, 0.52, 0.48, 0.52)
     else:
         raise SystemExit("unknown workload " + name)
     return text, label, crop

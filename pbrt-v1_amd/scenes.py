@@ -34,19 +34,20 @@ def lcg_soup(n_tris: int, seed: int = 12345) -> np.ndarray:
     n = n_tris * 12
     a, c, m = 1664525, 1013904223, 1 << 32
     # doubling scheme: (A_k, C_k) such that s_{i+k} = A_k s_i + C_k
-    s = np.empty(n, dtype=np.uint64)
     if n == 0:
         return np.zeros((0, 3, 3), np.float32)
+    s = np.empty(n, dtype=np.uint32)              # uint32 array arithmetic wraps mod 2^32, which is the LCG's modulus
     s[0] = (seed * a + c) % m
     filled = 1
     A, C = a, c
-    while filled < n:
-        k = min(filled, n - filled)
-        s[filled:filled + k] = (s[:k] * np.uint64(A) + np.uint64(C)) % np.uint64(m)
-        filled += k
-        C = (A * C + C) % m
-        A = (A * A) % m
-    u = ((s >> np.uint64(8)).astype(np.float64) / float(1 << 24)).astype(np.float32)
+    with np.errstate(over="ignore"):
+        while filled < n:
+            k = min(filled, n - filled)
+            s[filled:filled + k] = s[:k] * np.uint32(A) + np.uint32(C)
+            filled += k
+            C = (A * C + C) % m
+            A = (A * A) % m
+    u = (s >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / (1 << 24))     # < 2^24: exact in float32
     u = u.reshape(n_tris, 12)
     lo = np.array([50, 50, 50], np.float32)
     ext = np.array([450, 400, 450], np.float32)
@@ -57,8 +58,13 @@ def lcg_soup(n_tris: int, seed: int = 12345) -> np.ndarray:
 
 def soup_shape_text(tris: np.ndarray) -> str:
     n = tris.shape[0]
-    pts = " ".join("%.9g" % v for v in tris.reshape(-1))
-    idx = " ".join(str(i) for i in range(3 * n))
+    import io
+    buf = io.StringIO()
+    np.savetxt(buf, tris.reshape(-1, 9), fmt="%.9g")
+    pts = buf.getvalue()
+    buf = io.StringIO()
+    np.savetxt(buf, np.arange(3 * n, dtype=np.int64).reshape(-1, 3), fmt="%d")
+    idx = buf.getvalue()
     return 'Shape "trianglemesh" "integer indices" [%s] "point P" [%s]\n' % (idx, pts)
 
 
