@@ -146,10 +146,32 @@ def host_lib():
         L.pbrt_host_camera.argtypes = [C.c_void_p]
         L.pbrt_host_tri_verts.restype = C.POINTER(C.c_float)
         L.pbrt_host_tri_verts.argtypes = [C.c_void_p]
+        L.pbrt_host_write_exr.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6
+        L.pbrt_host_read_exr_info.argtypes = [C.c_char_p, C.POINTER(C.c_int * 6)]
+        L.pbrt_host_read_exr.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p]
         L.pbrt_host_accel_params.restype = C.c_void_p
         L.pbrt_host_accel_params.argtypes = [C.c_void_p]
         _host = L
     return _host
+
+
+def write_exr(path, rgb, alpha, total_res=None, offset=(0, 0)):
+    """WriteRGBAImage (core/exrio.cpp:75-96): RGBA half EXR with data/display windows (own minimal writer)."""
+    rgb = np.ascontiguousarray(rgb, np.float32); alpha = np.ascontiguousarray(alpha, np.float32)
+    h, w = alpha.shape
+    tw, th = total_res if total_res else (w, h)
+    if host_lib().pbrt_host_write_exr(path.encode(), rgb.ctypes.data, alpha.ctypes.data, w, h, tw, th, offset[0], offset[1]) != 0:
+        raise IOError("cannot write " + path)
+
+
+def read_exr(path):
+    info = (C.c_int * 6)()
+    if host_lib().pbrt_host_read_exr_info(path.encode(), C.byref(info)) != 0:
+        raise IOError("cannot read " + path)
+    w, h = info[0], info[1]
+    rgb = np.zeros((h, w, 3), np.float32); alpha = np.zeros((h, w), np.float32)
+    host_lib().pbrt_host_read_exr(path.encode(), rgb.ctypes.data, alpha.ctypes.data)
+    return rgb, alpha, dict(total_res=(info[2], info[3]), offset=(info[4], info[5]))
 
 
 class RtError(RuntimeError):

@@ -1,0 +1,140 @@
+// exr_io.h -- minimal OpenEXR (RGBA half, scanline) writer / reader for the film output.
+//
+// The reference writes its image through OpenEXR's RgbaOutputFile (core/exrio.cpp:75-96): RGBA *half* pixels, a
+// dataWindow equal to the rendered crop placed inside a displayWindow of the full resolution.  OpenEXR is a
+// third-party library that is not vendored in the reference tree (exrinstall.txt: "latest") and is not installed
+// here, so this is an independent writer of the published OpenEXR 2 single-part scanline layout: magic 20000630,
+// version 2, attributes channels/compression/dataWindow/displayWindow/lineOrder/pixelAspectRatio/
+// screenWindowCenter/screenWindowWidth, an offset table, one chunk per scanline with the channels in alphabetical
+// order (A, B, G, R).  Compression is NO_COMPRESSION (RgbaOutputFile's default is PIZ; the pixel values -- the only
+// thing parity is defined on -- are identical).  float -> half is round-to-nearest-even with overflow to infinity,
+// as ImfHalf / half.h do.  The reader accepts exactly what the writer produces (enough for tile merging, the role of
+// tools/exrassemble.cpp:42-67, and for tests).
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace pbrthip {
+
+inline uint16_t float_to_half(float f) {
+    uint32_t x; std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const int32_t e = int32_t((x >> 23) & 0xff) - 127 + 15;
+    uint32_t m = x & 0x7fffffu;
+    if (((x >> 23) & 0xff) == 0xff) return uint16_t(sign | 0x7c00u | (m ? (0x200u | (m >> 13)) : 0u));   // inf / nan
+    if (e >= 31) return uint16_t(sign | 0x7c00u);                                                        // overflow -> inf
+    if (e <= 0) {                                                                                        // half denormal / zero
+        if (e < -10) return uint16_t(sign);
+        m |= 0x800000u;
+        const int shift = 14 - e;
+        uint32_t h = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1), half_way = 1u << (shift - 1);
+        if (rem > half_way || (rem == half_way && (h & 1))) ++h;
+        return uint16_t(sign | h);
+    }
+    uint32_t h = (uint32_t(e) << 10) | (m >> 13);
+    const uint32_t rem = m & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1))) ++h;                                                // may carry into the exponent: still correct
+    return uint16_t(sign | h);
+}
+inline float half_to_float(uint16_t h) {
+    const uint32_t sign = uint32_t(h & 0x8000u) << 16;
+    uint32_t e = (h >> 10) & 0x1f, m = h & 0x3ffu, x;
+    if (e == 0) {
+        if (m == 0) x = sign;
+        else { e = 1; while (!(m & 0x400u)) { m <<= 1; --e; } m &= 0x3ffu; x = sign | ((e + 127 - 15) << 23) | (m << 13); }
+    } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+    else x = sign | ((e + 127 - 15) << 23) | (m << 13);
+    float f; std::memcpy(&f, &x, 4); return f;
+}
+
+struct ExrImage {
+    int xRes = 0, yRes = 0, totalXRes = 0, totalYRes = 0, xOffset = 0, yOffset = 0;
+    std::vector<float> rgb, alpha;      // [yRes][xRes][3], [yRes][xRes] (after half quantisation)
+};
+
+// same argument list as the reference's WriteRGBAImage (core/pbrt.h:236-238)
+inline bool WriteRGBAImage(const std::string &name, const float *pixels, const float *alpha, int xRes, int yRes,
+                           int totalXRes, int totalYRes, int xOffset, int yOffset) {
+    FILE *f = std::fopen(name.c_str(), "wb");
+    if (!f) return false;
+    std::vector<unsigned char> hdr;
+    auto put = [&](const void *p, size_t n) { const unsigned char *c = (const unsigned char *)p; hdr.insert(hdr.end(), c, c + n); };
+    auto puts0 = [&](const char *s) { put(s, std::strlen(s) + 1); };
+    auto puti = [&](int32_t v) { put(&v, 4); };
+    auto putf = [&](float v) { put(&v, 4); };
+    const unsigned char magic[8] = {0x76, 0x2f, 0x31, 0x01, 2, 0, 0, 0};
+    put(magic, 8);
+    puts0("channels"); puts0("chlist"); puti(4 * 18 + 1);
+    for (const char *ch : {"A", "B", "G", "R"}) { puts0(ch); puti(1 /*HALF*/); const unsigned char lin[4] = {0, 0, 0, 0}; put(lin, 4); puti(1); puti(1); }
+    hdr.push_back(0);
+    puts0("compression"); puts0("compression"); puti(1); hdr.push_back(0);
+    puts0("dataWindow"); puts0("box2i"); puti(16); puti(xOffset); puti(yOffset); puti(xOffset + xRes - 1); puti(yOffset + yRes - 1);
+    puts0("displayWindow"); puts0("box2i"); puti(16); puti(0); puti(0); puti(totalXRes - 1); puti(totalYRes - 1);
+    puts0("lineOrder"); puts0("lineOrder"); puti(1); hdr.push_back(0);
+    puts0("pixelAspectRatio"); puts0("float"); puti(4); putf(1.f);
+    puts0("screenWindowCenter"); puts0("v2f"); puti(8); putf(0.f); putf(0.f);
+    puts0("screenWindowWidth"); puts0("float"); puti(4); putf(1.f);
+    hdr.push_back(0);
+    const uint64_t row_bytes = uint64_t(xRes) * 4 * 2, chunk = 8 + row_bytes;
+    uint64_t off = hdr.size() + uint64_t(yRes) * 8;
+    std::fwrite(hdr.data(), 1, hdr.size(), f);
+    for (int y = 0; y < yRes; ++y, off += chunk) std::fwrite(&off, 8, 1, f);
+    std::vector<uint16_t> row(size_t(xRes) * 4);
+    for (int y = 0; y < yRes; ++y) {
+        for (int x = 0; x < xRes; ++x) {
+            const size_t i = size_t(y) * xRes + x;
+            row[x] = float_to_half(alpha ? alpha[i] : 1.f);
+            row[size_t(xRes) + x] = float_to_half(pixels[3 * i + 2]);
+            row[size_t(2) * xRes + x] = float_to_half(pixels[3 * i + 1]);
+            row[size_t(3) * xRes + x] = float_to_half(pixels[3 * i]);
+        }
+        const int32_t yy = yOffset + y, sz = int32_t(row_bytes);
+        std::fwrite(&yy, 4, 1, f); std::fwrite(&sz, 4, 1, f); std::fwrite(row.data(), 2, row.size(), f);
+    }
+    std::fclose(f);
+    return true;
+}
+
+inline bool ReadRGBAImage(const std::string &name, ExrImage &img) {
+    FILE *f = std::fopen(name.c_str(), "rb");
+    if (!f) return false;
+    std::vector<unsigned char> buf;
+    { std::fseek(f, 0, SEEK_END); long n = std::ftell(f); std::fseek(f, 0, SEEK_SET); buf.resize(size_t(n)); if (std::fread(buf.data(), 1, buf.size(), f) != buf.size()) { std::fclose(f); return false; } }
+    std::fclose(f);
+    if (buf.size() < 8 || buf[0] != 0x76 || buf[1] != 0x2f || buf[2] != 0x31 || buf[3] != 0x01 || buf[4] != 2) return false;
+    size_t p = 8; int dw[4] = {0, 0, -1, -1}, disp[4] = {0, 0, -1, -1}; int compression = -1; std::string chans;
+    while (p < buf.size() && buf[p]) {
+        std::string an((const char *)&buf[p]); p += an.size() + 1;
+        std::string ty((const char *)&buf[p]); p += ty.size() + 1;
+        int32_t sz; std::memcpy(&sz, &buf[p], 4); p += 4;
+        if (an == "dataWindow") std::memcpy(dw, &buf[p], 16);
+        else if (an == "displayWindow") std::memcpy(disp, &buf[p], 16);
+        else if (an == "compression") compression = buf[p];
+        else if (an == "channels") { size_t q = p; while (buf[q]) { std::string c((const char *)&buf[q]); chans += c; q += c.size() + 1 + 16; } }
+        p += size_t(sz);
+    }
+    ++p;
+    if (compression != 0 || chans != "ABGR") return false;
+    img.xRes = dw[2] - dw[0] + 1; img.yRes = dw[3] - dw[1] + 1; img.xOffset = dw[0]; img.yOffset = dw[1];
+    img.totalXRes = disp[2] + 1; img.totalYRes = disp[3] + 1;
+    img.rgb.assign(size_t(3) * img.xRes * img.yRes, 0.f); img.alpha.assign(size_t(img.xRes) * img.yRes, 0.f);
+    for (int y = 0; y < img.yRes; ++y) {
+        uint64_t off; std::memcpy(&off, &buf[p + size_t(8) * y], 8);
+        int32_t yy; std::memcpy(&yy, &buf[off], 4);
+        const uint16_t *row = (const uint16_t *)&buf[off + 8];
+        const int ry = yy - img.yOffset;
+        for (int x = 0; x < img.xRes; ++x) {
+            const size_t i = size_t(ry) * img.xRes + x;
+            uint16_t h[4]; for (int c = 0; c < 4; ++c) std::memcpy(&h[c], &row[size_t(c) * img.xRes + x], 2);
+            img.alpha[i] = half_to_float(h[0]); img.rgb[3 * i + 2] = half_to_float(h[1]);
+            img.rgb[3 * i + 1] = half_to_float(h[2]); img.rgb[3 * i] = half_to_float(h[3]);
+        }
+    }
+    return true;
+}
+
+}  // namespace pbrthip

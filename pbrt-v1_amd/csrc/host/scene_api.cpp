@@ -1,5 +1,6 @@
 // scene_api.cpp -- see scene_api.h.  Citations are to the reference tree (/root/reference).
 #include "scene_api.h"
+#include "exr_io.h"
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -536,4 +537,16 @@ void pbrt_host_scene_counts(const RtSceneDesc *s, unsigned *out4) { out4[0] = s-
 const float *pbrt_host_camera(const RtSceneDesc *s) { return s->camera.raster_to_camera; }
 const float *pbrt_host_tri_verts(const RtSceneDesc *s) { return s->tri_verts; }
 const RtAccelParams *pbrt_host_accel_params(const RtSceneDesc *s) { return &s->accel; }
+// Film output: the reference's WriteRGBAImage (core/exrio.cpp:75-96) and the tile merge of tools/exrassemble.cpp
+int pbrt_host_write_exr(const char *path, const float *rgb, const float *alpha, int xRes, int yRes, int totalX, int totalY, int xOff, int yOff) {
+    return WriteRGBAImage(path, rgb, alpha, xRes, yRes, totalX, totalY, xOff, yOff) ? 0 : -1;
+}
+int pbrt_host_read_exr_info(const char *path, int *out6) {
+    ExrImage img; if (!ReadRGBAImage(path, img)) return -1;
+    out6[0] = img.xRes; out6[1] = img.yRes; out6[2] = img.totalXRes; out6[3] = img.totalYRes; out6[4] = img.xOffset; out6[5] = img.yOffset; return 0;
+}
+int pbrt_host_read_exr(const char *path, float *rgb, float *alpha) {
+    ExrImage img; if (!ReadRGBAImage(path, img)) return -1;
+    std::memcpy(rgb, img.rgb.data(), img.rgb.size() * sizeof(float)); std::memcpy(alpha, img.alpha.data(), img.alpha.size() * sizeof(float)); return 0;
+}
 }

@@ -104,3 +104,21 @@ def test_soup_generator_is_deterministic_lcg(scenes):
     v0 = c + (np.array(vals[3:6], np.float32) * np.float32(8) - np.float32(4))
     assert np.allclose(a[0, 0], v0) and a.shape == (7, 3, 3)
     assert a.min() >= 46 and a.max() <= 504
+
+
+def test_exr_writer_round_trip_and_half_rounding(pkg, tmp_path):
+    """Own minimal EXR writer (the reference delegates to OpenEXR, core/exrio.cpp:75-96): RGBA half, data window inside
+    the display window; float->half must round to nearest even exactly like IEEE binary16 (numpy float16)."""
+    rng = np.random.default_rng(1)
+    vals = np.concatenate([rng.uniform(0, 30, 4000), rng.uniform(0, 1e-5, 500), [0, 1, 65504, 65520, 1e6, 6.1e-5, 5.96e-8, 2.98e-8, 0.333251953125]])
+    vals = np.resize(vals.astype(np.float32), (50, 91, 3))
+    alpha = rng.uniform(0, 1, (50, 91)).astype(np.float32)
+    p = str(tmp_path / "t.exr")
+    pkg.write_exr(p, vals, alpha, total_res=(200, 100), offset=(17, 23))
+    rgb, a, meta = pkg.read_exr(p)
+    assert meta == dict(total_res=(200, 100), offset=(17, 23))
+    with np.errstate(over="ignore"):
+        assert np.array_equal(rgb, vals.astype(np.float16).astype(np.float32))
+        assert np.array_equal(a, alpha.astype(np.float16).astype(np.float32))
+    raw = open(p, "rb").read()
+    assert raw[:8] == bytes([0x76, 0x2f, 0x31, 0x01, 2, 0, 0, 0]) and b"dataWindow\x00box2i" in raw and b"displayWindow" in raw
