@@ -23,13 +23,20 @@ def lib():
         L.oracle_trace.restype = C.c_int
         L.oracle_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_set_mailbox.restype = None
+        L.oracle_set_mailbox.argtypes = [C.c_int]
         L.oracle_resolve.restype = None
         L.oracle_resolve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
 
-COUNTER_NAMES = ("camera_rays", "closest_rays", "any_rays", "nodes_visited", "leaf_refs", "tri_tests", "bad_samples", "stack_overflows")
+def set_mailbox(mode: int):
+    """-1: per-primitive mailboxes like the reference; 0: none; 4: four-entry per-ray window like the HIP kernels."""
+    lib().oracle_set_mailbox(int(mode))
+
+
+COUNTER_NAMES = ("camera_rays", "closest_rays", "any_rays", "nodes_visited", "leaf_refs", "tri_tests", "bad_samples", "tri_tests_closest")
 
 
 def render(parsed, nodes=None, leaf_refs=None, bounds=None, premultiply=None, info=None):

@@ -23,6 +23,9 @@
 #ifndef RT_BLOCK
 #define RT_BLOCK 256
 #endif
+#ifndef RT_MAILBOX
+#define RT_MAILBOX 1
+#endif
 
 namespace rt {
 
@@ -39,6 +42,10 @@ struct Trav {
     // leaf / voxel primitive-list cursor for the lock-step ("while-while") traversal: at_leaf => test prims [li, ln)
     unsigned li, ln_, ly;
     bool at_leaf;
+#if RT_MAILBOX
+    unsigned mb0, mb1, mb2, mb3;   // the last four primitives tested for this ray (the reference mailboxes every primitive,
+                                   // kdtree.cpp:373-374; a short per-lane window removes most repeat tests of straddling triangles)
+#endif
     // grid 3D-DDA cursor (grid.cpp:238-260): voxel position and the ray parameter of the next crossing per axis
     int gpos[3];
     float gnext[3];
@@ -81,6 +88,9 @@ RT_DEV bool tri_test(V3 p1, V3 p2, V3 p3, V3 o, V3 d, float mint, float maxt, fl
 RT_DEV void trav_begin(Trav &tv, const DevScene &sc, const Ray &r, bool any) {
     tv.o = r.o; tv.d = r.d; tv.mint = r.mint; tv.maxt = r.maxt; tv.any = any;
     tv.hit_prim = -1; tv.b1 = 0.f; tv.b2 = 0.f; tv.sp = 0; tv.node = 0; tv.at_leaf = false; tv.li = tv.ln_ = tv.ly = 0;
+#if RT_MAILBOX
+    tv.mb0 = tv.mb1 = tv.mb2 = tv.mb3 = 0xffffffffu;
+#endif
     float t0 = r.mint, t1 = r.maxt;
     bool ok = true;
 #pragma unroll
@@ -129,7 +139,12 @@ RT_DEV void trav_step(Trav &tv, const DevScene &sc, uint2 *lds_stack, uint2 *spi
     const unsigned np = nd.x >> 2;
     for (unsigned i = 0; i < np; ++i) {
         const unsigned prim = (np == 1) ? nd.y : sc.leaf_refs[nd.y + i];
-        if (COUNT) { ++cnt.tris; if (np > 1) ++cnt.leaf_refs; }
+        if (COUNT && np > 1) ++cnt.leaf_refs;
+#if RT_MAILBOX
+        if (prim == tv.mb0 || prim == tv.mb1 || prim == tv.mb2 || prim == tv.mb3) continue;
+        tv.mb3 = tv.mb2; tv.mb2 = tv.mb1; tv.mb1 = tv.mb0; tv.mb0 = prim;
+#endif
+        if (COUNT) ++cnt.tris;
         V3 p1, p2, p3; unsigned bits; int light;
         tri_verts(sc.tris, prim, p1, p2, p3, bits, light);
         float t, b1, b2;
@@ -155,6 +170,9 @@ RT_DEV int arr3i(const int *a, int i) { return i == 0 ? a[0] : (i == 1 ? a[1] : 
 RT_DEV void grid_begin(Trav &tv, const DevScene &sc, const Ray &r, bool any) {
     tv.o = r.o; tv.d = r.d; tv.mint = r.mint; tv.maxt = r.maxt; tv.any = any;
     tv.hit_prim = -1; tv.b1 = 0.f; tv.b2 = 0.f; tv.sp = 0; tv.node = 0; tv.at_leaf = false; tv.li = tv.ln_ = tv.ly = 0;
+#if RT_MAILBOX
+    tv.mb0 = tv.mb1 = tv.mb2 = tv.mb3 = 0xffffffffu;
+#endif
     tv.inv = mk3(0.f); tv.tmin = tv.tmax = 0.f;
     float rayT;
     const V3 pm = r.o + r.d * r.mint;                                        // bounds.Inside(ray(ray.mint))
@@ -196,7 +214,12 @@ RT_DEV void grid_step(Trav &tv, const DevScene &sc, TravCounters &cnt) {
     if (COUNT) ++cnt.nodes;
     for (unsigned i = 0; i < vx.y; ++i) {
         const unsigned prim = sc.leaf_refs[vx.x + i];
-        if (COUNT) { ++cnt.tris; ++cnt.leaf_refs; }
+        if (COUNT) ++cnt.leaf_refs;
+#if RT_MAILBOX
+        if (prim == tv.mb0 || prim == tv.mb1 || prim == tv.mb2 || prim == tv.mb3) continue;
+        tv.mb3 = tv.mb2; tv.mb2 = tv.mb1; tv.mb1 = tv.mb0; tv.mb0 = prim;
+#endif
+        if (COUNT) ++cnt.tris;
         V3 p1, p2, p3; unsigned bits; int light;
         tri_verts(sc.tris, prim, p1, p2, p3, bits, light);
         float t, b1, b2;
@@ -255,7 +278,12 @@ RT_DEV void leaf_test_one(Trav &tv, const DevScene &sc, TravCounters &cnt) {
     const bool single = !GRID && tv.ln_ == 1;
     const unsigned prim = single ? tv.ly : sc.leaf_refs[tv.ly + tv.li];
     ++tv.li;
-    if (COUNT) { ++cnt.tris; if (!single) ++cnt.leaf_refs; }
+    if (COUNT && !single) ++cnt.leaf_refs;
+#if RT_MAILBOX
+    if (prim == tv.mb0 || prim == tv.mb1 || prim == tv.mb2 || prim == tv.mb3) return;   // already tested for this ray: same t, same outcome
+    tv.mb3 = tv.mb2; tv.mb2 = tv.mb1; tv.mb1 = tv.mb0; tv.mb0 = prim;
+#endif
+    if (COUNT) ++cnt.tris;
     V3 p1, p2, p3; unsigned bits; int light;
     tri_verts(sc.tris, prim, p1, p2, p3, bits, light);
     float t, b1, b2;

@@ -59,6 +59,40 @@ def test_kdtree_shape_matches_reference_statistics(pkg, name):
     assert len(refs) == int(nprims[nprims > 1].sum())
 
 
+@pytest.mark.parametrize("name", ["whitted_point", "whitted_area", "path_soup2k", "direct_soup5k_seed7", "whitted_glass_mirror"])
+def test_triangle_test_count_matches_reference_statistic(pkg, oracle, name):
+    """With one mailbox per primitive (kdtree.cpp:371-374) the restatement performs exactly the number of
+    Triangle::Intersect(P) calls the reference reports ("Triangle Ray Intersections  hits:tests", trianglemesh.cpp:217-220)
+    -- this pins the traversal ORDER and termination rules, not just the hits.  Emitter-pdf tests (Shape::Pdf ->
+    Triangle::Intersect, shape.h:96-107) are part of the reference's statistic and are added back here."""
+    g = load_golden(name)
+    ps = pkg.ParsedScene(text=g["scene"])
+    nodes, refs, bounds, info = ps.kdtree()
+    try:
+        oracle.set_mailbox(-1)
+        _, _, _, full = oracle.render(ps, nodes, refs, bounds, info=info)
+        oracle.set_mailbox(4)
+        _, _, _, win = oracle.render(ps, nodes, refs, bounds, info=info)
+        oracle.set_mailbox(0)
+        _, _, _, none = oracle.render(ps, nodes, refs, bounds, info=info)
+    finally:
+        oracle.set_mailbox(4)
+    assert full["tri_tests"] <= win["tri_tests"] <= none["tri_tests"]
+    assert full["nodes_visited"] == win["nodes_visited"] == none["nodes_visited"]
+    # the reference registers two StatsPercentage objects under one name (Triangle::Intersect and ::IntersectP,
+    # trianglemesh.cpp:215-220,281-286); the printed one is Intersect's: tests and hits of closest-hit rays, including
+    # the emitter-pdf calls of Shape::Pdf (shape.h:96-107), which the accelerator counters here do not include
+    hits, tests = g["stats"]["stats"]["Triangle Ray Intersections"].split(":")
+    ref_tests, exact = stat_int(tests)
+    mine = full["tri_tests_closest"]
+    if name == "whitted_point":                 # no emitter: the statistic is the accelerator's work alone -> exact
+        assert exact and mine == ref_tests, (mine, tests)
+    elif name == "whitted_area":                # + one Shape::Pdf per shaded point over the emitter's 2 triangles -> exact
+        assert exact and mine + 2 * int(g["stats"]["stats"]["Number of points shaded"]) == ref_tests, (mine, tests)
+    else:
+        assert 0.5 * ref_tests <= mine <= ref_tests * 1.0005 + 1, (mine, tests)
+
+
 def test_oracle_bruteforce_equals_kdtree(pkg, oracle):
     """Closest-hit results do not depend on the accelerator: the accelerator-free mode renders the same film."""
     g = load_golden("whitted_glass_mirror")

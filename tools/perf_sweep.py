@@ -24,6 +24,14 @@ def run(tag, defs=(), env=None, workload="c2", steps=2, extra=()):
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "a"
+    if which == "g":
+        for wl in ("c2", "p100000"):
+            run("mailbox_" + wl, workload=wl)
+            run("nomailbox_" + wl, ["-DRT_MAILBOX=0"], workload=wl)
+            run("w4_lds16_" + wl, ["-DRT_MIN_WAVES=4", "-DRT_STACK_LDS=16"], workload=wl)
+            run("w3_lds16_" + wl, ["-DRT_STACK_LDS=16"], workload=wl)
+            run("w5_lds12_" + wl, ["-DRT_MIN_WAVES=5", "-DRT_STACK_LDS=12"], workload=wl)
+        return
     if which == "f":
         run("auto_c2")
         run("auto_c3_100k", workload="c3_100000")
