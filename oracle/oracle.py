@@ -32,7 +32,7 @@ def lib():
 
 
 def set_mailbox(mode: int):
-    """-1: per-primitive mailboxes like the reference; 0: none; 4: four-entry per-ray window like the HIP kernels."""
+    """-1: per-primitive mailboxes like the reference; 0: none (default, like the HIP kernels); 4: four-entry window."""
     lib().oracle_set_mailbox(int(mode))
 
 

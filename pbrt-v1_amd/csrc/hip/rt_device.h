@@ -80,4 +80,20 @@ struct DevFrame {
     unsigned n_threads;
 };
 
+// Explicit address spaces.  Pointers that live inside DevScene/DevFrame are loaded from memory, so the compiler cannot
+// infer where they point and emits FLAT loads (which tie up both the vector-memory and the LDS counters); every hot
+// dereference therefore goes through one of these: global_load_* for HBM data, ds_* for the traversal stack.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_G __attribute__((address_space(1)))
+#define RT_L __attribute__((address_space(3)))
+#else
+#define RT_G
+#define RT_L
+#endif
+typedef const DevMaterial RT_G &MatRef;
+typedef const DevLight RT_G &LightRef;
+#define RT_MAT(sc, i) (*((const DevMaterial RT_G *)(sc).materials + (i)))
+#define RT_LIGHT(sc, i) (*((const DevLight RT_G *)(sc).lights + (i)))
+#define RT_GPTR(T, p) ((T RT_G *)(p))
+
 }  // namespace rt

@@ -135,7 +135,7 @@ RT_DEV void sample_write(const DevFrame &fr, const Lane &ln, V3 Ls, float alpha,
     if (Ls.x != Ls.x || Ls.y != Ls.y || Ls.z != Ls.z) { Ls = mk3(0.f); ++bad; }
     else if (y < -1e-5) { Ls = mk3(0.f); ++bad; }
     else if (isinf(y)) { Ls = mk3(0.f); ++bad; }
-    float4 *rec = fr.samples + size_t(ln.work) * 2;
+    float4 RT_G *rec = RT_GPTR(float4, fr.samples) + size_t(ln.work) * 2;
     rec[0] = make_float4(Ls.x, Ls.y, Ls.z, alpha);
     rec[1] = make_float4(ln.image_x, ln.image_y, 0.f, 0.f);
 }
@@ -240,11 +240,11 @@ RT_DEV void setup_sample(const DevScene &sc, const DevFrame &fr, Lane &ln, unsig
 }
 
 // ---- recursion frames (whitted / directlighting) ---------------------------------------------------------
-RT_DEV float *frame_ptr(const DevFrame &fr, int frame, unsigned gtid) {
-    return fr.frames + (size_t(frame) * RT_FRAME_WORDS) * fr.n_threads + gtid;
+RT_DEV float RT_G *frame_ptr(const DevFrame &fr, int frame, unsigned gtid) {
+    return RT_GPTR(float, fr.frames) + (size_t(frame) * RT_FRAME_WORDS) * fr.n_threads + gtid;
 }
 RT_DEV void frame_push(const DevFrame &fr, Lane &ln, unsigned gtid, V3 f, float absdot, int after) {
-    float *q = frame_ptr(fr, ln.fsp, gtid); const size_t st = fr.n_threads;
+    float RT_G *q = frame_ptr(fr, ln.fsp, gtid); const size_t st = fr.n_threads;
     q[0 * st] = ln.L.x; q[1 * st] = ln.L.y; q[2 * st] = ln.L.z;
     q[3 * st] = f.x; q[4 * st] = f.y; q[5 * st] = f.z; q[6 * st] = absdot;
     q[7 * st] = __int_as_float(after); q[8 * st] = __int_as_float(ln.depth);
@@ -257,7 +257,7 @@ RT_DEV void frame_push(const DevFrame &fr, Lane &ln, unsigned gtid, V3 f, float 
 }
 RT_DEV int frame_pop(const DevFrame &fr, Lane &ln, unsigned gtid, V3 child) {
     --ln.fsp;
-    const float *q = frame_ptr(fr, ln.fsp, gtid); const size_t st = fr.n_threads;
+    const float RT_G *q = frame_ptr(fr, ln.fsp, gtid); const size_t st = fr.n_threads;
     V3 Lp = mk3(q[0 * st], q[1 * st], q[2 * st]);
     V3 f = mk3(q[3 * st], q[4 * st], q[5 * st]);
     float absdot = q[6 * st];
@@ -285,13 +285,13 @@ RT_DEV void launch_ray(Lane &ln, const DevScene &sc, V3 o, V3 d, float mint, flo
 //   vol_rays [level][8][thread]   the ray of the Scene::Li invocation at recursion level `fsp` (o, d, mint, maxt)
 //   vol_state[13][thread]         suspended ray-march state of SingleScattering::Li while a shadow ray is traced
 //   vol_samp [3*Nmax][thread]     its LatinHypercube(samp, N, 3) table (single.cpp:76-77)
-RT_DEV float *vol_ray_ptr(const DevFrame &fr, int level, unsigned gtid) { return fr.vol_rays + size_t(level) * 8 * fr.n_threads + gtid; }
+RT_DEV float RT_G *vol_ray_ptr(const DevFrame &fr, int level, unsigned gtid) { return RT_GPTR(float, fr.vol_rays) + size_t(level) * 8 * fr.n_threads + gtid; }
 RT_DEV void vol_store_ray(const DevFrame &fr, int level, unsigned gtid, const Ray &r) {
-    float *q = vol_ray_ptr(fr, level, gtid); const size_t st = fr.n_threads;
+    float RT_G *q = vol_ray_ptr(fr, level, gtid); const size_t st = fr.n_threads;
     q[0] = r.o.x; q[st] = r.o.y; q[2 * st] = r.o.z; q[3 * st] = r.d.x; q[4 * st] = r.d.y; q[5 * st] = r.d.z; q[6 * st] = r.mint; q[7 * st] = r.maxt;
 }
 RT_DEV Ray vol_load_ray(const DevFrame &fr, int level, unsigned gtid) {
-    const float *q = vol_ray_ptr(fr, level, gtid); const size_t st = fr.n_threads;
+    const float RT_G *q = vol_ray_ptr(fr, level, gtid); const size_t st = fr.n_threads;
     Ray r; r.o = mk3(q[0], q[st], q[2 * st]); r.d = mk3(q[3 * st], q[4 * st], q[5 * st]); r.mint = q[6 * st]; r.maxt = q[7 * st];
     return r;
 }
@@ -332,10 +332,10 @@ RT_DEV V3 scene_transmittance(const DevScene &sc, Lane &ln, V3 o, V3 d, float mi
 // ---- EstimateDirect (core/transport.cpp:123-194), split at its two ray casts ------------------------------
 // BSDF-sampling half; returns with either a MIS ray in flight (ST_MIS_DONE) or ST_ED_DONE.
 RT_DEV void estimate_direct_bsdf(const DevScene &sc, Lane &ln) {
-    const DevLight &Lt = sc.lights[ln.cur_light];
+    LightRef Lt = RT_LIGHT(sc, ln.cur_light);
     ln.stage = ST_ED_DONE;
     if (Lt.type == RT_LIGHT_POINT) return;                                      // IsDeltaLight()
-    const DevMaterial &m = sc.materials[ln.v.mat];
+    MatRef m = RT_MAT(sc, ln.v.mat);
     V3 wi; float bsdfPdf; int sampled;
     V3 f = bsdf_sample_f(m, ln.v, ln.v.wo, wi, ln.bs1, ln.bs2, ln.bcs, bsdfPdf, BX_ALL & ~BX_SPECULAR, sampled);
     if (!is_black(f) && bsdfPdf > 0.f) {
@@ -354,8 +354,8 @@ RT_DEV void estimate_direct_bsdf(const DevScene &sc, Lane &ln) {
 RT_DEV void estimate_direct_begin(const DevScene &sc, Lane &ln, int light, float ls1, float ls2) {
     ln.cur_light = light;
     ln.Ld = mk3(0.f);
-    const DevLight &Lt = sc.lights[light];
-    const DevMaterial &m = sc.materials[ln.v.mat];
+    LightRef Lt = RT_LIGHT(sc, light);
+    MatRef m = RT_MAT(sc, ln.v.mat);
     V3 wi, Li, pseg; float lightPdf;
     if (Lt.type == RT_LIGHT_POINT) {                                            // point.cpp:55-66
         V3 lp = mat_color(Lt.pos);
@@ -406,7 +406,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
             if (ln.depth == 0) { ln.alpha = 1.f; if (VOL) vol_ray_ptr(fr, 0, gtid)[7 * size_t(fr.n_threads)] = ln.tv.maxt; }   // r.maxt = ray.maxt
             else if (VOL) ln.thr = ln.thr * scene_transmittance<VOL>(sc, ln, ln.tv.o, ln.tv.d, ln.tv.mint, ln.tv.maxt);           // path.cpp:89
             if ((ln.depth == 0 || ln.specular) && ln.v.light >= 0)              // path.cpp:91-92
-                ln.L = ln.L + ln.thr * area_L(sc.lights[ln.v.light], ln.v.nn, ln.v.wo);
+                ln.L = ln.L + ln.thr * area_L(RT_LIGHT(sc, ln.v.light), ln.v.nn, ln.v.wo);
         } else {
             if (!hit) {                                                         // whitted.cpp:52-59
                 ln.L = mk3(0.f);
@@ -417,7 +417,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
             if (ln.depth == 0) ln.alpha = 1.f;
             if (VOL) vol_ray_ptr(fr, ln.fsp, gtid)[7 * size_t(fr.n_threads)] = ln.tv.maxt;       // the hit shortens this level's ray
             ln.L = mk3(0.f);
-            if (ln.v.light >= 0) ln.L = ln.L + area_L(sc.lights[ln.v.light], ln.v.nn, ln.v.wo);
+            if (ln.v.light >= 0) ln.L = ln.L + area_L(RT_LIGHT(sc, ln.v.light), ln.v.nn, ln.v.wo);
         }
         ln.li = 0; ln.lj = 0; ln.L_all = mk3(0.f); ln.Ld_light = mk3(0.f);
         ln.stage = ST_DIRECT_NEXT;
@@ -462,8 +462,8 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
         // Whitted: one sample per light, unweighted (whitted.cpp:73-81)
         if (ln.li >= nLights) { ln.stage = ST_SPECULAR; return; }
         {
-            const DevLight &Lt = sc.lights[ln.li];
-            const DevMaterial &m = sc.materials[ln.v.mat];
+            LightRef Lt = RT_LIGHT(sc, ln.li);
+            MatRef m = RT_MAT(sc, ln.v.mat);
             const int cur = ln.li++;
             V3 wi, Li, pseg;
             if (Lt.type == RT_LIGHT_POINT) {                                    // point.cpp:55-60
@@ -540,7 +540,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
         return;
     }
     if constexpr (STAGE == ST_BOUNCE) {                                                           // path.cpp:111-143
-        const DevMaterial &m = sc.materials[ln.v.mat];
+        MatRef m = RT_MAT(sc, ln.v.mat);
         const int k = ln.depth;
         float bs1, bs2, bcs;
         if (k < 3) {
@@ -563,7 +563,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
     }
     if constexpr (STAGE == ST_SPECULAR) {                                                         // whitted.cpp:82-109
         if (!(ln.depth < fr.max_depth)) { ln.stage = ST_RETURN; return; }       // rayDepth++ < maxDepth
-        const DevMaterial &m = sc.materials[ln.v.mat];
+        MatRef m = RT_MAT(sc, ln.v.mat);
         float u3 = ln.rng.next_float(), u2 = ln.rng.next_float(), u1 = ln.rng.next_float();
         V3 wi; float pdf; int flags;
         V3 f = bsdf_sample_f(m, ln.v, ln.v.wo, wi, u1, u2, u3, pdf, BX_REFLECTION | BX_SPECULAR, flags);
@@ -580,7 +580,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
         return;
     }
     if constexpr (STAGE == ST_SPEC_TRANS) {                                                       // whitted.cpp:110-135
-        const DevMaterial &m = sc.materials[ln.v.mat];
+        MatRef m = RT_MAT(sc, ln.v.mat);
         float u3 = ln.rng.next_float(), u2 = ln.rng.next_float(), u1 = ln.rng.next_float();
         V3 wi; float pdf; int flags;
         V3 f = bsdf_sample_f(m, ln.v, ln.v.wo, wi, u1, u2, u3, pdf, BX_TRANSMISSION | BX_SPECULAR, flags);
@@ -607,8 +607,8 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
         const Ray ray = vol_load_ray(fr, ln.fsp, gtid);
         const bool single = fr.volume_integrator == RT_VOLUME_SINGLE;
         const size_t st = fr.n_threads;
-        float *vs = fr.vol_state + gtid;
-        float *samp = fr.vol_samp + gtid;
+        float RT_G *vs = RT_GPTR(float, fr.vol_state) + gtid;
+        float RT_G *samp = RT_GPTR(float, fr.vol_samp) + gtid;
         int i, N; float t0, step; V3 Tr, p, Lv;
         const V3 w = -ray.d;
         bool marching = true;
@@ -655,7 +655,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
                 if (!is_black(ss) && nLights > 0) {
                     const int lightNum = min(int(floorf(samp[size_t(3 * i) * st] * nLights)), nLights - 1);
                     const float u1 = samp[size_t(3 * i + 1) * st], u2 = samp[size_t(3 * i + 2) * st];
-                    const DevLight &Lt = sc.lights[lightNum];
+                    LightRef Lt = RT_LIGHT(sc, lightNum);
                     V3 wo, L, pseg; float pdf;
                     if (Lt.type == RT_LIGHT_POINT) {
                         V3 lp = mat_color(Lt.pos); wo = normalize3(lp - p); pdf = 1.f;

@@ -85,9 +85,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void render_kernel(const De
             const unsigned long long am = __ballot(act);
             if (!am) break;
             if (fr.exit_thresh > 0 && __popcll(am) <= fr.exit_thresh && __any(!act && ln.stage != ST_EXIT)) break;
-            if (fr.trav_mode == 1) accel_round<COUNT, ACCEL>(ln.tv, ln.has_ray, sc, lds_stack, fr.spill, fr.n_threads, gtid, tc);
-            else if (fr.trav_mode == 2) accel_round_batched<COUNT, ACCEL>(ln.tv, ln.has_ray, sc, lds_stack, fr.spill, fr.n_threads, gtid, tc);
-            else if (act) accel_step<COUNT, ACCEL>(ln.tv, sc, lds_stack, fr.spill, fr.n_threads, gtid, tc);
+            if (fr.trav_mode == 1) accel_round<COUNT, ACCEL>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc);
+            else if (fr.trav_mode == 2) accel_round_batched<COUNT, ACCEL>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc);
+            else if (act) accel_step<COUNT, ACCEL>(ln.tv, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc);
         }
         if (ln.has_ray && !ln.tv.active) ln.has_ray = false;
     }
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void film_gather_kernel(const DevFrame *__rest
                 const unsigned long long tile = pixel / fr.tile_pixels;
                 const bool mine = int(tile % fr.shard_count) == fr.shard_index;
                 if (k == 0) owned[c] = mine ? 1 : 0;
-                if (mine) lds_rec[c * col_stride + k] = fr.samples[((tile / fr.shard_count) * per_tile + (pixel % fr.tile_pixels) * fr.spp) * 2 + k];
+                if (mine) lds_rec[c * col_stride + k] = RT_GPTR(const float4, fr.samples)[((tile / fr.shard_count) * per_tile + (pixel % fr.tile_pixels) * fr.spp) * 2 + k];
             }
             __syncthreads();
             if (!live || sy < sy0 || sy > sy1) continue;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void film_gather_kernel(const DevFrame *__rest
                     if (x < x0 || x > x1 || y < y0 || y > y1) continue;
                     const float fx = fabsf((x - dImageX) * fr.inv_fxw * 16), fy = fabsf((y - dImageY) * fr.inv_fyw * 16);
                     const int ifx = min(int(floorf(fx)), 15), ify = min(int(floorf(fy)), 15);
-                    const float wt = fr.filter_table[ify * 16 + ifx];
+                    const float wt = RT_GPTR(const float, fr.filter_table)[ify * 16 + ifx];
                     const float4 L = rec[0];
                     a0 += wt * L.x; a1 += wt * L.y; a2 += wt * L.z;       // Spectrum::AddWeighted color.h:116-120
                     a3 += L.w * wt; a4 += wt;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(RT_BLOCK) void trace_kernel(DevScene sc, const RtRa
         r.mint = rays[i].mint; r.maxt = rays[i].maxt;
         Trav tv;
         if (sc.accel_kind == RT_ACCEL_GRID) { grid_begin(tv, sc, r, any != 0); while (tv.active) grid_step<true>(tv, sc, tc); }
-        else { trav_begin(tv, sc, r, any != 0); while (tv.active) trav_step<true>(tv, sc, lds_stack, spill, n_threads, gtid, tc); }
+        else { trav_begin(tv, sc, r, any != 0); while (tv.active) trav_step<true>(tv, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, spill), n_threads, gtid, tc); }
         if (any) occ[i] = tv.hit_prim >= 0 ? 1 : 0;
         else { hits[i].prim = tv.hit_prim; hits[i].t = tv.hit_prim >= 0 ? tv.maxt : 0.f; hits[i].b1 = tv.b1; hits[i].b2 = tv.b2; }
     }

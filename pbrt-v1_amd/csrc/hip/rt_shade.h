@@ -61,10 +61,10 @@ RT_DEV float sin_theta2(V3 w) { return fmaxf(0.f, 1.f - w.z * w.z); }
 RT_DEV float cos_phi(V3 w) { float s = sin_theta(w); if (s == 0.f) return 1.f; return clampf(w.x / s, -1.f, 1.f); }
 RT_DEV float sin_phi(V3 w) { float s = sin_theta(w); if (s == 0.f) return 0.f; return clampf(w.y / s, -1.f, 1.f); }
 
-RT_DEV V3 mat_color(const float *c) { return mk3(c[0], c[1], c[2]); }
+template <class P> RT_DEV V3 mat_color(P c) { return mk3(c[0], c[1], c[2]); }
 
 // Lambertian::f reflection.cpp:128-131 / OrenNayar::f :132-156
-RT_DEV V3 diffuse_f(const DevMaterial &m, V3 wo, V3 wi) {
+RT_DEV V3 diffuse_f(MatRef m, V3 wo, V3 wi) {
     V3 R = mat_color(m.r);
     if (m.on_b < 0.f) return R * RT_INV_PI;
     float sinthetai = sin_theta(wi), sinthetao = sin_theta(wo);
@@ -114,7 +114,7 @@ RT_DEV void concentric_disk(float u1, float u2, float &dx, float &dy) {
     dy = r * sinf(theta);
 }
 
-RT_DEV int bsdf_num_components(const DevMaterial &m, int flags) {
+RT_DEV int bsdf_num_components(MatRef m, int flags) {
     int n = 0;
     if (m.type == RT_MAT_MATTE) { if (((BX_REFLECTION | BX_DIFFUSE) & flags) == (BX_REFLECTION | BX_DIFFUSE)) ++n; }
     else {
@@ -123,10 +123,10 @@ RT_DEV int bsdf_num_components(const DevMaterial &m, int flags) {
     }
     return n;
 }
-RT_DEV int bsdf_total_components(const DevMaterial &m) { return bsdf_num_components(m, BX_ALL); }
+RT_DEV int bsdf_total_components(MatRef m) { return bsdf_num_components(m, BX_ALL); }
 
 // BSDF::f reflection.cpp:480-494 (flags = BSDF_ALL): only the diffuse lobe has a non-zero f
-RT_DEV V3 bsdf_f(const DevMaterial &m, const Vertex &v, V3 woW, V3 wiW) {
+RT_DEV V3 bsdf_f(MatRef m, const Vertex &v, V3 woW, V3 wiW) {
     if (m.type != RT_MAT_MATTE) return mk3(0.f);
     V3 wi = to_local(v, wiW), wo = to_local(v, woW);
     if (dot3(wiW, v.nn) * dot3(woW, v.nn) > 0) return mk3(0.f) + diffuse_f(m, wo, wi);   // BRDFs only
@@ -134,7 +134,7 @@ RT_DEV V3 bsdf_f(const DevMaterial &m, const Vertex &v, V3 woW, V3 wiW) {
 }
 
 // BSDF::Pdf reflection.cpp:458-470 (flags = BSDF_ALL)
-RT_DEV float bsdf_pdf(const DevMaterial &m, const Vertex &v, V3 woW, V3 wiW) {
+RT_DEV float bsdf_pdf(MatRef m, const Vertex &v, V3 woW, V3 wiW) {
     int nc = bsdf_total_components(m);
     if (nc == 0) return 0.f;
     if (m.type != RT_MAT_MATTE) return 0.f / float(nc);
@@ -145,7 +145,7 @@ RT_DEV float bsdf_pdf(const DevMaterial &m, const Vertex &v, V3 woW, V3 wiW) {
 }
 
 // BSDF::Sample_f reflection.cpp:402-457.  Returns f; pdf == 0 means "no sample".
-RT_DEV V3 bsdf_sample_f(const DevMaterial &m, const Vertex &v, V3 woW, V3 &wiW, float u1, float u2, float u3,
+RT_DEV V3 bsdf_sample_f(MatRef m, const Vertex &v, V3 woW, V3 &wiW, float u1, float u2, float u3,
                         float &pdf, int flags, int &sampled) {
     sampled = 0; pdf = 0.f;
     int matching = bsdf_num_components(m, flags);
@@ -200,13 +200,13 @@ RT_DEV V3 bsdf_sample_f(const DevMaterial &m, const Vertex &v, V3 woW, V3 &wiW, 
 
 // ---- lights ------------------------------------------------------------------------------
 RT_DEV void light_tri(const DevScene &sc, unsigned k, V3 &p1, V3 &p2, V3 &p3) {
-    const float *t = sc.light_tris + size_t(k) * 12;
+    const float RT_G *t = RT_GPTR(const float, sc.light_tris) + size_t(k) * 12;
     p1 = mk3(t[0], t[1], t[2]); p2 = mk3(t[3], t[4], t[5]); p3 = mk3(t[6], t[7], t[8]);
 }
 
 // Shape::Pdf(p, wi) shape.h:96-107 evaluated on the emitter's own triangles:
 // ShapeSet::Intersect (shape.h:150-156) keeps the LAST triangle hit, the ray's maxt is never shortened.
-RT_DEV float area_light_pdf(const DevScene &sc, const DevLight &L, V3 p, V3 wi) {
+RT_DEV float area_light_pdf(const DevScene &sc, LightRef L, V3 p, V3 wi) {
     bool any = false; float thit = 0.f; V3 nl = mk3(0.f);
     for (unsigned k = 0; k < L.n_tris; ++k) {
         V3 p1, p2, p3; light_tri(sc, L.first_tri + k, p1, p2, p3);
@@ -226,17 +226,17 @@ RT_DEV float area_light_pdf(const DevScene &sc, const DevLight &L, V3 p, V3 wi) 
 }
 
 // AreaLight::L light.h:93-96
-RT_DEV V3 area_L(const DevLight &L, V3 n, V3 w) { return dot3(n, w) > 0 ? mat_color(L.color) : mk3(0.f); }
+RT_DEV V3 area_L(LightRef L, V3 n, V3 w) { return dot3(n, w) > 0 ? mat_color(L.color) : mk3(0.f); }
 
 // shape->Sample(p,u1,u2,&ns): ShapeSet::Sample shape.h:115-121 (one extra RandomFloat when the emitter has
 // more than one triangle) + Triangle::Sample trianglemesh.cpp:336-349 + UniformSampleTriangle mc.cpp:136-141
 template <class RNG>
-RT_DEV V3 area_sample_point(const DevScene &sc, const DevLight &L, float u1, float u2, RNG &rng, V3 &ns) {
+RT_DEV V3 area_sample_point(const DevScene &sc, LightRef L, float u1, float u2, RNG &rng, V3 &ns) {
     unsigned k = 0;
     if (L.n_tris > 1) {
         float ls = rng.next_float();
         for (k = 0; k < L.n_tris - 1; ++k)
-            if (ls < sc.light_tris[size_t(L.first_tri + k) * 12 + 10]) break;
+            if (ls < RT_GPTR(const float, sc.light_tris)[size_t(L.first_tri + k) * 12 + 10]) break;
     }
     V3 p1, p2, p3; light_tri(sc, L.first_tri + k, p1, p2, p3);
     float su1 = sqrtf(u1);

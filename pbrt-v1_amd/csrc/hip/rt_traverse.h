@@ -23,8 +23,10 @@
 #ifndef RT_BLOCK
 #define RT_BLOCK 256
 #endif
+// Per-lane 4-entry mailbox window: measured SLOWER on MI355X (C2 92.9 vs 87.8 ms, 100k-soup path 169 vs 165 ms): the
+// four compares + rotates per candidate cost more VALU than the avoided re-tests save.  Kept as a compile-time knob.
 #ifndef RT_MAILBOX
-#define RT_MAILBOX 1
+#define RT_MAILBOX 0
 #endif
 
 namespace rt {
@@ -59,7 +61,8 @@ struct Trav {
 struct TravCounters { unsigned nodes, leaf_refs, tris, spills; };
 
 RT_DEV void tri_verts(const DevTri *tris, unsigned prim, V3 &p1, V3 &p2, V3 &p3, unsigned &bits, int &light) {
-    const float4 q0 = tris[prim].q0, q1 = tris[prim].q1, q2 = tris[prim].q2;
+    const DevTri RT_G *gt = RT_GPTR(const DevTri, tris) + prim;
+    const float4 q0 = gt->q0, q1 = gt->q1, q2 = gt->q2;
     p1 = mk3(q0.x, q0.y, q0.z); p2 = mk3(q0.w, q1.x, q1.y); p3 = mk3(q1.z, q1.w, q2.x);
     bits = __float_as_uint(q2.y); light = __float_as_int(q2.z);
 }
@@ -110,10 +113,10 @@ RT_DEV void trav_begin(Trav &tv, const DevScene &sc, const Ray &r, bool any) {
 
 // one node visit
 template <bool COUNT>
-RT_DEV void trav_step(Trav &tv, const DevScene &sc, uint2 *lds_stack, uint2 *spill, unsigned n_threads,
+RT_DEV void trav_step(Trav &tv, const DevScene &sc, uint2 RT_L *lds_stack, uint2 RT_G *spill, unsigned n_threads,
                       unsigned gtid, TravCounters &cnt) {
     if (!tv.any && tv.maxt < tv.tmin) { tv.active = false; return; }      // kdtree.cpp:330
-    const uint2 nd = sc.nodes[tv.node];
+    const uint2 nd = RT_GPTR(const uint2, sc.nodes)[tv.node];
     if (COUNT) ++cnt.nodes;
     if ((nd.x & 3u) != 3u) {
         const int axis = int(nd.x & 3u);
@@ -138,7 +141,7 @@ RT_DEV void trav_step(Trav &tv, const DevScene &sc, uint2 *lds_stack, uint2 *spi
     // leaf
     const unsigned np = nd.x >> 2;
     for (unsigned i = 0; i < np; ++i) {
-        const unsigned prim = (np == 1) ? nd.y : sc.leaf_refs[nd.y + i];
+        const unsigned prim = (np == 1) ? nd.y : RT_GPTR(const unsigned, sc.leaf_refs)[nd.y + i];
         if (COUNT && np > 1) ++cnt.leaf_refs;
 #if RT_MAILBOX
         if (prim == tv.mb0 || prim == tv.mb1 || prim == tv.mb2 || prim == tv.mb3) continue;
@@ -155,8 +158,11 @@ RT_DEV void trav_step(Trav &tv, const DevScene &sc, uint2 *lds_stack, uint2 *spi
     }
     if (tv.sp > 0) {
         --tv.sp;
-        const uint2 e = (tv.sp < RT_STACK_LDS) ? lds_stack[tv.sp * RT_BLOCK + threadIdx.x]
-                                                : spill[size_t(tv.sp - RT_STACK_LDS) * n_threads + gtid];
+        // always a ds_read_b64; the (rare) spilled entry overrides it -- written this way so that the two loads are
+        // not merged into one FLAT load through a selected generic pointer
+        const volatile uint2 RT_L *slot = (const volatile uint2 RT_L *)lds_stack + (tv.sp < RT_STACK_LDS ? tv.sp : RT_STACK_LDS - 1) * RT_BLOCK + threadIdx.x;
+        uint2 e; e.x = slot->x; e.y = slot->y;         // volatile: keeps the LDS read a ds_read
+        if (tv.sp >= RT_STACK_LDS) e = spill[size_t(tv.sp - RT_STACK_LDS) * n_threads + gtid];
         tv.node = e.x;
         tv.tmin = tv.tmax;
         tv.tmax = __uint_as_float(e.y);
@@ -210,10 +216,10 @@ RT_DEV void grid_begin(Trav &tv, const DevScene &sc, const Ray &r, bool any) {
 // one voxel visit
 template <bool COUNT>
 RT_DEV void grid_step(Trav &tv, const DevScene &sc, TravCounters &cnt) {
-    const uint2 vx = sc.nodes[(size_t(tv.gpos[2]) * sc.nvox[1] + tv.gpos[1]) * sc.nvox[0] + tv.gpos[0]];
+    const uint2 vx = RT_GPTR(const uint2, sc.nodes)[(size_t(tv.gpos[2]) * sc.nvox[1] + tv.gpos[1]) * sc.nvox[0] + tv.gpos[0]];
     if (COUNT) ++cnt.nodes;
     for (unsigned i = 0; i < vx.y; ++i) {
-        const unsigned prim = sc.leaf_refs[vx.x + i];
+        const unsigned prim = RT_GPTR(const unsigned, sc.leaf_refs)[vx.x + i];
         if (COUNT) ++cnt.leaf_refs;
 #if RT_MAILBOX
         if (prim == tv.mb0 || prim == tv.mb1 || prim == tv.mb2 || prim == tv.mb3) continue;
@@ -249,9 +255,9 @@ RT_DEV void grid_step(Trav &tv, const DevScene &sc, TravCounters &cnt) {
 // (cheap) until each sits at a leaf, then the expensive ray-triangle tests run with every lane that has a primitive
 // left -- instead of one lane's 8-triangle leaf serialising against 63 lanes doing 20-instruction plane tests.
 template <bool COUNT>
-RT_DEV void kd_descend(Trav &tv, const DevScene &sc, uint2 *lds_stack, uint2 *spill, unsigned n_threads, unsigned gtid, TravCounters &cnt) {
+RT_DEV void kd_descend(Trav &tv, const DevScene &sc, uint2 RT_L *lds_stack, uint2 RT_G *spill, unsigned n_threads, unsigned gtid, TravCounters &cnt) {
     if (!tv.any && tv.maxt < tv.tmin) { tv.active = false; return; }      // kdtree.cpp:330
-    const uint2 nd = sc.nodes[tv.node];
+    const uint2 nd = RT_GPTR(const uint2, sc.nodes)[tv.node];
     if (COUNT) ++cnt.nodes;
     if ((nd.x & 3u) == 3u) { tv.at_leaf = true; tv.li = 0; tv.ln_ = nd.x >> 2; tv.ly = nd.y; return; }
     const int axis = int(nd.x & 3u);
@@ -276,7 +282,7 @@ RT_DEV void kd_descend(Trav &tv, const DevScene &sc, uint2 *lds_stack, uint2 *sp
 template <bool COUNT, bool GRID>
 RT_DEV void leaf_test_one(Trav &tv, const DevScene &sc, TravCounters &cnt) {
     const bool single = !GRID && tv.ln_ == 1;
-    const unsigned prim = single ? tv.ly : sc.leaf_refs[tv.ly + tv.li];
+    const unsigned prim = single ? tv.ly : RT_GPTR(const unsigned, sc.leaf_refs)[tv.ly + tv.li];
     ++tv.li;
     if (COUNT && !single) ++cnt.leaf_refs;
 #if RT_MAILBOX
@@ -292,18 +298,21 @@ RT_DEV void leaf_test_one(Trav &tv, const DevScene &sc, TravCounters &cnt) {
         tv.maxt = t; tv.hit_prim = int(prim); tv.b1 = b1; tv.b2 = b2;
     }
 }
-RT_DEV void kd_leaf_done(Trav &tv, const uint2 *lds_stack, const uint2 *spill, unsigned n_threads, unsigned gtid) {
+RT_DEV void kd_leaf_done(Trav &tv, const uint2 RT_L *lds_stack, const uint2 RT_G *spill, unsigned n_threads, unsigned gtid) {
     tv.at_leaf = false;
     if (tv.sp > 0) {
         --tv.sp;
-        const uint2 e = (tv.sp < RT_STACK_LDS) ? lds_stack[tv.sp * RT_BLOCK + threadIdx.x]
-                                                : spill[size_t(tv.sp - RT_STACK_LDS) * n_threads + gtid];
+        // always a ds_read_b64; the (rare) spilled entry overrides it -- written this way so that the two loads are
+        // not merged into one FLAT load through a selected generic pointer
+        const volatile uint2 RT_L *slot = (const volatile uint2 RT_L *)lds_stack + (tv.sp < RT_STACK_LDS ? tv.sp : RT_STACK_LDS - 1) * RT_BLOCK + threadIdx.x;
+        uint2 e; e.x = slot->x; e.y = slot->y;         // volatile: keeps the LDS read a ds_read
+        if (tv.sp >= RT_STACK_LDS) e = spill[size_t(tv.sp - RT_STACK_LDS) * n_threads + gtid];
         tv.node = e.x; tv.tmin = tv.tmax; tv.tmax = __uint_as_float(e.y);
     } else tv.active = false;
 }
 template <bool COUNT>
 RT_DEV void grid_enter_voxel(Trav &tv, const DevScene &sc, TravCounters &cnt) {
-    const uint2 vx = sc.nodes[(size_t(tv.gpos[2]) * sc.nvox[1] + tv.gpos[1]) * sc.nvox[0] + tv.gpos[0]];
+    const uint2 vx = RT_GPTR(const uint2, sc.nodes)[(size_t(tv.gpos[2]) * sc.nvox[1] + tv.gpos[1]) * sc.nvox[0] + tv.gpos[0]];
     if (COUNT) ++cnt.nodes;
     tv.at_leaf = true; tv.li = 0; tv.ln_ = vx.y; tv.ly = vx.x;
 }
@@ -325,7 +334,7 @@ RT_DEV void grid_voxel_done(Trav &tv, const DevScene &sc) {               // gri
 
 // One lock-step round for the whole wave: descend -> test -> pop.  `mine` = this lane carries a live traversal.
 template <bool COUNT, int ACCEL>
-RT_DEV void accel_round(Trav &tv, bool mine, const DevScene &sc, uint2 *lds_stack, uint2 *spill, unsigned n_threads,
+RT_DEV void accel_round(Trav &tv, bool mine, const DevScene &sc, uint2 RT_L *lds_stack, uint2 RT_G *spill, unsigned n_threads,
                         unsigned gtid, TravCounters &cnt) {
     if (ACCEL == RT_ACCEL_GRID) {
         if (mine && tv.active && !tv.at_leaf) grid_enter_voxel<COUNT>(tv, sc, cnt);
@@ -348,7 +357,7 @@ RT_DEV void accel_round(Trav &tv, bool mine, const DevScene &sc, uint2 *lds_stac
 #define RT_BATCH_K 16
 #endif
 template <bool COUNT, int ACCEL>
-RT_DEV void accel_round_batched(Trav &tv, bool mine, const DevScene &sc, uint2 *lds_stack, uint2 *spill, unsigned n_threads,
+RT_DEV void accel_round_batched(Trav &tv, bool mine, const DevScene &sc, uint2 RT_L *lds_stack, uint2 RT_G *spill, unsigned n_threads,
                                 unsigned gtid, TravCounters &cnt) {
     const bool act = mine && tv.active;
     const bool desc = act && !tv.at_leaf;
@@ -372,7 +381,7 @@ RT_DEV void accel_begin(Trav &tv, const DevScene &sc, const Ray &r, bool any) {
     if (ACCEL == RT_ACCEL_GRID) grid_begin(tv, sc, r, any); else trav_begin(tv, sc, r, any);
 }
 template <bool COUNT, int ACCEL>
-RT_DEV void accel_step(Trav &tv, const DevScene &sc, uint2 *lds_stack, uint2 *spill, unsigned n_threads, unsigned gtid,
+RT_DEV void accel_step(Trav &tv, const DevScene &sc, uint2 RT_L *lds_stack, uint2 RT_G *spill, unsigned n_threads, unsigned gtid,
                        TravCounters &cnt) {
     if (ACCEL == RT_ACCEL_GRID) grid_step<COUNT>(tv, sc, cnt); else trav_step<COUNT>(tv, sc, lds_stack, spill, n_threads, gtid, cnt);
 }

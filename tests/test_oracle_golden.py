@@ -76,7 +76,7 @@ def test_triangle_test_count_matches_reference_statistic(pkg, oracle, name):
         oracle.set_mailbox(0)
         _, _, _, none = oracle.render(ps, nodes, refs, bounds, info=info)
     finally:
-        oracle.set_mailbox(4)
+        oracle.set_mailbox(0)
     assert full["tri_tests"] <= win["tri_tests"] <= none["tri_tests"]
     assert full["nodes_visited"] == win["nodes_visited"] == none["nodes_visited"]
     # the reference registers two StatsPercentage objects under one name (Triangle::Intersect and ::IntersectP,
