@@ -33,8 +33,11 @@ namespace rt {
 #endif
 // Scene and frame descriptors are read through pointers (uniform addresses -> scalar loads on demand) instead of
 // being passed by value: the by-value form pinned >100 SGPRs and spilled them.
-template <bool COUNT, int INTEG, int ACCEL, bool VOL>
-__global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void render_kernel(const DevScene *__restrict__ scp,
+// MINW = minimum waves per SIMD the register allocator must make room for: 1 = natural allocation (~140 VGPRs, 3 waves/SIMD,
+// best when VALU-bound: tiny cache-resident scenes); 5 = cap at 96 VGPRs (spills to scratch) for 5 waves/SIMD, measured +20 %
+// on the memory-latency-bound 100k..1M-triangle scenes and -15 % on Cornell.
+template <bool COUNT, int INTEG, int ACCEL, bool VOL, int MINW>
+__global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *__restrict__ scp,
                                                                        const DevFrame *__restrict__ frp) {
     __shared__ uint2 lds_stack[RT_STACK_LDS * RT_BLOCK];
     const DevScene &sc = *scp;
@@ -238,12 +241,14 @@ __global__ void camera_kernel(DevScene sc, DevFrame fr, unsigned long long first
 // ------------------------------------------------------------------------------------------ host side
 using namespace rt;
 
-// render_kernel instantiations, index = ((VOL*2 + ACCEL)*2 + COUNT)*3 + INTEG
+// render_kernel instantiations, index = ((VOL*2 + ACCEL)*2 + COUNT)*3 + INTEG; +24..35: the high-occupancy flavour
+// (COUNT = false only), index = 24 + (VOL*2 + ACCEL)*3 + INTEG
 typedef void (*RenderKernelFn)(const DevScene *, const DevFrame *);
-#define RT_K3(C, A, V) render_kernel<C, 0, A, V>, render_kernel<C, 1, A, V>, render_kernel<C, 2, A, V>
-static const RenderKernelFn g_render_kernels[24] = {
-    RT_K3(false, 0, false), RT_K3(true, 0, false), RT_K3(false, 1, false), RT_K3(true, 1, false),
-    RT_K3(false, 0, true),  RT_K3(true, 0, true),  RT_K3(false, 1, true),  RT_K3(true, 1, true)};
+#define RT_K3(C, A, V, W) render_kernel<C, 0, A, V, W>, render_kernel<C, 1, A, V, W>, render_kernel<C, 2, A, V, W>
+static const RenderKernelFn g_render_kernels[36] = {
+    RT_K3(false, 0, false, RT_MIN_WAVES), RT_K3(true, 0, false, RT_MIN_WAVES), RT_K3(false, 1, false, RT_MIN_WAVES), RT_K3(true, 1, false, RT_MIN_WAVES),
+    RT_K3(false, 0, true, RT_MIN_WAVES),  RT_K3(true, 0, true, RT_MIN_WAVES),  RT_K3(false, 1, true, RT_MIN_WAVES),  RT_K3(true, 1, true, RT_MIN_WAVES),
+    RT_K3(false, 0, false, 5), RT_K3(false, 1, false, 5), RT_K3(false, 0, true, 5), RT_K3(false, 1, true, 5)};
 #undef RT_K3
 
 static thread_local std::string g_err;
@@ -277,7 +282,7 @@ struct RtScene {
     uint2 *spill = nullptr; size_t spill_entries = 0;
     float *frames = nullptr; size_t frames_floats = 0;
     unsigned grid = 0, n_threads = 0;
-    unsigned grids[24] = {0};          // resident grid per render_kernel<COUNT, INTEG> instantiation
+    unsigned grids[36] = {0};          // resident grid per render_kernel<COUNT, INTEG> instantiation
     DevScene *dev_scene = nullptr; DevFrame *dev_frame = nullptr;   // descriptors in HBM (read with scalar loads)
     float4 *samples = nullptr; size_t samples_cap = 0;          // per-shard sample buffer
     float ms_render = 0.f, ms_gather = 0.f; hipEvent_t ev2 = nullptr;
@@ -419,7 +424,7 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
     HIPCHK(hipGetDeviceProperties(&prop, s->device));
     {
         unsigned mx = 0;
-        for (int k = 0; k < 24; ++k) {
+        for (int k = 0; k < 36; ++k) {
             int per_cu = 0;
             HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)g_render_kernels[k], RT_BLOCK, 0));
             if (per_cu < 1) per_cu = 1;
@@ -601,6 +606,8 @@ static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool nee
         const bool tiny = nn <= 4096 && per_leaf >= 1.5;       // few fat leaves: triangle tests dominate -> lock-step rounds
         fr.trav_mode = tiny ? 1 : 2;                           // else batched rounds (measured best on 100k-1M triangle soups)
         fr.exit_thresh = tiny ? 0 : 32;                        // long divergent rays: let finished lanes refill early
+        fr.high_occupancy = tiny ? 0 : 1;
+        if (const char *e = std::getenv("PBRT_HIP_HIGH_OCC")) fr.high_occupancy = std::atoi(e);
         if (const char *e = std::getenv("PBRT_HIP_TRAV_MODE")) fr.trav_mode = std::atoi(e);
         if (const char *e = std::getenv("PBRT_HIP_EXIT_THRESH")) fr.exit_thresh = std::atoi(e);
     }
@@ -730,7 +737,8 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
         s->samples_cap = fr.total_work;
     }
     fr.samples = s->samples;
-    const int variant = (((s->volume.present ? 1 : 0) * 2 + (s->accel_kind == RT_ACCEL_GRID ? 1 : 0)) * 2 + (s->counting ? 1 : 0)) * 3 + rd->integrator;
+    int variant = (((s->volume.present ? 1 : 0) * 2 + (s->accel_kind == RT_ACCEL_GRID ? 1 : 0)) * 2 + (s->counting ? 1 : 0)) * 3 + rd->integrator;
+    if (fr.high_occupancy && !s->counting) variant = 24 + ((s->volume.present ? 1 : 0) * 2 + (s->accel_kind == RT_ACCEL_GRID ? 1 : 0)) * 3 + rd->integrator;
     HIPCHK(hipMemcpyAsync(s->filter_dev, rd->filter_table, 256 * sizeof(float), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemcpyAsync(s->dev_frame, &fr, sizeof(DevFrame), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemsetAsync(s->work_counter, 0, sizeof(unsigned long long), s->stream));

@@ -17,8 +17,10 @@
 #pragma once
 #include "rt_device.h"
 
+// LDS stack entries per lane: 12 x 8 B x 256 lanes = 24 KB per workgroup, so LDS never limits residency below 6 workgroups
+// per CU; deeper pushes (tree depth reaches ~17 at 1M triangles, rarely) spill to HBM and are counted.
 #ifndef RT_STACK_LDS
-#define RT_STACK_LDS 24
+#define RT_STACK_LDS 12
 #endif
 #ifndef RT_BLOCK
 #define RT_BLOCK 256

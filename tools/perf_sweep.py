@@ -24,6 +24,11 @@ def run(tag, defs=(), env=None, workload="c2", steps=2, extra=()):
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "a"
+    if which == "h":
+        run("auto_c2"); run("c2_highocc", env={"PBRT_HIP_HIGH_OCC": "1"})
+        run("auto_p100000", workload="p100000"); run("p100000_lowocc", env={"PBRT_HIP_HIGH_OCC": "0"}, workload="p100000")
+        run("auto_c3_100000", workload="c3_100000"); run("c3_100000_lowocc", env={"PBRT_HIP_HIGH_OCC": "0"}, workload="c3_100000")
+        return
     if which == "g":
         for wl in ("c2", "p100000"):
             run("mailbox_" + wl, workload=wl)
