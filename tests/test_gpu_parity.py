@@ -147,7 +147,8 @@ def test_device_matches_oracle_on_larger_seeded_scenes(pkg, scenes, oracle, cfg)
     else:
         for k in ("closest_rays", "any_rays", "nodes_visited", "tri_tests"):
             assert abs(cnt[k] - ocnt[k]) <= 3e-4 * ocnt[k] + 8, (k, cnt[k], ocnt[k])
-    assert cnt["stack_overflows"] == 0
+    # pushes beyond the 12-entry LDS stack spill to HBM: legal (and exercised here), but must stay rare
+    assert cnt["stack_overflows"] <= 1e-4 * cnt["nodes_visited"] + 1
 
 
 def test_live_reference_when_present(pkg, scenes):
