@@ -256,6 +256,8 @@ class ParsedScene:
         return build_kdtree(self.tri_verts(), self.accel_params_ptr())
 
     def tri_verts(self):
+        if self.n_tris == 0:
+            return np.zeros((0, 3, 3), np.float32)
         p = host_lib().pbrt_host_tri_verts(self.scene_desc)
         return np.ctypeslib.as_array(p, shape=(self.n_tris, 3, 3)).copy()
 

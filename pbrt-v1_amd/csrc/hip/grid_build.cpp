@@ -30,6 +30,10 @@ void build_grid(const float *tri_verts, uint32_t n_tris, GridAccelData &out) {
         }
     }
     for (int a = 0; a < 3; ++a) { out.bounds[a] = lo[a]; out.bounds[3 + a] = hi[a]; }
+    if (n_tris == 0) {                                   // empty world: a single empty voxel
+        for (int a = 0; a < 3; ++a) { out.nvox[a] = 1; out.width[a] = 0.f; out.inv_width[a] = 0.f; }
+        out.voxels.assign(1, Node{0, 0}); out.refs.clear(); return;
+    }
     const float delta[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
     const int maxAxis = (delta[0] > delta[1] && delta[0] > delta[2]) ? 0 : ((delta[1] > delta[2]) ? 1 : 2);   // geometry.h:265-273
     const float invMaxWidth = 1.f / delta[maxAxis];

@@ -56,7 +56,8 @@ class Builder {
 
     void run() {
         int depth = prm.max_depth;
-        if (depth <= 0) depth = round_to_int(8 + 1.3f * log2_int(float(nTris)));
+        if (nTris == 0) depth = 1;                       // empty world: one empty leaf (the reference evaluates log(0) here)
+        else if (depth <= 0) depth = round_to_int(8 + 1.3f * log2_int(float(nTris)));
         tree.max_depth = depth;
         for (int a = 0; a < 3; ++a) edges[a].resize(size_t(2) * nTris);
         std::vector<int> below(nTris), above(size_t(depth + 1) * nTris), all(nTris);

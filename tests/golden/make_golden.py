@@ -60,7 +60,25 @@ CONFIGS = {
                                        world_kwargs=dict(point_light=True)),
 }
 
+EDGE_HDR = scenes.options_block(xres=16, yres=16, integrator="path", xsamples=2, ysamples=1, keyed=True, count=True)
+EDGE_SCENES = {   # degenerate inputs: empty world, a single triangle, zero-area / repeated-index triangles, nsamples 0
+    "edge_empty_world": EDGE_HDR + 'WorldBegin\nLightSource "point" "point from" [278 273 0]\nWorldEnd\n',
+    "edge_one_triangle": EDGE_HDR + 'WorldBegin\nLightSource "point" "point from" [278 273 -100]\nShape "trianglemesh" "integer indices" [0 1 2] '
+                         '"point P" [100 100 300 450 100 300 278 450 300]\nWorldEnd\n',
+    "edge_degenerate_triangles": EDGE_HDR + 'WorldBegin\nLightSource "point" "point from" [278 273 -100]\nShape "trianglemesh" "integer indices" [0 1 2 0 0 0 3 4 5] '
+                                 '"point P" [100 100 300 450 100 300 278 450 300  1 1 1 2 2 2 3 3 3]\nWorldEnd\n',
+    "edge_emitter_nsamples0": EDGE_HDR.replace('"path"', '"directlighting"') + 'WorldBegin\nAreaLightSource "area" "color L" [5 5 5] "integer nsamples" [0]\n'
+                              'Shape "trianglemesh" "integer indices" [0 2 1] "point P" [100 100 300 450 100 300 278 450 300]\n'
+                              'AreaLightSource "area" "color L" [0 0 0]\nMaterial "matte"\nShape "trianglemesh" "integer indices" [0 1 2 0 2 3] '
+                              '"point P" [0 0 500 556 0 500 556 549 500 0 549 500]\nWorldEnd\n',
+}
+
+
 def main():
+    for name, text in EDGE_SCENES.items():
+        rgb, alpha, st = pkg.run_reference(text, keyed=True)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), scene=np.array(text), rgb=rgb, alpha=alpha, stats=np.array(json.dumps(st)))
+        print(name, rgb.shape, "mean", float(rgb.mean()), {k: st[k] for k in ("closest_rays", "any_rays")})
     for name, kw in CONFIGS.items():
         text = scenes.cornell_scene(keyed=True, count=True, **kw)
         if name == "whitted_orennayar_triangle":

@@ -40,7 +40,7 @@ def test_grid_shape_matches_reference_statistics(pkg):
     assert abs(int((voxels[:, 1] == 0).sum()) - empty) <= 60 and abs(len(voxels) - total) <= 60      # printed as "64.4k:79.5k"
 
 
-@pytest.mark.parametrize("name", [n for n in FILMS if "grid" not in n])
+@pytest.mark.parametrize("name", [n for n in FILMS if "grid" not in n and not n.startswith("edge_")])
 def test_kdtree_shape_matches_reference_statistics(pkg, name):
     """rt_kdtree_build (host-only ABI) against the node counts KdTreeAccel reports through StatsPrint
     (kdtree.cpp:41-52,68-69): interior nodes, leaf nodes, total leaf references, max primitives per leaf."""
