@@ -17,6 +17,8 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <atomic>
+#include <thread>
 
 namespace rt {
 namespace {
@@ -40,7 +42,7 @@ class Builder {
   public:
     Builder(const float *verts, uint32_t n, const RtAccelParams &p, KdTree &out)
         : nTris(n), prm(p), tree(out) {
-        primBox.resize(n);
+        primBoxOwn.resize(n); primBoxPtr = &primBoxOwn; std::vector<Box> &primBox = primBoxOwn;
         for (int a = 0; a < 3; ++a) { tree.bounds[a] = INFINITY; tree.bounds[3 + a] = -INFINITY; }
         for (uint32_t i = 0; i < n; ++i) {
             const float *v = verts + size_t(9) * i;
@@ -54,6 +56,19 @@ class Builder {
         }
     }
 
+    // ---- parallel build: the top of the tree is built serially; every subtree with <= cutoff primitives becomes a task
+    // that an independent Builder turns into its own node / leaf-reference arrays; stitching them back in depth-first
+    // order reproduces the serial build's arrays exactly (each subtree's construction depends only on its arguments).
+    struct Task { Box nb; std::vector<int> prims; int depth, bad; uint32_t placeholder; KdTree sub; };
+    std::vector<Task> *tasks = nullptr;
+    int cutoff = 0;
+    void build_subtree(const Box &nb, const std::vector<int> &prims, int depth, int bad) {
+        const int n = int(prims.size());
+        for (int a = 0; a < 3; ++a) edges[a].resize(size_t(2) * std::max(n, 1));
+        std::vector<int> below(std::max(n, 1)), above(size_t(depth + 1) * std::max(n, 1));
+        split(nb, prims.data(), n, depth, below.data(), above.data(), bad);
+    }
+
     void run() {
         int depth = prm.max_depth;
         if (nTris == 0) depth = 1;                       // empty world: one empty leaf (the reference evaluates log(0) here)
@@ -63,15 +78,76 @@ class Builder {
         std::vector<int> below(nTris), above(size_t(depth + 1) * nTris), all(nTris);
         for (uint32_t i = 0; i < nTris; ++i) all[i] = int(i);
         Box root; for (int a = 0; a < 3; ++a) { root.lo[a] = tree.bounds[a]; root.hi[a] = tree.bounds[3 + a]; }
-        tree.nodes.reserve(size_t(nTris) * 4 + 64);
+        int threads = prm.build_threads > 0 ? prm.build_threads : int(std::thread::hardware_concurrency());
+        if (threads > 64) threads = 64;
+        if (threads < 2 || nTris < 20000) {             // serial
+            tree.nodes.reserve(size_t(nTris) * 4 + 64);
+            split(root, all.data(), int(nTris), depth, below.data(), above.data(), 0);
+            return;
+        }
+        std::vector<Task> tk; tasks = &tk; cutoff = std::max(2048, int(nTris / (8 * threads)));
         split(root, all.data(), int(nTris), depth, below.data(), above.data(), 0);
+        tasks = nullptr;
+        std::vector<int>().swap(above); std::vector<int>().swap(below);
+        std::atomic<size_t> next(0);
+        auto worker = [&]() {
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= tk.size()) return;
+                Builder sub(*this, tk[i].sub);
+                sub.build_subtree(tk[i].nb, tk[i].prims, tk[i].depth, tk[i].bad);
+                std::vector<int>().swap(tk[i].prims);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
+        for (auto &th : pool) th.join();
+        // stitch: depth-first walk of the serial top; placeholders expand to their subtree with rebased indices
+        std::vector<Node> top; top.swap(tree.nodes);
+        std::vector<uint32_t> topRefs; topRefs.swap(tree.leaf_refs);
+        size_t total = top.size(), totalRefs = topRefs.size();
+        for (const Task &t : tk) { total += t.sub.nodes.size() - 1; totalRefs += t.sub.leaf_refs.size(); }
+        tree.nodes.reserve(total); tree.leaf_refs.reserve(totalRefs);
+        struct Emit {
+            const std::vector<Node> &top; const std::vector<uint32_t> &topRefs; std::vector<Task> &tk; KdTree &out;
+            void go(uint32_t i) {
+                const Node nd = top[i];
+                if (nd.x == 0xFFFFFFFFu) {                                  // placeholder -> whole subtree
+                    const Task &t = tk[nd.y];
+                    const uint32_t nodeBase = uint32_t(out.nodes.size()), refBase = uint32_t(out.leaf_refs.size());
+                    for (const Node &sn : t.sub.nodes) {
+                        Node o = sn;
+                        if ((sn.x & 3u) != 3u) o.y = sn.y + nodeBase;       // interior: above-child index
+                        else if ((sn.x >> 2) > 1) o.y = sn.y + refBase;     // leaf with a reference list
+                        out.nodes.push_back(o);
+                    }
+                    out.leaf_refs.insert(out.leaf_refs.end(), t.sub.leaf_refs.begin(), t.sub.leaf_refs.end());
+                    return;
+                }
+                const uint32_t me = uint32_t(out.nodes.size());
+                out.nodes.push_back(nd);
+                if ((nd.x & 3u) == 3u) {                                    // leaf built in the serial top
+                    const uint32_t np = nd.x >> 2;
+                    if (np > 1) { out.nodes[me].y = uint32_t(out.leaf_refs.size()); for (uint32_t k = 0; k < np; ++k) out.leaf_refs.push_back(topRefs[nd.y + k]); }
+                    return;
+                }
+                go(i + 1);                                                  // below child
+                out.nodes[me].y = uint32_t(out.nodes.size());
+                go(nd.y);                                                   // above child (top-array index)
+            }
+        } emit{top, topRefs, tk, tree};
+        emit.go(0);
     }
+
+    // subtree builder borrowing the parent's primitive boxes
+    Builder(const Builder &parent, KdTree &out) : nTris(parent.nTris), prm(parent.prm), tree(out), primBoxPtr(parent.primBoxPtr) {}
 
   private:
     uint32_t nTris;
     RtAccelParams prm;
     KdTree &tree;
-    std::vector<Box> primBox;
+    std::vector<Box> primBoxOwn;
+    const std::vector<Box> *primBoxPtr = nullptr;
     std::vector<Edge> edges[3];
 
     void leaf(uint32_t at, const int *prims, int n) {
@@ -88,6 +164,12 @@ class Builder {
         const uint32_t me = uint32_t(tree.nodes.size());
         tree.nodes.push_back(Node{0, 0});
         if (n <= prm.max_prims || depth == 0) { leaf(me, prims, n); return; }
+        if (tasks && n <= cutoff) {                       // hand this subtree to the task pool
+            Task t; t.nb = nb; t.prims.assign(prims, prims + n); t.depth = depth; t.bad = bad; t.placeholder = me;
+            tree.nodes[me].x = 0xFFFFFFFFu; tree.nodes[me].y = uint32_t(tasks->size());
+            tasks->push_back(std::move(t));
+            return;
+        }
 
         int bestAxis = -1, bestEdge = -1;
         float bestCost = INFINITY;
@@ -101,8 +183,8 @@ class Builder {
             Edge *e = edges[axis].data();
             for (int i = 0; i < n; ++i) {
                 const int p = prims[i];
-                e[2 * i] = Edge{primBox[p].lo[axis], p, 0};
-                e[2 * i + 1] = Edge{primBox[p].hi[axis], p, 1};
+                e[2 * i] = Edge{(*primBoxPtr)[p].lo[axis], p, 0};
+                e[2 * i + 1] = Edge{(*primBoxPtr)[p].hi[axis], p, 1};
             }
             std::sort(e, e + 2 * n);
             int nBelow = 0, nAbove = n;
