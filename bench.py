@@ -36,6 +36,11 @@ def workload(name: str):
                                     jitter=True, pixel_filter="mitchell", accelerator="kdtree")
         label = "Cornell box (12 tris + 2-tri area light), PathIntegrator maxdepth=5, 1024x1024 @ 64 spp (stratified 8x8 jittered), mitchell 2x2 filter, kd-tree"
         crop = (0.4375, 0.5625, 0.4375, 0.5625)
+    elif name in ("c2w", "c2d"):        # same frame as c2 with the cheaper integrators (where does the time go?)
+        integ = "whitted" if name == "c2w" else "directlighting"
+        text = scenes.cornell_scene(xres=1024, yres=1024, integrator=integ, xsamples=8, ysamples=8, jitter=True, pixel_filter="mitchell")
+        label = "Cornell box, %s, 1024x1024 @ 64 spp, mitchell, kd-tree" % integ
+        crop = (0.4375, 0.5625, 0.4375, 0.5625)
     elif name == "c1":
         text = scenes.cornell_scene(xres=512, yres=512, integrator="whitted", xsamples=1, ysamples=1, jitter=False,
                                     pixel_filter="box")
@@ -181,7 +186,7 @@ def main():
                        "rng": "counter-based keyed RNG, seed 0"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 5), "traffic": None,
-                         "kernel": "rt::render_kernel<false>", "kernel_ms": round(k_ms, 3),
+                         "kernel": "rt::render_kernel<COUNT=false,...> (persistent wavefront renderer)", "kernel_ms": round(k_ms, 3),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "bytes_per_ray": round(alg_bytes / max(rays_local, 1), 1),
                          "nodes_per_ray": round(cnt["nodes_visited"] / max(rays_local, 1), 2),
