@@ -33,11 +33,14 @@ struct DimReq { unsigned f_base, u_base; unsigned short n; unsigned short dims; 
 
 struct DevScene {
     const DevTri *tris;
+    const float4 *tri_shade;   // per triangle 2 x float4, read once per HIT: {nn.xyz, material|flip<<16} {sn.xyz, area-light index}:
+                               // the geometric normal and BSDF tangent are constants of the triangle, precomputed on the host with
+                               // the reference's expressions (rt_shade.h tri_frame) instead of two normalisations per vertex
     const uint2 *nodes;
     const unsigned *leaf_refs;
     const DevMaterial *materials;
     const DevLight *lights;
-    const float *light_tris;   // [n][12]: 9 vertex floats, per-triangle area, area CDF, pad
+    const float *light_tris;   // [n][16]: 9 vertex floats, per-triangle area, area CDF, pad, emitter normal nl.xyz (flipped), pad
     unsigned n_tris, n_lights;
     float bounds[6];
     // uniform grid (RT_ACCEL_GRID): `nodes` holds one {offset,count} voxel per cell, `leaf_refs` the primitive lists

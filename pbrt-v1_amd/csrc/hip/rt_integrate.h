@@ -509,10 +509,9 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
     if constexpr (STAGE == ST_MIS_DONE) {
         if (COUNT) ++*c_closest;
         if (ln.tv.hit_prim >= 0) {                                              // transport.cpp:180-184
-            V3 p1, p2, p3; unsigned bits; int light;
-            tri_verts(sc.tris, unsigned(ln.tv.hit_prim), p1, p2, p3, bits, light);
+            V3 nh; int light;
+            prim_normal_light(sc, unsigned(ln.tv.hit_prim), nh, light);
             if (light == ln.cur_light) {
-                V3 nh, dpdu; tri_frame(p1, p2, p3, (bits >> 16) & 1u, nh, dpdu);
                 if (dot3(nh, -ln.tv.d) > 0)                                    // isect.Le(-wi) non-black; transport.cpp:188-190
                     ln.Ld = ln.Ld + ln.pend * scene_transmittance<VOL>(sc, ln, ln.tv.o, ln.tv.d, ln.tv.mint, ln.tv.maxt);
             }

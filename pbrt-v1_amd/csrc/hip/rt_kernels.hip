@@ -296,6 +296,25 @@ struct RtScene {
     uint32_t n_tris = 0;
 };
 
+// tri_frame() of rt_shade.h on the host: same operations in the same order (trianglemesh.cpp:248-274, shape.cpp:43-50,
+// reflection.cpp:475-476)
+static void host_tri_frame(const float *v, bool flip, float nn[3], float sn[3]) {
+    const float du1 = 0.f - 1.f, du2 = 1.f - 1.f, dv1 = 0.f - 1.f, dv2 = 0.f - 1.f;
+    const float determinant = du1 * dv2 - dv1 * du2;
+    const float invdet = 1.f / determinant;
+    float dpdu[3], dpdv[3];
+    for (int a = 0; a < 3; ++a) {
+        const float dp1 = v[a] - v[6 + a], dp2 = v[3 + a] - v[6 + a];
+        dpdu[a] = invdet * ((dv2 * dp1) - (dv1 * dp2));
+        dpdv[a] = invdet * ((-du2 * dp1) + (du1 * dp2));
+    }
+    float c[3] = {(dpdu[1] * dpdv[2]) - (dpdu[2] * dpdv[1]), (dpdu[2] * dpdv[0]) - (dpdu[0] * dpdv[2]), (dpdu[0] * dpdv[1]) - (dpdu[1] * dpdv[0])};
+    float inv = 1.f / sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    for (int a = 0; a < 3; ++a) { nn[a] = c[a] * inv; if (flip) nn[a] = -1.f * nn[a]; }
+    inv = 1.f / sqrtf(dpdu[0] * dpdu[0] + dpdu[1] * dpdu[1] + dpdu[2] * dpdu[2]);
+    for (int a = 0; a < 3; ++a) sn[a] = dpdu[a] * inv;
+}
+
 template <class T>
 static int upload(RtScene *s, const T *host, size_t n, const T **dev) {
     void *p = nullptr;
@@ -356,7 +375,20 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
         tris[i].q1 = make_float4(v[4], v[5], v[6], v[7]);
         tris[i].q2 = make_float4(v[8], fb, fl, 0.f);
     }
+    // per-triangle shading constants: tri_frame() (rt_shade.h) evaluated once on the host with the same float
+    // expressions (this file is compiled -ffp-contract=off for the host too; sqrt and divide are IEEE on both sides)
+    std::vector<float4> shade(size_t(2) * d->n_tris);
+    for (uint32_t i = 0; i < d->n_tris; ++i) {
+        float nn[3], sn[3];
+        host_tri_frame(d->tri_verts + size_t(9) * i, (d->tri_flags[i] & 1u) != 0, nn, sn);
+        uint32_t bits = uint32_t(d->tri_material[i]) | (uint32_t(d->tri_flags[i] & 1u) << 16);
+        int32_t light = d->tri_light[i];
+        float fb, fl; std::memcpy(&fb, &bits, 4); std::memcpy(&fl, &light, 4);
+        shade[2 * i] = make_float4(nn[0], nn[1], nn[2], fb);
+        shade[2 * i + 1] = make_float4(sn[0], sn[1], sn[2], fl);
+    }
     int rc;
+    if ((rc = upload(s, shade.data(), shade.size(), &s->dev.tri_shade))) return rc;
     if ((rc = upload(s, tris.data(), tris.size(), &s->dev.tris))) return rc;
     const uint2 *nodes_dev = nullptr;
     if ((rc = upload(s, reinterpret_cast<const uint2 *>(s->tree.nodes.data()), s->tree.nodes.size(), &nodes_dev))) return rc;
@@ -381,7 +413,7 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
     if ((rc = upload(s, mats.data(), mats.size(), &s->dev.materials))) return rc;
 
     // lights + emitter triangles with ShapeSet area CDF (shape.h:122-135)
-    std::vector<float> ltris(size_t(d->n_light_tris) * 12, 0.f);
+    std::vector<float> ltris(size_t(d->n_light_tris) * 16, 0.f);
     std::vector<DevLight> lights(d->n_lights);
     for (uint32_t i = 0; i < d->n_lights; ++i) {
         const RtLight &L = d->lights[i]; DevLight &o = lights[i];
@@ -394,8 +426,9 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
         float area = 0.f; std::vector<float> areas;
         for (uint32_t k = 0; k < L.n_tris; ++k) {
             const float *v = d->light_tris + size_t(L.first_tri + k) * 9;
-            float *q = &ltris[size_t(L.first_tri + k) * 12];
+            float *q = &ltris[size_t(L.first_tri + k) * 16];
             std::memcpy(q, v, 9 * sizeof(float));
+            { float nl[3], sn_unused[3]; host_tri_frame(v, L.flip_normal != 0, nl, sn_unused); q[12] = nl[0]; q[13] = nl[1]; q[14] = nl[2]; }
             // Triangle::Area trianglemesh.cpp:329-335
             float ax = v[3] - v[0], ay = v[4] - v[1], az = v[5] - v[2];
             float bx = v[6] - v[0], by = v[7] - v[1], bz = v[8] - v[2];
@@ -406,7 +439,7 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
         float prev = 0.f;
         for (uint32_t k = 0; k < L.n_tris; ++k) {
             float c = prev + areas[k] / area;
-            ltris[size_t(L.first_tri + k) * 12 + 10] = c; prev = c;
+            ltris[size_t(L.first_tri + k) * 16 + 10] = c; prev = c;
         }
         o.area = (L.n_tris == 1) ? areas[0] : area;
     }

@@ -37,16 +37,22 @@ RT_DEV void tri_frame(V3 p1, V3 p2, V3 p3, bool flip, V3 &nn, V3 &dpdu) {
 }
 
 RT_DEV void make_vertex(const DevScene &sc, const Trav &tv, Vertex &v) {
-    V3 p1, p2, p3; unsigned bits; int light;
-    tri_verts(sc.tris, unsigned(tv.hit_prim), p1, p2, p3, bits, light);
+    const float4 RT_G *q = RT_GPTR(const float4, sc.tri_shade) + size_t(2) * unsigned(tv.hit_prim);
+    const float4 a = q[0], b = q[1];
     v.p = tv.o + tv.d * tv.maxt;                         // ray(t), geometry.h:210
-    V3 dpdu;
-    tri_frame(p1, p2, p3, (bits >> 16) & 1u, v.nn, dpdu);
-    v.sn = normalize3(dpdu);
+    v.nn = mk3(a.x, a.y, a.z);                           // tri_frame(), precomputed per triangle on the host
+    v.sn = mk3(b.x, b.y, b.z);
     v.tn = cross3(v.nn, v.sn);
     v.wo = -tv.d;
-    v.mat = int(bits & 0xffffu);
-    v.light = light;
+    v.mat = int(__float_as_uint(a.w) & 0xffffu);
+    v.light = __float_as_int(b.w);
+}
+// geometric normal (orientation flip applied) and area-light index of a primitive
+RT_DEV void prim_normal_light(const DevScene &sc, unsigned prim, V3 &nn, int &light) {
+    const float4 RT_G *q = RT_GPTR(const float4, sc.tri_shade) + size_t(2) * prim;
+    const float4 a = q[0];
+    nn = mk3(a.x, a.y, a.z);
+    light = __float_as_int(q[1].w);
 }
 
 RT_DEV V3 to_local(const Vertex &v, V3 w) { return mk3(dot3(w, v.sn), dot3(w, v.tn), dot3(w, v.nn)); }
@@ -200,7 +206,7 @@ RT_DEV V3 bsdf_sample_f(MatRef m, const Vertex &v, V3 woW, V3 &wiW, float u1, fl
 
 // ---- lights ------------------------------------------------------------------------------
 RT_DEV void light_tri(const DevScene &sc, unsigned k, V3 &p1, V3 &p2, V3 &p3) {
-    const float RT_G *t = RT_GPTR(const float, sc.light_tris) + size_t(k) * 12;
+    const float RT_G *t = RT_GPTR(const float, sc.light_tris) + size_t(k) * 16;
     p1 = mk3(t[0], t[1], t[2]); p2 = mk3(t[3], t[4], t[5]); p3 = mk3(t[6], t[7], t[8]);
 }
 
@@ -213,7 +219,8 @@ RT_DEV float area_light_pdf(const DevScene &sc, LightRef L, V3 p, V3 wi) {
         float t, b1, b2;
         if (tri_test(p1, p2, p3, p, wi, RT_RAY_EPSILON, RT_INF, t, b1, b2)) {
             any = true; thit = t;
-            V3 dpdu; tri_frame(p1, p2, p3, L.flip_normal != 0, nl, dpdu);
+            const float RT_G *ltr = RT_GPTR(const float, sc.light_tris) + size_t(L.first_tri + k) * 16;
+            nl = mk3(ltr[12], ltr[13], ltr[14]);             // tri_frame() of the emitter triangle, precomputed
         }
     }
     if (!any) return 0.f;
@@ -236,7 +243,7 @@ RT_DEV V3 area_sample_point(const DevScene &sc, LightRef L, float u1, float u2, 
     if (L.n_tris > 1) {
         float ls = rng.next_float();
         for (k = 0; k < L.n_tris - 1; ++k)
-            if (ls < RT_GPTR(const float, sc.light_tris)[size_t(L.first_tri + k) * 12 + 10]) break;
+            if (ls < RT_GPTR(const float, sc.light_tris)[size_t(L.first_tri + k) * 16 + 10]) break;
     }
     V3 p1, p2, p3; light_tri(sc, L.first_tri + k, p1, p2, p3);
     float su1 = sqrtf(u1);
