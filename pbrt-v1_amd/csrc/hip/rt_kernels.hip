@@ -40,19 +40,37 @@ template <bool COUNT, int INTEG, int ACCEL, bool VOL, int MINW>
 __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *__restrict__ scp,
                                                                        const DevFrame *__restrict__ frp) {
     __shared__ uint2 lds_stack[RT_STACK_LDS * RT_BLOCK];
+    constexpr bool POOL = MINW < 5;                       // the pooled-leaf scratch (19 KB) is only carried by the kernels that use it
+    constexpr int PN = POOL ? RT_BLOCK : 64;
+    __shared__ unsigned long long pool_key[PN];
+    __shared__ float4 pool_res[PN];
+    __shared__ unsigned pool_head[PN];
+    __shared__ float4 pool_ray[3 * PN];
     const DevScene &sc = *scp;
     const DevFrame &fr = *frp;
+    const unsigned wave0 = POOL ? (threadIdx.x & ~63u) : 0u;
+    const PoolLds pool = {(unsigned long long RT_L *)pool_key + wave0, (float4 RT_L *)pool_res + wave0, (unsigned RT_L *)pool_head + wave0,
+                          (float4 RT_L *)pool_ray + 3 * wave0};
     const unsigned gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63;
     Lane ln;
     ln.stage = ST_FETCH; ln.has_ray = false; ln.fsp = 0; ln.tv.active = false; ln.tv.hit_prim = -1;
     ln.L = mk3(0.f); ln.thr = mk3(1.f); ln.alpha = 0.f; ln.depth = 0; ln.specular = false;
     TravCounters tc; tc.nodes = tc.leaf_refs = tc.tris = tc.spills = 0;
+    RT_PFT(tc.c_desc = tc.c_leaf = tc.n_chunks = tc.n_pooled = tc.n_iter = 0;)
     unsigned c_cam = 0, c_closest = 0, c_any = 0, c_bad = 0;
 
+#ifdef RT_PROFILE
+    unsigned long long pf_shade = 0, pf_trav = 0, pf_outer = 0, pf_inner = 0, pf_rounds = 0, pf_act = 0, pf_rays = 0, pf_t0 = 0;
+#define RT_PF(x) x
+#else
+#define RT_PF(x)
+#endif
     for (;;) {
+        RT_PF(pf_t0 = __builtin_readcyclecounter(); ++pf_outer;)
         // ---- shade / regenerate: run every lane that is not waiting on a ray until it is (or is out of work)
         do {
+            RT_PF(++pf_inner;)
             advance_pass<COUNT, INTEG, VOL>(sc, fr, ln, gtid, &c_closest, &c_any, &c_bad);
             const unsigned long long want = __ballot(!ln.has_ray && ln.stage == ST_FETCH);
             if (want) {                                                   // wave-aggregated work fetch
@@ -80,6 +98,7 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
                 }
             }
         } while (__any(!ln.has_ray && ln.stage != ST_EXIT));
+        RT_PF({ unsigned long long t1 = __builtin_readcyclecounter(); pf_shade += t1 - pf_t0; pf_t0 = t1; pf_rays += __popcll(__ballot(ln.has_ray && ln.tv.active)); })
         if (!__any(ln.has_ray)) break;
         // ---- extend: one shared traversal loop.  Leave it early when only a few lanes are still traversing AND some
         // lane could meanwhile shade / fetch (its traversal state stays in registers + LDS and resumes next round).
@@ -87,13 +106,22 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
             const bool act = ln.has_ray && ln.tv.active;
             const unsigned long long am = __ballot(act);
             if (!am) break;
+            RT_PF(++pf_rounds; pf_act += __popcll(am);)
             if (fr.exit_thresh > 0 && __popcll(am) <= fr.exit_thresh && __any(!act && ln.stage != ST_EXIT)) break;
             if (fr.trav_mode == 1) accel_round<COUNT, ACCEL>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc);
             else if (fr.trav_mode == 2) accel_round_batched<COUNT, ACCEL>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc);
+            else if (POOL && fr.trav_mode == 3) accel_round_pooled<COUNT, ACCEL>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc, pool);
             else if (act) accel_step<COUNT, ACCEL>(ln.tv, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc);
         }
         if (ln.has_ray && !ln.tv.active) ln.has_ray = false;
+        RT_PF(pf_trav += __builtin_readcyclecounter() - pf_t0;)
     }
+#ifdef RT_PROFILE
+    if (lane == 0) {
+        unsigned long long v[12] = {pf_shade, pf_trav, pf_outer, pf_inner, pf_rounds, pf_act, pf_rays, tc.c_desc, tc.c_leaf, tc.n_chunks, tc.n_pooled, tc.n_iter};
+        for (int k = 0; k < 12; ++k) atomicAdd(fr.counters + 8 + k, v[k]);
+    }
+#endif
 
     if (COUNT) {
         unsigned long long v[8] = {c_cam, c_closest, c_any, tc.nodes, tc.leaf_refs, tc.tris, c_bad, tc.spills};
@@ -470,8 +498,8 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
     s->spill_depth = s->tree.max_depth > RT_STACK_LDS ? s->tree.max_depth - RT_STACK_LDS + 1 : 1;
     HIPCHK(hipMalloc((void **)&s->spill, size_t(s->spill_depth) * s->n_threads * sizeof(uint2)));
     HIPCHK(hipMalloc((void **)&s->work_counter, sizeof(unsigned long long)));
-    HIPCHK(hipMalloc((void **)&s->counters, 8 * sizeof(unsigned long long)));
-    HIPCHK(hipMemset(s->counters, 0, 8 * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void **)&s->counters, 24 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(s->counters, 0, 24 * sizeof(unsigned long long)));
     HIPCHK(hipMalloc((void **)&s->filter_dev, 256 * sizeof(float)));
     HIPCHK(hipMalloc((void **)&s->dev_scene, sizeof(DevScene)));
     HIPCHK(hipMalloc((void **)&s->dev_frame, sizeof(DevFrame)));
@@ -637,12 +665,15 @@ static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool nee
         if (s->accel_kind == RT_ACCEL_KDTREE) for (const Node &n : s->tree.nodes) if ((n.x & 3u) == 3u && (n.x >> 2)) { ++leaves; refs += n.x >> 2; }
         const double per_leaf = leaves ? double(refs) / double(leaves) : 1.0;
         const bool tiny = nn <= 4096 && per_leaf >= 1.5;       // few fat leaves: triangle tests dominate -> lock-step rounds
-        fr.trav_mode = tiny ? 1 : 2;                           // else batched rounds (measured best on 100k-1M triangle soups)
+        fr.trav_mode = tiny ? 3 : 2;                           // lock-step rounds with pooled leaf tests (C2: 83.0 vs 87.1 ms for plain
+                                                               // lock-step); else batched rounds (measured best on 100k-1M triangle soups)
         fr.exit_thresh = tiny ? 0 : 32;                        // long divergent rays: let finished lanes refill early
         fr.high_occupancy = tiny ? 0 : 1;
         if (const char *e = std::getenv("PBRT_HIP_HIGH_OCC")) fr.high_occupancy = std::atoi(e);
         if (const char *e = std::getenv("PBRT_HIP_TRAV_MODE")) fr.trav_mode = std::atoi(e);
         if (const char *e = std::getenv("PBRT_HIP_EXIT_THRESH")) fr.exit_thresh = std::atoi(e);
+        if (fr.trav_mode == 3 && fr.high_occupancy) fr.trav_mode = 1;   // the high-occupancy kernels carry no pooled-leaf scratch
+        if (fr.trav_mode < 0 || fr.trav_mode > 3) fr.trav_mode = 1;
     }
     fr.work_counter = s->work_counter; fr.counters = s->counters; fr.spill = s->spill; fr.n_threads = s->n_threads;
     fr.frames = s->frames;
@@ -795,6 +826,22 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
     }
     HIPCHK(hipEventRecord(s->ev2, s->stream));
     s->have_timing = true;
+#ifdef RT_PROFILE
+    {   // tools/perf_sweep.py 'p': per-wave cycle split of the render kernel (debug builds only)
+        unsigned long long v[24];
+        HIPCHK(hipStreamSynchronize(s->stream));
+        HIPCHK(hipMemcpy(v, s->counters, sizeof v, hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "RT_PROFILE shade_cyc=%llu trav_cyc=%llu outer=%llu inner=%llu rounds=%llu act_lane_rounds=%llu rays_at_trav_start=%llu desc_cyc=%llu leaf_cyc=%llu chunks=%llu pooled_rounds=%llu leaf_iters=%llu\n",
+                     v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15], v[16], v[17], v[18], v[19]);
+        HIPCHK(hipMemsetAsync(s->counters + 8, 0, 16 * sizeof(unsigned long long), s->stream));
+        unsigned long long st[64];
+        HIPCHK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_pf_stage), sizeof st));
+        for (int k = 0; k < 32; ++k) if (st[2 * k + 1])
+            std::fprintf(stderr, "RT_PROFILE_STAGE %d cyc=%llu passes=%llu lanes=%llu\n", k, st[2 * k], st[2 * k + 1] >> 40, st[2 * k + 1] & ((1ull << 40) - 1));
+        std::memset(st, 0, sizeof st);
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_pf_stage), st, sizeof st));
+    }
+#endif
     return RT_OK;
 }
 
@@ -818,7 +865,7 @@ int rt_counters(RtScene *s, RtCounters *out) {
 int rt_counters_reset(RtScene *s) {
     if (!s) return fail(RT_EINVAL, "null scene");
     HIPCHK(hipSetDevice(s->device));
-    HIPCHK(hipMemsetAsync(s->counters, 0, 8 * sizeof(unsigned long long), s->stream));
+    HIPCHK(hipMemsetAsync(s->counters, 0, 24 * sizeof(unsigned long long), s->stream));
     return RT_OK;
 }
 int rt_set_counting(RtScene *s, int enabled) {

@@ -60,7 +60,17 @@ struct Trav {
     bool active;
 };
 
-struct TravCounters { unsigned nodes, leaf_refs, tris, spills; };
+struct TravCounters {
+    unsigned nodes, leaf_refs, tris, spills;
+#ifdef RT_PROFILE
+    unsigned long long c_desc, c_leaf, n_chunks, n_pooled, n_iter;
+#endif
+};
+#ifdef RT_PROFILE
+#define RT_PFT(x) x
+#else
+#define RT_PFT(x)
+#endif
 
 RT_DEV void tri_verts(const DevTri *tris, unsigned prim, V3 &p1, V3 &p2, V3 &p3, unsigned &bits, int &light) {
     const DevTri RT_G *gt = RT_GPTR(const DevTri, tris) + prim;
@@ -338,14 +348,144 @@ RT_DEV void grid_voxel_done(Trav &tv, const DevScene &sc) {               // gri
 template <bool COUNT, int ACCEL>
 RT_DEV void accel_round(Trav &tv, bool mine, const DevScene &sc, uint2 RT_L *lds_stack, uint2 RT_G *spill, unsigned n_threads,
                         unsigned gtid, TravCounters &cnt) {
+    RT_PFT(unsigned long long t0 = __builtin_readcyclecounter();)
     if (ACCEL == RT_ACCEL_GRID) {
         if (mine && tv.active && !tv.at_leaf) grid_enter_voxel<COUNT>(tv, sc, cnt);
     } else {
         while (__any(mine && tv.active && !tv.at_leaf))
             if (mine && tv.active && !tv.at_leaf) kd_descend<COUNT>(tv, sc, lds_stack, spill, n_threads, gtid, cnt);
     }
-    while (__any(mine && tv.active && tv.at_leaf && tv.li < tv.ln_))
+    RT_PFT(unsigned long long t1 = __builtin_readcyclecounter(); cnt.c_desc += t1 - t0;)
+    while (__any(mine && tv.active && tv.at_leaf && tv.li < tv.ln_)) {
+        RT_PFT(++cnt.n_iter;)
         if (mine && tv.active && tv.at_leaf && tv.li < tv.ln_) leaf_test_one<COUNT, ACCEL == RT_ACCEL_GRID>(tv, sc, cnt);
+    }
+    RT_PFT(cnt.c_leaf += __builtin_readcyclecounter() - t1;)
+    if (mine && tv.active && tv.at_leaf) {
+        if (ACCEL == RT_ACCEL_GRID) grid_voxel_done(tv, sc); else kd_leaf_done(tv, lds_stack, spill, n_threads, gtid);
+    }
+}
+
+// ---- pooled leaf tests ----------------------------------------------------------------------------------------
+// In a lock-step round the lanes sit in leaves of different sizes (Cornell: 1..9 triangles) and about half of the
+// lanes have no live ray at all, so "one triangle per lane per iteration" keeps the wave busy for max(n) iterations
+// at ~25 % lane use.  Here the wave pools its (ray, triangle) pairs instead: T = sum(n) tests are dealt to the 64 lanes
+// in chunks of 64, whatever lane owns the ray.  A worker lane pulls the owner's ray with ds_bpermute, runs the
+// reference's test against the owner's maxt as it was when the leaf was entered, and posts a hit with one LDS
+// atomic-min on the owner's 64-bit key {ordered(t), ~k}: the minimum is exactly what the sequential loop
+// (trianglemesh.cpp:213-246 under primitive.cpp:120) ends with -- smallest t, the LATER list position on ties
+// (a later hit with t == maxt is accepted).  For IntersectP rays the key is k: the first position that hits, which
+// also gives the number of tests the sequential loop would have made.  Per-lane visit order, hits, ties and
+// counters are unchanged; only the interleaving across lanes differs.
+struct PoolLds {
+    unsigned long long RT_L *key;   // [64] per wave: best hit of the ray owned by lane i
+    float4 RT_L *res;               // [64] {t, b1, b2, prim} of that hit
+    unsigned RT_L *head;            // [64] slot -> owner+1 at the first slot of each owner's run
+    float4 RT_L *ray;               // [64][3] {o, mint} {d, maxt} {leaf list, n | any << 31, first slot, -} of the ray owned by lane i
+};
+RT_DEV unsigned ordered_bits(float f) {
+    const unsigned b = __float_as_uint(f);
+    return b ^ (unsigned(int(b) >> 31) | 0x80000000u);
+}
+// inclusive wave64 scans on the DPP network (row_shr within rows of 16, then row_bcast:15 / :31 across rows): 6 VALU ops
+#define RT_DPP_STEP(OP, CTRL, ROWMASK) { const unsigned u = unsigned(__builtin_amdgcn_update_dpp(0, int(v), CTRL, ROWMASK, 0xf, false)); v = OP; }
+RT_DEV unsigned wave_scan_add(unsigned v) {
+    RT_DPP_STEP(v + u, 0x111, 0xf) RT_DPP_STEP(v + u, 0x112, 0xf) RT_DPP_STEP(v + u, 0x114, 0xf) RT_DPP_STEP(v + u, 0x118, 0xf)
+    RT_DPP_STEP(v + u, 0x142, 0xa) RT_DPP_STEP(v + u, 0x143, 0xc)
+    return v;
+}
+RT_DEV unsigned wave_scan_max(unsigned v) {
+    RT_DPP_STEP(u > v ? u : v, 0x111, 0xf) RT_DPP_STEP(u > v ? u : v, 0x112, 0xf) RT_DPP_STEP(u > v ? u : v, 0x114, 0xf)
+    RT_DPP_STEP(u > v ? u : v, 0x118, 0xf) RT_DPP_STEP(u > v ? u : v, 0x142, 0xa) RT_DPP_STEP(u > v ? u : v, 0x143, 0xc)
+    return v;
+}
+#undef RT_DPP_STEP
+template <bool COUNT, bool GRID>
+RT_DEV void leaf_phase_pooled(Trav &tv, bool need, const DevScene &sc, PoolLds pl, TravCounters &cnt) {
+    const int lane = int(__lane_id());
+    const unsigned n = need ? tv.ln_ : 0u;
+    const unsigned incl = wave_scan_add(n), start = incl - n;
+    const unsigned T = unsigned(__builtin_amdgcn_readlane(int(incl), 63));
+    // the owner's ray, leaf list and first slot, where any worker lane can read them (3 x ds_write_b128 per round,
+    // 3 x ds_read_b128 per chunk instead of a dozen ds_bpermutes)
+    pl.key[lane] = tv.any ? ~0ull : ((unsigned long long)ordered_bits(tv.maxt + 0.f) << 32) | 0xFFFFFFFFull;
+    pl.ray[3 * lane] = make_float4(tv.o.x, tv.o.y, tv.o.z, tv.mint);
+    pl.ray[3 * lane + 1] = make_float4(tv.d.x, tv.d.y, tv.d.z, tv.maxt);
+    pl.ray[3 * lane + 2] = make_float4(__uint_as_float(tv.ly), __uint_as_float(tv.ln_ | (tv.any ? 0x80000000u : 0u)), __uint_as_float(start), 0.f);
+    for (unsigned c0 = 0; c0 < T; c0 += 64) {
+        pl.head[lane] = 0u;
+        __builtin_amdgcn_wave_barrier();
+        if (n && start < c0 + 64 && start + n > c0) pl.head[(start > c0 ? start : c0) - c0] = unsigned(lane) + 1u;
+        __builtin_amdgcn_wave_barrier();
+        const unsigned h = wave_scan_max(pl.head[lane]);
+        const unsigned w = c0 + unsigned(lane);
+        const bool work = w < T;
+        const int owner = work ? int(h) - 1 : lane;
+        bool hit = false, oany = false;
+        unsigned long long key = 0;
+        float t = 0.f, b1 = 0.f, b2 = 0.f;
+        unsigned prim = 0;
+        if (work) {
+            const float4 r0 = pl.ray[3 * owner], r1 = pl.ray[3 * owner + 1], r2 = pl.ray[3 * owner + 2];
+            const unsigned oly = __float_as_uint(r2.x), opk = __float_as_uint(r2.y), k = w - __float_as_uint(r2.z);
+            oany = (opk & 0x80000000u) != 0;
+            const bool osingle = !GRID && (opk & 0x7fffffffu) == 1u;
+            prim = osingle ? oly : RT_GPTR(const unsigned, sc.leaf_refs)[oly + k];
+            V3 p1, p2, p3; unsigned bits; int light;
+            tri_verts(sc.tris, prim, p1, p2, p3, bits, light);
+            hit = tri_test(p1, p2, p3, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), r0.w, r1.w, t, b1, b2);
+            if (hit) {
+                key = oany ? (unsigned long long)k : ((unsigned long long)ordered_bits(t + 0.f) << 32) | (unsigned long long)(0xFFFFFFFEu - k);
+                atomicMin((unsigned long long *)(pl.key + owner), key);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (hit && !oany) {                                   // the one lane holding the owner's current minimum publishes it
+            if (pl.key[owner] == key) pl.res[owner] = make_float4(t, b1, b2, __uint_as_float(prim));
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (need) {
+        const unsigned long long kf = pl.key[lane];
+        unsigned tested = tv.ln_;
+        if (tv.any) {
+            if (kf != ~0ull) { tv.hit_prim = 0; tv.active = false; tested = unsigned(kf) + 1u; }   // kdtree.cpp:432-434
+        } else if (unsigned(kf) != 0xFFFFFFFFu) {
+            const float4 r = pl.res[lane];
+            tv.maxt = r.x; tv.b1 = r.y; tv.b2 = r.z; tv.hit_prim = int(__float_as_uint(r.w));       // primitive.cpp:120
+        }
+        if (COUNT) { cnt.tris += tested; if (GRID || tv.ln_ != 1) cnt.leaf_refs += tested; }
+        tv.li = tv.ln_;
+    }
+}
+// lock-step round with the leaf phase pooled when that is cheaper than max(n) per-lane iterations
+template <bool COUNT, int ACCEL>
+RT_DEV void accel_round_pooled(Trav &tv, bool mine, const DevScene &sc, uint2 RT_L *lds_stack, uint2 RT_G *spill, unsigned n_threads,
+                               unsigned gtid, TravCounters &cnt, PoolLds pl) {
+    RT_PFT(unsigned long long t0 = __builtin_readcyclecounter();)
+    if (ACCEL == RT_ACCEL_GRID) {
+        if (mine && tv.active && !tv.at_leaf) grid_enter_voxel<COUNT>(tv, sc, cnt);
+    } else {
+        while (__any(mine && tv.active && !tv.at_leaf))
+            if (mine && tv.active && !tv.at_leaf) kd_descend<COUNT>(tv, sc, lds_stack, spill, n_threads, gtid, cnt);
+    }
+    RT_PFT(unsigned long long t1 = __builtin_readcyclecounter(); cnt.c_desc += t1 - t0;)
+    const bool need = mine && tv.active && tv.at_leaf;
+    const unsigned n = need ? tv.ln_ : 0u;
+    // max(n) and sum(n) from ballots (exact while max(n) <= 8; beyond that pooling wins anyway)
+    unsigned m = 0, T = 0;
+#pragma unroll
+    for (unsigned k = 1; k <= 8; ++k) { const unsigned long long b = __ballot(n >= k); if (b) { m = k; T += unsigned(__popcll(b)); } }
+    const unsigned chunks = (T + 63u) >> 6;
+    if (m >= 8 || (m >= 2 && chunks * 7u + 3u < m * 5u)) {
+        RT_PFT(++cnt.n_pooled; cnt.n_chunks += chunks;)
+        leaf_phase_pooled<COUNT, ACCEL == RT_ACCEL_GRID>(tv, need, sc, pl, cnt);
+    } else
+        while (__any(mine && tv.active && tv.at_leaf && tv.li < tv.ln_)) {
+            RT_PFT(++cnt.n_iter;)
+            if (mine && tv.active && tv.at_leaf && tv.li < tv.ln_) leaf_test_one<COUNT, ACCEL == RT_ACCEL_GRID>(tv, sc, cnt);
+        }
+    RT_PFT(cnt.c_leaf += __builtin_readcyclecounter() - t1;)
     if (mine && tv.active && tv.at_leaf) {
         if (ACCEL == RT_ACCEL_GRID) grid_voxel_done(tv, sc); else kd_leaf_done(tv, lds_stack, spill, n_threads, gtid);
     }

@@ -21,9 +21,15 @@ def run(tag, defs=(), env=None, workload="c2", steps=2, extra=()):
                               frac=j["roofline"]["frac"], rays_per_frame=j["config"]["rays_per_frame"])), flush=True)
     except Exception as ex:
         print(json.dumps(dict(tag=tag, error=str(ex), stderr=r.stderr[-300:])), flush=True)
+    if "-DRT_PROFILE" in defs:
+        print("\n".join(l for l in r.stderr.splitlines() if l.startswith("RT_PROFILE")[-3:]) if False else "\n".join([l for l in r.stderr.splitlines() if l.startswith("RT_PROFILE")][-14:]), flush=True)
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "a"
+    if which == "p":
+        for wl in ("c2",):
+            run("profile_mode3_" + wl, ["-DRT_PROFILE"], env={"PBRT_HIP_TRAV_MODE": "3"}, workload=wl)
+        return
     if which == "h":
         run("auto_c2"); run("c2_highocc", env={"PBRT_HIP_HIGH_OCC": "1"})
         run("auto_p100000", workload="p100000"); run("p100000_lowocc", env={"PBRT_HIP_HIGH_OCC": "0"}, workload="p100000")
