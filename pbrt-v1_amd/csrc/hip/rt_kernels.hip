@@ -25,6 +25,9 @@ namespace rt {
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 1
 #endif
+#ifndef RT_HIGH_OCC_WAVES
+#define RT_HIGH_OCC_WAVES 5
+#endif
 #ifndef RT_EXIT_THRESH
 #define RT_EXIT_THRESH 0
 #endif
@@ -40,7 +43,7 @@ template <bool COUNT, int INTEG, int ACCEL, bool VOL, int MINW>
 __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *__restrict__ scp,
                                                                        const DevFrame *__restrict__ frp) {
     __shared__ uint2 lds_stack[RT_STACK_LDS * RT_BLOCK];
-    constexpr bool POOL = MINW < 5;                       // the pooled-leaf scratch (19 KB) is only carried by the kernels that use it
+    constexpr bool POOL = MINW < RT_HIGH_OCC_WAVES;                       // the pooled-leaf scratch (19 KB) is only carried by the kernels that use it
     constexpr int PN = POOL ? RT_BLOCK : 64;
     __shared__ unsigned long long pool_key[PN];
     __shared__ float4 pool_res[PN];
@@ -163,36 +166,91 @@ __global__ __launch_bounds__(256) void film_gather_kernel(const DevFrame *__rest
     const int X0 = fr.x_pixel_start + bx * 16, Y0 = fr.y_pixel_start + by * 16;
     const int bsx0 = max(X0 - rx, fr.x_start), bsx1 = min(X0 + 15 + rx, fr.x_end - 1);
     const int bsy0 = max(Y0 - ry, fr.y_start), bsy1 = min(Y0 + 15 + ry, fr.y_end - 1);
+    const int spp = fr.spp;
+    const float inv_fxw = fr.inv_fxw, inv_fyw = fr.inv_fyw;
     const int col_stride = fr.spp * 2 + 1;                              // float4 units, +1 pad
-    int *owned = reinterpret_cast<int *>(lds_rec + size_t(cols_per_chunk) * col_stride);
+    unsigned long long *colbase = reinterpret_cast<unsigned long long *>(lds_rec + size_t(cols_per_chunk) * col_stride);
+    __shared__ float ftab[256];                                         // FILTER_TABLE_SIZE^2 (film/image.cpp:53-64)
+    ftab[threadIdx.x] = RT_GPTR(const float, fr.filter_table)[threadIdx.x];
     for (int sy = bsy0; sy <= bsy1; ++sy)
         for (int cx = bsx0; cx <= bsx1; cx += cols_per_chunk) {
             const int ncols = min(cols_per_chunk, bsx1 - cx + 1);
             __syncthreads();
-            const int per_col = fr.spp * 2;
-            for (int i = threadIdx.x; i < ncols * per_col; i += 256) {
-                const int c = i / per_col, k = i - c * per_col;
-                const unsigned long long pixel = (unsigned long long)(sy - fr.y_start) * ew + (cx + c - fr.x_start);
+            // one thread per column resolves where that sample pixel's records live in this shard's buffer (64-bit tile
+            // arithmetic once per column, not once per staged float4)
+            if (int(threadIdx.x) < ncols) {
+                const unsigned long long pixel = (unsigned long long)(sy - fr.y_start) * ew + (cx + int(threadIdx.x) - fr.x_start);
                 const unsigned long long tile = pixel / fr.tile_pixels;
                 const bool mine = int(tile % fr.shard_count) == fr.shard_index;
-                if (k == 0) owned[c] = mine ? 1 : 0;
-                if (mine) lds_rec[c * col_stride + k] = RT_GPTR(const float4, fr.samples)[((tile / fr.shard_count) * per_tile + (pixel % fr.tile_pixels) * fr.spp) * 2 + k];
+                colbase[threadIdx.x] = mine ? ((tile / fr.shard_count) * per_tile + (pixel % fr.tile_pixels) * fr.spp) * 2 : ~0ull;
             }
             __syncthreads();
+            const int per_col = fr.spp * 2;
+            int c = int(threadIdx.x) / per_col, k = int(threadIdx.x) - c * per_col;
+            for (; c < ncols;) {
+                const unsigned long long base = colbase[c];
+#ifdef RT_GATHER_NOSTAGE
+                if (false) {
+#else
+                if (base != ~0ull) {
+#endif
+                    float4 q = RT_GPTR(const float4, fr.samples)[base + k];
+                    if (k & 1) {
+                        // the sample's pixel footprint (film/image.cpp:108-116) depends on the sample only: computed once here by the
+                        // staging thread and packed as two int16 pairs into the record's spare words, not once per pixel under it
+                        const float dImageX = q.x - 0.5f, dImageY = q.y - 0.5f;
+                        const int x0 = max(int(ceilf(dImageX - fr.fxw)), xlo), x1 = min(int(floorf(dImageX + fr.fxw)), xhi);
+                        const int y0 = max(int(ceilf(dImageY - fr.fyw)), ylo), y1 = min(int(floorf(dImageY + fr.fyw)), yhi);
+                        q.z = __uint_as_float((unsigned(x0) & 0xffffu) | (unsigned(x1) << 16));
+                        q.w = __uint_as_float((unsigned(y0) & 0xffffu) | (unsigned(y1) << 16));
+                    }
+                    lds_rec[c * col_stride + k] = q;
+                }
+                k += 256;
+                while (k >= per_col) { k -= per_col; ++c; }
+            }
+            __syncthreads();
+#ifdef RT_GATHER_NOACC
+            continue;
+#endif
             if (!live || sy < sy0 || sy > sy1) continue;
             for (int sx = max(cx, sx0); sx <= min(cx + ncols - 1, sx1); ++sx) {
                 const int c = sx - cx;
-                if (!owned[c]) continue;
+                if (colbase[c] == ~0ull) continue;
                 const float4 *rec = lds_rec + c * col_stride;
-                for (int s = 0; s < fr.spp; ++s, rec += 2) {
+                // four samples per trip: their records, footprint tests and filter weights are independent (8 + 4 LDS reads in
+                // flight); only the five accumulations keep the reference's sample order
+                int s = 0;
+                for (; s + 4 <= spp; s += 4, rec += 8) {
+                    float4 L[4], q[4]; float wt[4]; bool in[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { L[u] = rec[2 * u]; q[u] = rec[2 * u + 1]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int bx_ = __float_as_int(q[u].z), by_ = __float_as_int(q[u].w);
+                        const int x0 = int(short(bx_ & 0xffff)), x1 = bx_ >> 16, y0 = int(short(by_ & 0xffff)), y1 = by_ >> 16;
+                        in[u] = !(x < x0 || x > x1 || y < y0 || y > y1);
+                        const float dImageX = q[u].x - 0.5f, dImageY = q[u].y - 0.5f;
+                        const float fx = fabsf((x - dImageX) * inv_fxw * 16), fy = fabsf((y - dImageY) * inv_fyw * 16);
+                        const int ifx = min(int(floorf(fx)), 15), ify = min(int(floorf(fy)), 15);
+                        wt[u] = ftab[(ify * 16 + ifx) & 255];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (in[u]) {
+                            a0 += wt[u] * L[u].x; a1 += wt[u] * L[u].y; a2 += wt[u] * L[u].z;   // Spectrum::AddWeighted color.h:116-120
+                            a3 += L[u].w * wt[u]; a4 += wt[u];
+                        }
+                }
+                for (; s < spp; ++s, rec += 2) {
                     const float4 q = rec[1];
-                    const float dImageX = q.x - 0.5f, dImageY = q.y - 0.5f;
-                    const int x0 = max(int(ceilf(dImageX - fr.fxw)), xlo), x1 = min(int(floorf(dImageX + fr.fxw)), xhi);
-                    const int y0 = max(int(ceilf(dImageY - fr.fyw)), ylo), y1 = min(int(floorf(dImageY + fr.fyw)), yhi);
+                    const int bx_ = __float_as_int(q.z), by_ = __float_as_int(q.w);
+                    const int x0 = int(short(bx_ & 0xffff)), x1 = bx_ >> 16, y0 = int(short(by_ & 0xffff)), y1 = by_ >> 16;
                     if (x < x0 || x > x1 || y < y0 || y > y1) continue;
-                    const float fx = fabsf((x - dImageX) * fr.inv_fxw * 16), fy = fabsf((y - dImageY) * fr.inv_fyw * 16);
+                    const float dImageX = q.x - 0.5f, dImageY = q.y - 0.5f;
+                    const float fx = fabsf((x - dImageX) * inv_fxw * 16), fy = fabsf((y - dImageY) * inv_fyw * 16);
                     const int ifx = min(int(floorf(fx)), 15), ify = min(int(floorf(fy)), 15);
-                    const float wt = RT_GPTR(const float, fr.filter_table)[ify * 16 + ifx];
+                    const float wt = ftab[ify * 16 + ifx];
                     const float4 L = rec[0];
                     a0 += wt * L.x; a1 += wt * L.y; a2 += wt * L.z;       // Spectrum::AddWeighted color.h:116-120
                     a3 += L.w * wt; a4 += wt;
@@ -276,7 +334,8 @@ typedef void (*RenderKernelFn)(const DevScene *, const DevFrame *);
 static const RenderKernelFn g_render_kernels[36] = {
     RT_K3(false, 0, false, RT_MIN_WAVES), RT_K3(true, 0, false, RT_MIN_WAVES), RT_K3(false, 1, false, RT_MIN_WAVES), RT_K3(true, 1, false, RT_MIN_WAVES),
     RT_K3(false, 0, true, RT_MIN_WAVES),  RT_K3(true, 0, true, RT_MIN_WAVES),  RT_K3(false, 1, true, RT_MIN_WAVES),  RT_K3(true, 1, true, RT_MIN_WAVES),
-    RT_K3(false, 0, false, 5), RT_K3(false, 1, false, 5), RT_K3(false, 0, true, 5), RT_K3(false, 1, true, 5)};
+    RT_K3(false, 0, false, RT_HIGH_OCC_WAVES), RT_K3(false, 1, false, RT_HIGH_OCC_WAVES), RT_K3(false, 0, true, RT_HIGH_OCC_WAVES),
+    RT_K3(false, 1, true, RT_HIGH_OCC_WAVES)};
 #undef RT_K3
 
 static thread_local std::string g_err;
@@ -817,10 +876,14 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
         const unsigned gb = unsigned((fr.x_pixel_count + 15) / 16) * unsigned((fr.y_pixel_count + 15) / 16);
         const int grx = int(std::floor(fr.fxw + 0.5f)), gry = int(std::floor(fr.fyw + 0.5f));   // reach of a sample pixel: |x - sx| <= w + .5
         const size_t col_bytes = size_t(fr.spp * 2 + 1) * sizeof(float4);
-        int cols = int((size_t(60) << 10) / col_bytes);
+        if (fr.x_pixel_start + fr.x_pixel_count > 32767 || fr.y_pixel_start + fr.y_pixel_count > 32767)
+            return fail(RT_EINVAL, "rt_render: film coordinates beyond 32767 (the gather packs sample footprints as int16)");
+        size_t lds_kb = 40;                                   // 3 workgroups per CU (measured 60 KB: 5.6 ms, 40 KB: 5.3 ms on C2)
+        if (const char *e = std::getenv("PBRT_HIP_GATHER_LDS_KB")) lds_kb = size_t(std::max(4, std::atoi(e)));
+        int cols = int((lds_kb << 10) / col_bytes);
         if (cols < 1) return fail(RT_EINVAL, "rt_render: more samples per pixel than the film gather stages in LDS (max ~1900)");
         if (cols > 16 + 2 * grx) cols = 16 + 2 * grx;
-        const size_t lds_bytes = size_t(cols) * col_bytes + size_t(cols) * sizeof(int) + 16;
+        const size_t lds_bytes = size_t(cols) * col_bytes + size_t(cols) * sizeof(unsigned long long) + 16;
         hipLaunchKernelGGL(film_gather_kernel, dim3(gb), dim3(256), lds_bytes, s->stream, s->dev_frame, grx, gry, cols);
         HIPCHK(hipGetLastError());
     }

@@ -26,6 +26,17 @@ def run(tag, defs=(), env=None, workload="c2", steps=2, extra=()):
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "a"
+    if which == "r":
+        for w in (5, 6, 8):
+            run("highocc%d_p1m" % w, ["-DRT_HIGH_OCC_WAVES=%d" % w], workload="p1000000")
+            run("highocc%d_p100k" % w, ["-DRT_HIGH_OCC_WAVES=%d" % w], workload="p100000")
+        run("highocc8_lds8_p1m", ["-DRT_HIGH_OCC_WAVES=8", "-DRT_STACK_LDS=8"], workload="p1000000")
+        run("highocc8_lds8_p100k", ["-DRT_HIGH_OCC_WAVES=8", "-DRT_STACK_LDS=8"], workload="p100000")
+        return
+    if which == "q":
+        run("gather_full"); run("gather_nostage", ["-DRT_GATHER_NOSTAGE"]); run("gather_noacc", ["-DRT_GATHER_NOACC"])
+        run("gather_none", ["-DRT_GATHER_NOACC", "-DRT_GATHER_NOSTAGE"]); run("nofilm", env={"PBRT_HIP_DEBUG_NOFILM": "1"})
+        return
     if which == "p":
         for wl in ("c2",):
             run("profile_mode3_" + wl, ["-DRT_PROFILE"], env={"PBRT_HIP_TRAV_MODE": "3"}, workload=wl)
