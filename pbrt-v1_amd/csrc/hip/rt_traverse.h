@@ -9,7 +9,7 @@
 //     8 B per entry {far child, tmax}: the popped tmin is always the tmax of the leaf just
 //     finished, because the leaves visited partition [tmin,tmax] contiguously, so it need not
 //     be stored (the reference stores 12 B + pointer);
-//   * entries beyond RT_STACK_LDS spill to HBM (counted), so depth is unbounded like MAX_TODO=64
+//   * the LDS ring keeps the top RT_STACK_LDS entries; older ones spill to HBM (counted), so depth is unbounded like MAX_TODO=64
 //     never is in practice (<= 17 at 1M triangles);
 //   * one step() = one node visit, so a wave can leave the loop when few lanes are still
 //     traversing and let the others shade / fetch new rays (persistent-thread scheme).
@@ -18,7 +18,7 @@
 #include "rt_device.h"
 
 // LDS stack entries per lane: 12 x 8 B x 256 lanes = 24 KB per workgroup, so LDS never limits residency below 6 workgroups
-// per CU; deeper pushes (tree depth reaches ~17 at 1M triangles, rarely) spill to HBM and are counted.
+// per CU; when the ring is full the oldest entry spills to HBM (counted) -- see stack_push / stack_pop.
 #ifndef RT_STACK_LDS
 #define RT_STACK_LDS 12
 #endif
@@ -42,7 +42,7 @@ struct Trav {
     // traversal cursor
     unsigned node;
     float tmin, tmax;
-    int sp;
+    int sp, sbase;                 // todo stack: entries [sbase, sp) live in the LDS ring, [0, sbase) in HBM
     // leaf / voxel primitive-list cursor for the lock-step ("while-while") traversal: at_leaf => test prims [li, ln)
     unsigned li, ln_, ly;
     bool at_leaf;
@@ -99,10 +99,36 @@ RT_DEV bool tri_test(V3 p1, V3 p2, V3 p3, V3 o, V3 d, float mint, float maxt, fl
     return true;
 }
 
+// ---- todo stack --------------------------------------------------------------------------------------------------
+// The LDS ring holds the TOP RT_STACK_LDS entries (slot = index mod RT_STACK_LDS); when it is full the OLDEST entry moves to
+// HBM, and a pop below the ring's base reads that entry back.  Pushes and pops cluster at the top of the stack, so a deep
+// tree (depth 34 at 1M triangles) costs a handful of HBM round trips per ray instead of one per push/pop beyond entry 12.
+template <bool COUNT>
+RT_DEV void stack_push(Trav &tv, uint2 e, uint2 RT_L *lds_stack, uint2 RT_G *spill, unsigned n_threads, unsigned gtid, TravCounters &cnt) {
+    if (tv.sp - tv.sbase == RT_STACK_LDS) {
+        const volatile uint2 RT_L *slot = (const volatile uint2 RT_L *)lds_stack + (unsigned(tv.sbase) % RT_STACK_LDS) * RT_BLOCK + threadIdx.x;
+        uint2 old; old.x = slot->x; old.y = slot->y;
+        spill[size_t(tv.sbase) * n_threads + gtid] = old;
+        ++tv.sbase;
+        if (COUNT) ++cnt.spills;
+    }
+    lds_stack[(unsigned(tv.sp) % RT_STACK_LDS) * RT_BLOCK + threadIdx.x] = e;
+    ++tv.sp;
+}
+RT_DEV uint2 stack_pop(Trav &tv, const uint2 RT_L *lds_stack, const uint2 RT_G *spill, unsigned n_threads, unsigned gtid) {
+    --tv.sp;
+    // always a ds_read_b64; the (rare) spilled entry overrides it -- written this way so that the two loads are
+    // not merged into one FLAT load through a selected generic pointer
+    const volatile uint2 RT_L *slot = (const volatile uint2 RT_L *)lds_stack + (unsigned(tv.sp) % RT_STACK_LDS) * RT_BLOCK + threadIdx.x;
+    uint2 e; e.x = slot->x; e.y = slot->y;             // volatile: keeps the LDS read a ds_read
+    if (tv.sp < tv.sbase) { e = spill[size_t(tv.sp) * n_threads + gtid]; tv.sbase = tv.sp; }
+    return e;
+}
+
 // start a traversal: slab-clip against the tree bounds (geometry.cpp:51-68, NaN-preserving ternaries)
 RT_DEV void trav_begin(Trav &tv, const DevScene &sc, const Ray &r, bool any) {
     tv.o = r.o; tv.d = r.d; tv.mint = r.mint; tv.maxt = r.maxt; tv.any = any;
-    tv.hit_prim = -1; tv.b1 = 0.f; tv.b2 = 0.f; tv.sp = 0; tv.node = 0; tv.at_leaf = false; tv.li = tv.ln_ = tv.ly = 0;
+    tv.hit_prim = -1; tv.b1 = 0.f; tv.b2 = 0.f; tv.sp = 0; tv.sbase = 0; tv.node = 0; tv.at_leaf = false; tv.li = tv.ln_ = tv.ly = 0;
 #if RT_MAILBOX
     tv.mb0 = tv.mb1 = tv.mb2 = tv.mb3 = 0xffffffffu;
 #endif
@@ -141,10 +167,7 @@ RT_DEV void trav_step(Trav &tv, const DevScene &sc, uint2 RT_L *lds_stack, uint2
         if (tplane > tv.tmax || tplane <= 0.f) tv.node = first;
         else if (tplane < tv.tmin) tv.node = second;
         else {
-            const uint2 e = make_uint2(second, __float_as_uint(tv.tmax));
-            if (tv.sp < RT_STACK_LDS) lds_stack[tv.sp * RT_BLOCK + threadIdx.x] = e;
-            else { spill[size_t(tv.sp - RT_STACK_LDS) * n_threads + gtid] = e; if (COUNT) ++cnt.spills; }
-            ++tv.sp;
+            stack_push<COUNT>(tv, make_uint2(second, __float_as_uint(tv.tmax)), lds_stack, spill, n_threads, gtid, cnt);
             tv.node = first;
             tv.tmax = tplane;
         }
@@ -169,12 +192,7 @@ RT_DEV void trav_step(Trav &tv, const DevScene &sc, uint2 RT_L *lds_stack, uint2
         }
     }
     if (tv.sp > 0) {
-        --tv.sp;
-        // always a ds_read_b64; the (rare) spilled entry overrides it -- written this way so that the two loads are
-        // not merged into one FLAT load through a selected generic pointer
-        const volatile uint2 RT_L *slot = (const volatile uint2 RT_L *)lds_stack + (tv.sp < RT_STACK_LDS ? tv.sp : RT_STACK_LDS - 1) * RT_BLOCK + threadIdx.x;
-        uint2 e; e.x = slot->x; e.y = slot->y;         // volatile: keeps the LDS read a ds_read
-        if (tv.sp >= RT_STACK_LDS) e = spill[size_t(tv.sp - RT_STACK_LDS) * n_threads + gtid];
+        const uint2 e = stack_pop(tv, lds_stack, spill, n_threads, gtid);
         tv.node = e.x;
         tv.tmin = tv.tmax;
         tv.tmax = __uint_as_float(e.y);
@@ -187,7 +205,7 @@ RT_DEV float arr3(const float *a, int i) { return i == 0 ? a[0] : (i == 1 ? a[1]
 RT_DEV int arr3i(const int *a, int i) { return i == 0 ? a[0] : (i == 1 ? a[1] : a[2]); }
 RT_DEV void grid_begin(Trav &tv, const DevScene &sc, const Ray &r, bool any) {
     tv.o = r.o; tv.d = r.d; tv.mint = r.mint; tv.maxt = r.maxt; tv.any = any;
-    tv.hit_prim = -1; tv.b1 = 0.f; tv.b2 = 0.f; tv.sp = 0; tv.node = 0; tv.at_leaf = false; tv.li = tv.ln_ = tv.ly = 0;
+    tv.hit_prim = -1; tv.b1 = 0.f; tv.b2 = 0.f; tv.sp = 0; tv.sbase = 0; tv.node = 0; tv.at_leaf = false; tv.li = tv.ln_ = tv.ly = 0;
 #if RT_MAILBOX
     tv.mb0 = tv.mb1 = tv.mb2 = tv.mb3 = 0xffffffffu;
 #endif
@@ -282,10 +300,7 @@ RT_DEV void kd_descend(Trav &tv, const DevScene &sc, uint2 RT_L *lds_stack, uint
     if (tplane > tv.tmax || tplane <= 0.f) tv.node = first;
     else if (tplane < tv.tmin) tv.node = second;
     else {
-        const uint2 e = make_uint2(second, __float_as_uint(tv.tmax));
-        if (tv.sp < RT_STACK_LDS) lds_stack[tv.sp * RT_BLOCK + threadIdx.x] = e;
-        else { spill[size_t(tv.sp - RT_STACK_LDS) * n_threads + gtid] = e; if (COUNT) ++cnt.spills; }
-        ++tv.sp;
+        stack_push<COUNT>(tv, make_uint2(second, __float_as_uint(tv.tmax)), lds_stack, spill, n_threads, gtid, cnt);
         tv.node = first;
         tv.tmax = tplane;
     }
@@ -313,12 +328,7 @@ RT_DEV void leaf_test_one(Trav &tv, const DevScene &sc, TravCounters &cnt) {
 RT_DEV void kd_leaf_done(Trav &tv, const uint2 RT_L *lds_stack, const uint2 RT_G *spill, unsigned n_threads, unsigned gtid) {
     tv.at_leaf = false;
     if (tv.sp > 0) {
-        --tv.sp;
-        // always a ds_read_b64; the (rare) spilled entry overrides it -- written this way so that the two loads are
-        // not merged into one FLAT load through a selected generic pointer
-        const volatile uint2 RT_L *slot = (const volatile uint2 RT_L *)lds_stack + (tv.sp < RT_STACK_LDS ? tv.sp : RT_STACK_LDS - 1) * RT_BLOCK + threadIdx.x;
-        uint2 e; e.x = slot->x; e.y = slot->y;         // volatile: keeps the LDS read a ds_read
-        if (tv.sp >= RT_STACK_LDS) e = spill[size_t(tv.sp - RT_STACK_LDS) * n_threads + gtid];
+        const uint2 e = stack_pop(tv, lds_stack, spill, n_threads, gtid);
         tv.node = e.x; tv.tmin = tv.tmax; tv.tmax = __uint_as_float(e.y);
     } else tv.active = false;
 }

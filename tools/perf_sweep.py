@@ -8,7 +8,7 @@ BASE = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=of
 
 def run(tag, defs=(), env=None, workload="c2", steps=2, extra=()):
     cmd = BASE + list(defs) + [os.path.join(HIP, "rt_kernels.hip"), os.path.join(HIP, "kd_build.cpp"), os.path.join(HIP, "grid_build.cpp"), "-o", LIB]
-    subprocess.check_call(cmd)
+    subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
     e = dict(os.environ); e.update(env or {})
     try:
       r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--steps", str(steps), "--warmup", "1",
@@ -27,11 +27,10 @@ def run(tag, defs=(), env=None, workload="c2", steps=2, extra=()):
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "a"
     if which == "r":
-        for w in (5, 6, 8):
+        for w in (5, 6, 7, 8):
             run("highocc%d_p1m" % w, ["-DRT_HIGH_OCC_WAVES=%d" % w], workload="p1000000")
             run("highocc%d_p100k" % w, ["-DRT_HIGH_OCC_WAVES=%d" % w], workload="p100000")
-        run("highocc8_lds8_p1m", ["-DRT_HIGH_OCC_WAVES=8", "-DRT_STACK_LDS=8"], workload="p1000000")
-        run("highocc8_lds8_p100k", ["-DRT_HIGH_OCC_WAVES=8", "-DRT_STACK_LDS=8"], workload="p100000")
+        run("highocc8_lds10_p1m", ["-DRT_HIGH_OCC_WAVES=8", "-DRT_STACK_LDS=10"], workload="p1000000")
         return
     if which == "q":
         run("gather_full"); run("gather_nostage", ["-DRT_GATHER_NOSTAGE"]); run("gather_noacc", ["-DRT_GATHER_NOACC"])
