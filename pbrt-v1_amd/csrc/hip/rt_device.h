@@ -64,6 +64,7 @@ struct DevFrame {
     float4 *samples;             // per-shard sample buffer, 2 x float4 per work item
     int shard_index, shard_count, tile_pixels;
     int exit_thresh;             // leave the shared traversal loop when <= this many lanes still traverse (0 = never)
+    int phase_sync;             // path integrator: alternate the two halves of the state machine between sweeps (rt_integrate.h)
     int high_occupancy;          // host-side choice of the 5-waves/SIMD kernel flavour (not read by the device)
     int trav_mode;               // 0 = one node per lane per round, 1 = lock-step (descend all, then test), 2 = batched
     unsigned long long total_work;     // samples this shard renders

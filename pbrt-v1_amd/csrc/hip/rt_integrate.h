@@ -705,9 +705,20 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
 #ifdef RT_PROFILE
 __device__ unsigned long long g_pf_stage[64];
 #endif
+// Phase gating (path integrator): a path alternates [closest-hit ray -> VERTEX, DIRECT_NEXT -> shadow ray] and
+// [shadow ray -> SHADOW_DONE .. BOUNCE -> closest-hit ray]; 64 lanes at random phases run every pass of a sweep half
+// empty.  With `phase` 0 / 1 a sweep runs only the first / second group and the kernel alternates them, so the lanes of
+// a wave fall into step (a lane that leaves the rhythm -- its ray missed, its light sample was black -- idles one
+// trace and is back in step).  phase < 0: no gating.  The per-lane order of stages is unchanged.
+RT_DEV bool stage_in_phase(int stage, int phase) {
+    if (stage == ST_EXIT) return false;
+    if (phase < 0) return true;
+    const bool first = stage == ST_VERTEX || stage == ST_DIRECT_NEXT;
+    return phase == 0 ? first : !first;
+}
 template <bool COUNT, int INTEG, bool VOL>
 RT_DEV void advance_pass(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigned gtid,
-                         unsigned *c_closest, unsigned *c_any, unsigned *c_bad) {
+                         unsigned *c_closest, unsigned *c_any, unsigned *c_bad, int phase) {
 #ifdef RT_PROFILE
 #define RT_RUN(S) { const unsigned long long m_ = __ballot(!ln.has_ray && ln.stage == S); if (m_) { const unsigned long long t_ = __builtin_readcyclecounter(); \
         if (!ln.has_ray && ln.stage == S) stage_body<COUNT, INTEG, VOL, S>(sc, fr, ln, gtid, c_closest, c_any, c_bad); \
@@ -715,17 +726,23 @@ RT_DEV void advance_pass(const DevScene &sc, const DevFrame &fr, Lane &ln, unsig
 #else
 #define RT_RUN(S) if (!ln.has_ray && ln.stage == S) stage_body<COUNT, INTEG, VOL, S>(sc, fr, ln, gtid, c_closest, c_any, c_bad)
 #endif
-    RT_RUN(ST_MIS_DONE);
-    RT_RUN(ST_SHADOW_DONE);
-    RT_RUN(ST_VERTEX);
-    RT_RUN(ST_DIRECT_NEXT);
-    if (INTEG != RT_INTEGRATOR_WHITTED) { RT_RUN(ST_ED_BSDF); RT_RUN(ST_ED_DONE); }
-    if (INTEG == RT_INTEGRATOR_PATH) { RT_RUN(ST_BOUNCE); }
-    else { RT_RUN(ST_SPECULAR); RT_RUN(ST_SPEC_TRANS); }
-    RT_RUN(ST_RETURN);
-    if (VOL) { RT_RUN(ST_VOL_STEP); RT_RUN(ST_VOL_BEGIN); }
-    RT_RUN(ST_POP);
-    RT_RUN(ST_FINISH);
+    if (phase != 0) {
+        RT_RUN(ST_MIS_DONE);
+        RT_RUN(ST_SHADOW_DONE);
+    }
+    if (phase != 1) {
+        RT_RUN(ST_VERTEX);
+        RT_RUN(ST_DIRECT_NEXT);
+    }
+    if (phase != 0) {
+        if (INTEG != RT_INTEGRATOR_WHITTED) { RT_RUN(ST_ED_BSDF); RT_RUN(ST_ED_DONE); }
+        if (INTEG == RT_INTEGRATOR_PATH) { RT_RUN(ST_BOUNCE); }
+        else { RT_RUN(ST_SPECULAR); RT_RUN(ST_SPEC_TRANS); }
+        RT_RUN(ST_RETURN);
+        if (VOL) { RT_RUN(ST_VOL_STEP); RT_RUN(ST_VOL_BEGIN); }
+        RT_RUN(ST_POP);
+        RT_RUN(ST_FINISH);
+    }
 #undef RT_RUN
 }
 

@@ -69,13 +69,16 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
 #else
 #define RT_PF(x)
 #endif
+    // phase gating (rt_integrate.h, stage_in_phase): sweeps alternate between the two halves of the path state machine;
+    // the first sweep is of the second kind (it contains the work fetch)
+    int phase = (INTEG == RT_INTEGRATOR_PATH && fr.phase_sync) ? 1 : -1;
     for (;;) {
         RT_PF(pf_t0 = __builtin_readcyclecounter(); ++pf_outer;)
         // ---- shade / regenerate: run every lane that is not waiting on a ray until it is (or is out of work)
         do {
             RT_PF(++pf_inner;)
-            advance_pass<COUNT, INTEG, VOL>(sc, fr, ln, gtid, &c_closest, &c_any, &c_bad);
-            const unsigned long long want = __ballot(!ln.has_ray && ln.stage == ST_FETCH);
+            advance_pass<COUNT, INTEG, VOL>(sc, fr, ln, gtid, &c_closest, &c_any, &c_bad, phase);
+            const unsigned long long want = phase == 0 ? 0ull : __ballot(!ln.has_ray && ln.stage == ST_FETCH);
             if (want) {                                                   // wave-aggregated work fetch
                 const int leader = __ffsll((long long)want) - 1;
                 unsigned long long base = 0;
@@ -100,9 +103,13 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
                     }
                 }
             }
-        } while (__any(!ln.has_ray && ln.stage != ST_EXIT));
+        } while (__any(!ln.has_ray && stage_in_phase(ln.stage, phase)));
+        if (phase >= 0) phase ^= 1;
         RT_PF({ unsigned long long t1 = __builtin_readcyclecounter(); pf_shade += t1 - pf_t0; pf_t0 = t1; pf_rays += __popcll(__ballot(ln.has_ray && ln.tv.active)); })
-        if (!__any(ln.has_ray)) break;
+        if (!__any(ln.has_ray)) {
+            if (!__any(ln.stage != ST_EXIT)) break;
+            continue;                                                     // everybody waits for the other kind of sweep
+        }
         // ---- extend: one shared traversal loop.  Leave it early when only a few lanes are still traversing AND some
         // lane could meanwhile shade / fetch (its traversal state stays in registers + LDS and resumes next round).
         for (;;) {
@@ -731,6 +738,8 @@ static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool nee
         if (const char *e = std::getenv("PBRT_HIP_HIGH_OCC")) fr.high_occupancy = std::atoi(e);
         if (const char *e = std::getenv("PBRT_HIP_TRAV_MODE")) fr.trav_mode = std::atoi(e);
         if (const char *e = std::getenv("PBRT_HIP_EXIT_THRESH")) fr.exit_thresh = std::atoi(e);
+        fr.phase_sync = tiny ? 1 : 0;                          // C2: 63.6 vs 82.4 ms; 100k/1M soups (early-exit rounds): 8 % slower
+        if (const char *e = std::getenv("PBRT_HIP_PHASE_SYNC")) fr.phase_sync = std::atoi(e);
         if (fr.trav_mode == 3 && fr.high_occupancy) fr.trav_mode = 1;   // the high-occupancy kernels carry no pooled-leaf scratch
         if (fr.trav_mode < 0 || fr.trav_mode > 3) fr.trav_mode = 1;
     }
