@@ -702,7 +702,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
 // shadow ray, from a MIS ray or straight from a vertex.  (A switch executed once per transition would run every
 // stage body once per lane phase: ~8x lower SIMD utilisation with 64 lanes at random phases.)  Backward edges
 // (next light of the all-lights loop, popping a recursion frame) simply take another pass.
-#ifdef RT_PROFILE
+#ifdef RT_PROFILE_STAGES
 __device__ unsigned long long g_pf_stage[64];
 #endif
 // Phase gating (path integrator): a path alternates [closest-hit ray -> VERTEX, DIRECT_NEXT -> shadow ray] and
@@ -719,7 +719,7 @@ RT_DEV bool stage_in_phase(int stage, int phase) {
 template <bool COUNT, int INTEG, bool VOL>
 RT_DEV void advance_pass(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigned gtid,
                          unsigned *c_closest, unsigned *c_any, unsigned *c_bad, int phase) {
-#ifdef RT_PROFILE
+#ifdef RT_PROFILE_STAGES
 #define RT_RUN(S) { const unsigned long long m_ = __ballot(!ln.has_ray && ln.stage == S); if (m_) { const unsigned long long t_ = __builtin_readcyclecounter(); \
         if (!ln.has_ray && ln.stage == S) stage_body<COUNT, INTEG, VOL, S>(sc, fr, ln, gtid, c_closest, c_any, c_bad); \
         if (__lane_id() == 0) { atomicAdd(&g_pf_stage[2 * S], __builtin_readcyclecounter() - t_); atomicAdd(&g_pf_stage[2 * S + 1], (unsigned long long)__popcll(m_) | (1ull << 40)); } } }

@@ -906,12 +906,14 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
         std::fprintf(stderr, "RT_PROFILE shade_cyc=%llu trav_cyc=%llu outer=%llu inner=%llu rounds=%llu act_lane_rounds=%llu rays_at_trav_start=%llu desc_cyc=%llu leaf_cyc=%llu chunks=%llu pooled_rounds=%llu leaf_iters=%llu\n",
                      v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15], v[16], v[17], v[18], v[19]);
         HIPCHK(hipMemsetAsync(s->counters + 8, 0, 16 * sizeof(unsigned long long), s->stream));
+#ifdef RT_PROFILE_STAGES
         unsigned long long st[64];
         HIPCHK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_pf_stage), sizeof st));
         for (int k = 0; k < 32; ++k) if (st[2 * k + 1])
             std::fprintf(stderr, "RT_PROFILE_STAGE %d cyc=%llu passes=%llu lanes=%llu\n", k, st[2 * k], st[2 * k + 1] >> 40, st[2 * k + 1] & ((1ull << 40) - 1));
         std::memset(st, 0, sizeof st);
         HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_pf_stage), st, sizeof st));
+#endif
     }
 #endif
     return RT_OK;

@@ -38,7 +38,8 @@ def main():
         return
     if which == "p":
         for wl in ("c2",):
-            run("profile_mode3_" + wl, ["-DRT_PROFILE"], env={"PBRT_HIP_TRAV_MODE": "3"}, workload=wl)
+            run("profile_" + wl, ["-DRT_PROFILE"], workload=wl)
+            run("profile_stages_" + wl, ["-DRT_PROFILE", "-DRT_PROFILE_STAGES"], workload=wl)
         return
     if which == "h":
         run("auto_c2"); run("c2_highocc", env={"PBRT_HIP_HIGH_OCC": "1"})
