@@ -197,11 +197,22 @@ def main():
         prof = os.path.join(ROOT, "profiles", "latest_%s_render_kernel.json" % args.workload)
         if world == 1 and os.path.exists(prof):
             pj = json.load(open(prof))
+            # profiles/r01_fetch_size_calibration.txt: on this library's gathers FETCH_SIZE tallies 64 B per fabric read request
+            # (exact for 64-B requests, 1/2 for 128-B ones, the guide's streaming case); WRITE_SIZE is exact.  `traffic` is the
+            # conservative figure (reads doubled); the lower bound is reported beside it.
             out["roofline"]["traffic"] = int(pj["hbm_bytes_per_launch_fetch_doubled"])
+            out["roofline"]["traffic_lower_bound"] = int(pj["hbm_bytes_per_launch_uncorrected"])
             out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(os.path.realpath(prof)) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per launch)"
-            out["roofline"]["note"] = ("this workload's 23-node tree and 14 triangles are L1/L2 resident: measured HBM traffic is ~1%% of the "
-                                       "algorithmic bytes, so the HBM roofline is not the binding limit here; VALU issue under divergence is "
-                                       "(VALUBusy %.0f%%, %.0f%% of lanes active)" % (pj["derived"]["VALUBusy_percent"], pj["derived"]["VALUUtilization_percent_active_lanes"]))
+            busy = "VALUBusy %.0f%%, %.0f%% of lanes active" % (pj["derived"]["VALUBusy_percent"], pj["derived"]["VALUUtilization_percent_active_lanes"])
+            if out["roofline"]["traffic"] < 0.1 * alg_bytes:
+                out["roofline"]["note"] = ("this workload's tree and triangles are L1/L2 resident: measured HBM traffic is ~%.0f%% of the algorithmic "
+                                           "bytes (mostly the 32-byte sample records written once), so the HBM roofline is not the binding limit "
+                                           "here; VALU issue under divergence is (%s)" % (100.0 * out["roofline"]["traffic"] / alg_bytes, busy))
+            else:
+                out["roofline"]["note"] = ("fabric traffic %.2f-%.2fx the algorithmic bytes: 64-byte sectors fetched for 8-byte nodes, plus the "
+                                           "register-spill scratch of the 96-VGPR high-occupancy flavour (WRITE_SIZE %.0f GB/launch vs 0.5 GB of "
+                                           "sample records); L2 hit rate %.0f%%; %s" % (out["roofline"]["traffic_lower_bound"] / alg_bytes,
+                                           out["roofline"]["traffic"] / alg_bytes, pj["WRITE_SIZE_KB"] * 1024 / 1e9, 100 * pj["derived"]["L2_hit_rate"], busy))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, args.workload, crop)
             if out["cpu_baseline"].get("value"):
