@@ -43,17 +43,20 @@ typedef struct RtMaterial {
     float ior;     /* glass "index"                                              */
 } RtMaterial;
 
-/* ---- lights: lights/point.cpp:49-69, lights/area.cpp:28-105 ---- */
-enum { RT_LIGHT_POINT = 0, RT_LIGHT_AREA = 1 };
+/* ---- lights: lights/point.cpp:49-69, lights/area.cpp:28-105, lights/spot.cpp:54-79, lights/distant.cpp:51-62 ---- */
+enum { RT_LIGHT_POINT = 0, RT_LIGHT_AREA = 1, RT_LIGHT_SPOT = 2, RT_LIGHT_DISTANT = 3 };
 typedef struct RtLight {
     int32_t type;
-    float color[3];      /* point: I      area: Lemit                                */
-    float pos[3];        /* point light position (world)                            */
+    float color[3];      /* point/spot: I   area: Lemit   distant: L                 */
+    float pos[3];        /* point/spot light position (world, LightToWorld(0,0,0))  */
     int32_t n_samples;   /* Light::nSamples (light.h:39)                            */
     uint32_t first_tri;  /* area: range in light_tris (ShapeSet order, shape.h:112) */
     uint32_t n_tris;
     int32_t reverse_orientation; /* Triangle::Sample flips Ns by this only (trianglemesh.cpp:346) */
     int32_t flip_normal;         /* reverseOrientation ^ transformSwapsHandedness (shape.cpp:49)   */
+    float dir[3];                /* distant: lightDir = Normalize(LightToWorld(from - to)) (distant.cpp:51-56) */
+    float world_to_light[9];     /* spot: upper-left 3x3 of WorldToLight, row-major (Falloff, spot.cpp:68-79)   */
+    float cos_total_width, cos_falloff_start;   /* spot.cpp:58-59 */
 } RtLight;
 
 /* ---- camera: core/camera.cpp:50-70, cameras/perspective.cpp:51-82 ---- */

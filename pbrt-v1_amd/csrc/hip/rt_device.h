@@ -26,6 +26,9 @@ struct DevLight {
     unsigned first_tri, n_tris;
     int reverse_orientation, flip_normal;
     float area;        // ShapeSet::area / Triangle::Area() (shape.h:123-131, trianglemesh.cpp:329-335)
+    float dir[3];      // distant
+    float w2l[9];      // spot: WorldToLight 3x3
+    float cos_total, cos_falloff;
 };
 
 #define RT_MAX_DIM_REQ 40

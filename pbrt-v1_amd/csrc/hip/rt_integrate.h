@@ -334,7 +334,7 @@ RT_DEV V3 scene_transmittance(const DevScene &sc, Lane &ln, V3 o, V3 d, float mi
 RT_DEV void estimate_direct_bsdf(const DevScene &sc, Lane &ln) {
     LightRef Lt = RT_LIGHT(sc, ln.cur_light);
     ln.stage = ST_ED_DONE;
-    if (Lt.type == RT_LIGHT_POINT) return;                                      // IsDeltaLight()
+    if (light_is_delta(Lt)) return;                                             // IsDeltaLight()
     MatRef m = RT_MAT(sc, ln.v.mat);
     V3 wi; float bsdfPdf; int sampled;
     V3 f = bsdf_sample_f(m, ln.v, ln.v.wo, wi, ln.bs1, ln.bs2, ln.bcs, bsdfPdf, BX_ALL & ~BX_SPECULAR, sampled);
@@ -356,34 +356,30 @@ RT_DEV void estimate_direct_begin(const DevScene &sc, Lane &ln, int light, float
     ln.Ld = mk3(0.f);
     LightRef Lt = RT_LIGHT(sc, light);
     MatRef m = RT_MAT(sc, ln.v.mat);
-    V3 wi, Li, pseg; float lightPdf;
-    if (Lt.type == RT_LIGHT_POINT) {                                            // point.cpp:55-66
-        V3 lp = mat_color(Lt.pos);
-        wi = normalize3(lp - ln.v.p);
+    V3 wi, Li, sd; float lightPdf, smax;
+    if (light_is_delta(Lt)) {                                                   // point.cpp:61-66, spot.cpp:80-84, distant.cpp:63-67
+        Li = delta_light_sample(Lt, ln.v.p, wi, sd, smax);
         lightPdf = 1.f;
-        V3 dd = lp - ln.v.p;
-        Li = div_s(mat_color(Lt.color), dd.x * dd.x + dd.y * dd.y + dd.z * dd.z);
-        pseg = lp;
     } else {                                                                    // area.cpp:58-68
         V3 ns;
         V3 ps = area_sample_point(sc, Lt, ls1, ls2, ln.rng, ns);
         wi = normalize3(ps - ln.v.p);
         lightPdf = area_light_pdf(sc, Lt, ln.v.p, wi);
         Li = area_L(Lt, ns, -wi);
-        pseg = ps;
+        sd = ps - ln.v.p; smax = 1.f - RT_RAY_EPSILON;
     }
     if (lightPdf > 0.f && !is_black(Li)) {
         V3 f = bsdf_f(m, ln.v, ln.v.wo, wi);
         if (!is_black(f)) {
-            if (Lt.type == RT_LIGHT_POINT) ln.pend = div_s((f * Li) * absdot3(wi, ln.v.nn), lightPdf);
+            if (light_is_delta(Lt)) ln.pend = div_s((f * Li) * absdot3(wi, ln.v.nn), lightPdf);
             else {
                 float bsdfPdf = bsdf_pdf(m, ln.v, ln.v.wo, wi);
                 float fw = 1 * lightPdf, gw = 1 * bsdfPdf;
                 float weight = (fw * fw) / (fw * fw + gw * gw);
                 ln.pend = div_s(((f * Li) * absdot3(wi, ln.v.nn)) * weight, lightPdf);
             }
-            // VisibilityTester::SetSegment light.h:78-80
-            launch_ray(ln, sc, ln.v.p, pseg - ln.v.p, RT_RAY_EPSILON, 1.f - RT_RAY_EPSILON, true, ST_SHADOW_DONE);
+            // VisibilityTester::SetSegment / SetRay light.h:78-83
+            launch_ray(ln, sc, ln.v.p, sd, RT_RAY_EPSILON, smax, true, ST_SHADOW_DONE);
             return;
         }
     }
@@ -465,28 +461,23 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
             LightRef Lt = RT_LIGHT(sc, ln.li);
             MatRef m = RT_MAT(sc, ln.v.mat);
             const int cur = ln.li++;
-            V3 wi, Li, pseg;
-            if (Lt.type == RT_LIGHT_POINT) {                                    // point.cpp:55-60
-                V3 lp = mat_color(Lt.pos);
-                wi = normalize3(lp - ln.v.p);
-                V3 dd = lp - ln.v.p;
-                Li = div_s(mat_color(Lt.color), dd.x * dd.x + dd.y * dd.y + dd.z * dd.z);
-                pseg = lp;
-            } else {                                                            // area.cpp:96-105
+            V3 wi, Li, sd; float smax;
+            if (light_is_delta(Lt)) Li = delta_light_sample(Lt, ln.v.p, wi, sd, smax);   // point.cpp:55-60, spot.cpp:61-67, distant.cpp:57-62
+            else {                                                              // area.cpp:96-105
                 float u2 = ln.rng.next_float();     // g++ evaluates the two RandomFloat() arguments right to left
                 float u1 = ln.rng.next_float();
                 V3 ns; V3 ps = area_sample_point(sc, Lt, u1, u2, ln.rng, ns);
                 wi = normalize3(ps - ln.v.p);
                 float pdf = area_light_pdf(sc, Lt, ln.v.p, wi);
                 Li = (pdf == 0.f) ? mk3(0.f) : div_s(area_L(Lt, ns, -wi), pdf);
-                pseg = ps;
+                sd = ps - ln.v.p; smax = 1.f - RT_RAY_EPSILON;
             }
             (void)cur;
             if (is_black(Li)) return;
             V3 f = bsdf_f(m, ln.v, ln.v.wo, wi);
             if (is_black(f)) return;
             ln.pend = (f * Li) * absdot3(wi, ln.v.nn);
-            launch_ray(ln, sc, ln.v.p, pseg - ln.v.p, RT_RAY_EPSILON, 1.f - RT_RAY_EPSILON, true, ST_SHADOW_DONE);
+            launch_ray(ln, sc, ln.v.p, sd, RT_RAY_EPSILON, smax, true, ST_SHADOW_DONE);
         }
         return;
     }
@@ -655,13 +646,12 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
                     const int lightNum = min(int(floorf(samp[size_t(3 * i) * st] * nLights)), nLights - 1);
                     const float u1 = samp[size_t(3 * i + 1) * st], u2 = samp[size_t(3 * i + 2) * st];
                     LightRef Lt = RT_LIGHT(sc, lightNum);
-                    V3 wo, L, pseg; float pdf;
-                    if (Lt.type == RT_LIGHT_POINT) {
-                        V3 lp = mat_color(Lt.pos); wo = normalize3(lp - p); pdf = 1.f;
-                        V3 dd = lp - p; L = div_s(mat_color(Lt.color), dd.x * dd.x + dd.y * dd.y + dd.z * dd.z); pseg = lp;
-                    } else {
+                    V3 wo, L, sd; float pdf, smax;
+                    if (light_is_delta(Lt)) { L = delta_light_sample(Lt, p, wo, sd, smax); pdf = 1.f; }
+                    else {
                         V3 ns; V3 ps = area_sample_point(sc, Lt, u1, u2, ln.rng, ns);
-                        wo = normalize3(ps - p); pdf = area_light_pdf(sc, Lt, p, wo); L = area_L(Lt, ns, -wo); pseg = ps;
+                        wo = normalize3(ps - p); pdf = area_light_pdf(sc, Lt, p, wo); L = area_L(Lt, ns, -wo);
+                        sd = ps - p; smax = 1.f - RT_RAY_EPSILON;
                     }
                     if (!is_black(L) && pdf > 0.f) {
                         const float costheta = dot3(w, -wo);                       // PhaseHG volume.cpp:44-48
@@ -670,7 +660,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
                         vs[0] = __int_as_float(i); vs[st] = __int_as_float(N); vs[2 * st] = t0; vs[3 * st] = step;
                         vs[4 * st] = Tr.x; vs[5 * st] = Tr.y; vs[6 * st] = Tr.z; vs[7 * st] = p.x; vs[8 * st] = p.y; vs[9 * st] = p.z;
                         vs[10 * st] = Lv.x; vs[11 * st] = Lv.y; vs[12 * st] = Lv.z;
-                        launch_ray(ln, sc, p, pseg - p, RT_RAY_EPSILON, 1.f - RT_RAY_EPSILON, true, ST_VOL_STEP);
+                        launch_ray(ln, sc, p, sd, RT_RAY_EPSILON, smax, true, ST_VOL_STEP);
                         return;
                     }
                 }

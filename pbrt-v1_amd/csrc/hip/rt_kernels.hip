@@ -515,6 +515,10 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
         for (int c = 0; c < 3; ++c) { o.color[c] = L.color[c]; o.pos[c] = L.pos[c]; }
         o.first_tri = L.first_tri; o.n_tris = L.n_tris; o.reverse_orientation = L.reverse_orientation;
         o.flip_normal = L.flip_normal; o.area = 0.f;
+        for (int c = 0; c < 3; ++c) o.dir[c] = L.dir[c];
+        for (int c = 0; c < 9; ++c) o.w2l[c] = L.world_to_light[c];
+        o.cos_total = L.cos_total_width; o.cos_falloff = L.cos_falloff_start;
+        if (L.type < RT_LIGHT_POINT || L.type > RT_LIGHT_DISTANT) return fail(RT_EINVAL, "rt_scene_create: unknown light type");
         if (L.type != RT_LIGHT_AREA) continue;
         if (size_t(L.first_tri) + L.n_tris > d->n_light_tris) return fail(RT_EINVAL, "rt_scene_create: light triangle range out of bounds");
         float area = 0.f; std::vector<float> areas;

@@ -210,6 +210,34 @@ RT_DEV void light_tri(const DevScene &sc, unsigned k, V3 &p1, V3 &p2, V3 &p3) {
     p1 = mk3(t[0], t[1], t[2]); p2 = mk3(t[3], t[4], t[5]); p3 = mk3(t[6], t[7], t[8]);
 }
 
+// ---- delta lights: {Point,Spot,Distant}Light::Sample_L(p, &wi, &visibility) (point.cpp:55-60, spot.cpp:61-79,
+// distant.cpp:57-62).  Returns the incident radiance; `sd`, `smax` = the visibility ray's direction and maxt
+// (SetSegment: p -> light position, maxt 1 - eps; SetRay: p along wi, unbounded; light.h:78-83).
+RT_DEV bool light_is_delta(LightRef Lt) { return Lt.type != RT_LIGHT_AREA; }
+RT_DEV V3 delta_light_sample(LightRef Lt, V3 p, V3 &wi, V3 &sd, float &smax) {
+    if (Lt.type == RT_LIGHT_DISTANT) {
+        wi = mk3(Lt.dir[0], Lt.dir[1], Lt.dir[2]);
+        sd = wi; smax = RT_INF;
+        return mat_color(Lt.color);
+    }
+    const V3 lp = mat_color(Lt.pos);
+    const V3 dd = lp - p;
+    wi = normalize3(dd);
+    sd = dd; smax = 1.f - RT_RAY_EPSILON;
+    const float d2 = dd.x * dd.x + dd.y * dd.y + dd.z * dd.z;                  // DistanceSquared geometry.h
+    if (Lt.type == RT_LIGHT_POINT) return div_s(mat_color(Lt.color), d2);
+    // SpotLight::Falloff(-wi)
+    const V3 w = -wi;
+    const V3 wl = normalize3(mk3(Lt.w2l[0] * w.x + Lt.w2l[1] * w.y + Lt.w2l[2] * w.z, Lt.w2l[3] * w.x + Lt.w2l[4] * w.y + Lt.w2l[5] * w.z,
+                                 Lt.w2l[6] * w.x + Lt.w2l[7] * w.y + Lt.w2l[8] * w.z));
+    const float costheta = wl.z;
+    float fall;
+    if (costheta < Lt.cos_total) fall = 0.f;
+    else if (costheta > Lt.cos_falloff) fall = 1.f;
+    else { const float delta = (costheta - Lt.cos_total) / (Lt.cos_falloff - Lt.cos_total); fall = delta * delta * delta * delta; }
+    return div_s(mat_color(Lt.color) * fall, d2);
+}
+
 // Shape::Pdf(p, wi) shape.h:96-107 evaluated on the emitter's own triangles:
 // ShapeSet::Intersect (shape.h:150-156) keeps the LAST triangle hit, the ray's maxt is never shortened.
 RT_DEV float area_light_pdf(const DevScene &sc, LightRef L, V3 p, V3 wi) {

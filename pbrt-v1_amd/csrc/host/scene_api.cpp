@@ -311,15 +311,46 @@ void PbrtApi::ReverseOrientation() { if (verifyWorld("ReverseOrientation")) gs.r
 void PbrtApi::LightSource(const std::string &n, const ParamList &p) {
     if (!verifyWorld("LightSource")) return;
     ParamSet ps(p);
-    if (n != "point") { Error("pbrtLightSource: light type \"%s\" unknown.", n.c_str()); return; }
-    // CreateLight lights/point.cpp:78-84 + PointLight ctor :49-54
-    Float3 I = ps.FindOneSpectrum("I", Float3{1.f, 1.f, 1.f});
-    Float3 P = ps.FindOnePoint("from", Float3{0, 0, 0});
-    Xform l2w = pbrthip::Translate(P.x, P.y, P.z) * ctm;
-    ps.ReportUnused();
     RtLight L; std::memset(&L, 0, sizeof L);
-    L.type = RT_LIGHT_POINT; L.color[0] = I.x; L.color[1] = I.y; L.color[2] = I.z; L.n_samples = 1;
-    const float origin[3] = {0, 0, 0}; l2w.point(origin, L.pos);
+    L.n_samples = 1;
+    if (n == "point") {
+        // CreateLight lights/point.cpp:78-84 + PointLight ctor :49-54
+        Float3 I = ps.FindOneSpectrum("I", Float3{1.f, 1.f, 1.f});
+        Float3 P = ps.FindOnePoint("from", Float3{0, 0, 0});
+        Xform l2w = pbrthip::Translate(P.x, P.y, P.z) * ctm;
+        L.type = RT_LIGHT_POINT; L.color[0] = I.x; L.color[1] = I.y; L.color[2] = I.z;
+        const float origin[3] = {0, 0, 0}; l2w.point(origin, L.pos);
+    } else if (n == "spot") {
+        // CreateLight lights/spot.cpp:95-117 + SpotLight ctor :54-60
+        Float3 I = ps.FindOneSpectrum("I", Float3{1.f, 1.f, 1.f});
+        float coneangle = ps.FindOneFloat("coneangle", 30.f), conedelta = ps.FindOneFloat("conedeltaangle", 5.f);
+        Float3 from = ps.FindOnePoint("from", Float3{0, 0, 0}), to = ps.FindOnePoint("to", Float3{0, 0, 1});
+        float dx = to.x - from.x, dy = to.y - from.y, dz = to.z - from.z;
+        { float il = 1.f / std::sqrt(dx * dx + dy * dy + dz * dz); dx *= il; dy *= il; dz *= il; }       // Normalize
+        float ux, uy, uz;                                                                        // CoordinateSystem geometry.h:324-334
+        if (std::fabs(dx) > std::fabs(dy)) { float il = 1.f / std::sqrt(dx * dx + dz * dz); ux = -dz * il; uy = 0.f; uz = dx * il; }
+        else { float il = 1.f / std::sqrt(dy * dy + dz * dz); ux = 0.f; uy = dz * il; uz = -dy * il; }
+        float vx = (dy * uz) - (dz * uy), vy = (dz * ux) - (dx * uz), vz = (dx * uy) - (dy * ux);
+        Xform dirToZ(Mat4(ux, uy, uz, 0, vx, vy, vz, 0, dx, dy, dz, 0, 0, 0, 0, 1));
+        Xform l2w = ctm * pbrthip::Translate(from.x, from.y, from.z) * dirToZ.inverse();
+        L.type = RT_LIGHT_SPOT; L.color[0] = I.x; L.color[1] = I.y; L.color[2] = I.z;
+        const float origin[3] = {0, 0, 0}; l2w.point(origin, L.pos);
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) L.world_to_light[3 * r + c] = l2w.inv.m[r][c];   // Light::WorldToLight light.h:36
+        L.cos_total_width = cosf(pbrthip::radians(coneangle));
+        L.cos_falloff_start = cosf(pbrthip::radians(coneangle - conedelta));
+    } else if (n == "distant") {
+        // CreateLight lights/distant.cpp:94-101 + DistantLight ctor :51-56
+        Float3 Lr = ps.FindOneSpectrum("L", Float3{1.f, 1.f, 1.f});
+        Float3 from = ps.FindOnePoint("from", Float3{0, 0, 0}), to = ps.FindOnePoint("to", Float3{0, 0, 1});
+        const float x = from.x - to.x, y = from.y - to.y, z = from.z - to.z;
+        const Mat4 &m = ctm.m;                                                                   // Transform::operator()(Vector) transform.h:94-101
+        float wx = m.m[0][0] * x + m.m[0][1] * y + m.m[0][2] * z, wy = m.m[1][0] * x + m.m[1][1] * y + m.m[1][2] * z,
+              wz = m.m[2][0] * x + m.m[2][1] * y + m.m[2][2] * z;
+        float il = 1.f / std::sqrt(wx * wx + wy * wy + wz * wz);
+        L.type = RT_LIGHT_DISTANT; L.color[0] = Lr.x; L.color[1] = Lr.y; L.color[2] = Lr.z;
+        L.dir[0] = wx * il; L.dir[1] = wy * il; L.dir[2] = wz * il;
+    } else { Error("pbrtLightSource: light type \"%s\" unknown.", n.c_str()); return; }
+    ps.ReportUnused();
     lights.push_back(L);
 }
 

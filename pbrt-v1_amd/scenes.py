@@ -72,8 +72,10 @@ def cornell_world(soup: np.ndarray | None = None, soup_materials: bool = False,
                   point_light: bool = False, area_light: bool = True,
                   light_L=(17, 12, 4), light_nsamples: int = 1,
                   glass_sphere_tris: np.ndarray | None = None,
-                  mirror_quad: bool = False, volume: str | None = None) -> str:
+                  mirror_quad: bool = False, volume: str | None = None, extra: str = "") -> str:
     out = ["WorldBegin\n"]
+    if extra:
+        out.append(extra)
     if point_light:
         out.append('LightSource "point" "point from" [278 450 279.5] "color I" [400000 400000 400000]\n')
     for name, kd, verts in CORNELL_QUADS:

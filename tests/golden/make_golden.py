@@ -19,6 +19,12 @@ from pbrt_v1_amd import scenes
 OUT = os.path.dirname(os.path.abspath(__file__))
 blob = scenes.icosphere((200, 120, 250), 90, 1)
 
+SPOT = 'LightSource "spot" "point from" [278 540 100] "point to" [200 0 330] "color I" [600000 500000 400000] "float coneangle" [35] "float conedeltaangle" [12]\n'
+DISTANT = 'LightSource "distant" "point from" [0.3 1 -0.8] "point to" [0 0 0] "color L" [1.5 1.6 2.0]\n'
+SPOT_XF = ('AttributeBegin\nTranslate 30 0 10\nRotate 20 0 1 0\nLightSource "spot" "point from" [250 500 200] "point to" [300 0 300] "color I" [300000 300000 500000]\n'
+           'AttributeEnd\n')
+DISTANT_XF = 'AttributeBegin\nRotate -35 1 0 0.2\nScale 2 2 2\nLightSource "distant" "point from" [0 1 0] "point to" [0 0 0] "color L" [2 2 1.5]\nAttributeEnd\n'
+
 CONFIGS = {
     # name: cornell_scene kwargs  (all keyed RNG + counted rays)
     "whitted_point": dict(xres=48, yres=48, integrator="whitted", world_kwargs=dict(point_light=True, area_light=False)),
@@ -56,6 +62,13 @@ CONFIGS = {
                                     world_kwargs=dict(volume='"float g" [.3]', glass_sphere_tris=blob, point_light=True)),
     "vol_single_path_grid": dict(xres=24, yres=24, integrator="path", xsamples=2, ysamples=2, jitter=True, accelerator="grid",
                                  volume_integrator='"single" "float stepsize" [50]', world_kwargs=dict(volume='"color Le" [.001 .001 .001]')),
+    # spot and distant lights (also under a non-identity CTM)
+    "whitted_spot_distant": dict(xres=40, yres=40, integrator="whitted", world_kwargs=dict(area_light=False, extra=SPOT + DISTANT)),
+    "direct_spot_area": dict(xres=40, yres=40, integrator="directlighting", xsamples=2, ysamples=1, jitter=True, world_kwargs=dict(extra=SPOT_XF)),
+    "path_distant_spot_glass": dict(xres=32, yres=32, integrator="path", xsamples=2, ysamples=2, world_kwargs=dict(area_light=False, extra=SPOT + DISTANT_XF,
+                                                                                                              glass_sphere_tris=blob)),
+    "vol_single_spot": dict(xres=24, yres=24, integrator="whitted", volume_integrator='"single" "float stepsize" [60]',
+                            world_kwargs=dict(volume=' ', area_light=False, extra=SPOT)),
     "whitted_orennayar_triangle": dict(xres=32, yres=32, integrator="whitted", pixel_filter="triangle",
                                        world_kwargs=dict(point_light=True)),
 }
@@ -75,6 +88,12 @@ EDGE_SCENES = {   # degenerate inputs: empty world, a single triangle, zero-area
 
 
 def main():
+    only = set(sys.argv[1:])
+    if only:
+        for k in list(EDGE_SCENES):
+            if k not in only: del EDGE_SCENES[k]
+        for k in list(CONFIGS):
+            if k not in only: del CONFIGS[k]
     for name, text in EDGE_SCENES.items():
         rgb, alpha, st = pkg.run_reference(text, keyed=True)
         np.savez_compressed(os.path.join(OUT, name + ".npz"), scene=np.array(text), rgb=rgb, alpha=alpha, stats=np.array(json.dumps(st)))
@@ -87,7 +106,7 @@ def main():
         np.savez_compressed(os.path.join(OUT, name + ".npz"), scene=np.array(text), rgb=rgb, alpha=alpha, stats=np.array(json.dumps(st)))
         print(name, rgb.shape, "mean", float(rgb.mean()), {k: st[k] for k in ("closest_rays", "any_rays")}, st.get("stats", {}))
     # probe fixtures: camera rays + hits
-    for name, kw in {"probe_cornell": dict(xres=24, yres=24), "probe_soup3k_jitter": dict(xres=24, yres=24, soup_tris=3000, xsamples=2, ysamples=1, jitter=True),
+    for name, kw in {} if only else {"probe_cornell": dict(xres=24, yres=24), "probe_soup3k_jitter": dict(xres=24, yres=24, soup_tris=3000, xsamples=2, ysamples=1, jitter=True),
                      "probe_lens": dict(xres=16, yres=16, xsamples=2, ysamples=2, jitter=True, lensradius=4.0, focaldistance=700.0)}.items():
         d = tempfile.mkdtemp()
         dump = os.path.join(d, "rays.bin")
