@@ -59,12 +59,15 @@ typedef struct RtLight {
     float cos_total_width, cos_falloff_start;   /* spot.cpp:58-59 */
 } RtLight;
 
-/* ---- camera: core/camera.cpp:50-70, cameras/perspective.cpp:51-82 ---- */
+/* ---- camera: core/camera.cpp:50-70, cameras/perspective.cpp:51-82, orthographic.cpp:48-79, environment.cpp:47-61 ---- */
+enum { RT_CAMERA_PERSPECTIVE = 0, RT_CAMERA_ORTHOGRAPHIC = 1, RT_CAMERA_ENVIRONMENT = 2 };
 typedef struct RtCamera {
     float raster_to_camera[16]; /* row-major 4x4, as Matrix4x4::m (core/transform.h) */
     float camera_to_world[16];
     float lens_radius, focal_distance, hither, yon;
     float shutter_open, shutter_close;
+    int32_t type;                /* RT_CAMERA_*                                                        */
+    int32_t x_res, y_res;        /* film resolution (environment camera: theta/phi from imageY/imageX) */
 } RtCamera;
 
 /* ---- homogeneous medium: volumes/homogeneous.cpp:27-74 ---- */

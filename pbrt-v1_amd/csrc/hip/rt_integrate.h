@@ -169,12 +169,22 @@ RT_DEV void stratified_camera_sample(const DevFrame &fr, uint32_t pixel_index, i
     (void)pixel_index;
 }
 
-// PerspectiveCamera::GenerateRay cameras/perspective.cpp:51-82
+// {Perspective,Ortho,Environment}Camera::GenerateRay (cameras/perspective.cpp:51-82, orthographic.cpp:48-79,
+// environment.cpp:47-61)
 RT_DEV Ray camera_ray(const RtCamera &cam, float ix, float iy, float lensU, float lensV) {
-    V3 Pcamera = xform_point(cam.raster_to_camera, mk3(ix, iy, 0.f));
     Ray r;
+    if (cam.type == RT_CAMERA_ENVIRONMENT) {
+        r.o = xform_point(cam.camera_to_world, mk3(0.f, 0.f, 0.f));               // rayOrigin = CameraToWorld(Point(0,0,0))
+        const float theta = RT_PI * iy / cam.y_res;                               // M_PI is a float (pbrt.h:204); int -> float promotion
+        const float phi = 2 * RT_PI * ix / cam.x_res;
+        const V3 dir = mk3(sinf(theta) * cosf(phi), cosf(theta), sinf(theta) * sinf(phi));
+        r.d = xform_vector(cam.camera_to_world, dir);
+        r.mint = cam.hither; r.maxt = cam.yon;
+        return r;
+    }
+    V3 Pcamera = xform_point(cam.raster_to_camera, mk3(ix, iy, 0.f));
     r.o = Pcamera;
-    r.d = Pcamera;
+    r.d = cam.type == RT_CAMERA_ORTHOGRAPHIC ? mk3(0.f, 0.f, 1.f) : Pcamera;
     if (cam.lens_radius > 0.f) {
         float lu, lv; concentric_disk(lensU, lensV, lu, lv);
         lu *= cam.lens_radius; lv *= cam.lens_radius;
@@ -186,7 +196,7 @@ RT_DEV Ray camera_ray(const RtCamera &cam, float ix, float iy, float lensU, floa
     }
     r.d = normalize3(r.d);
     r.mint = 0.f;
-    r.maxt = (cam.yon - cam.hither) / r.d.z;
+    r.maxt = cam.type == RT_CAMERA_ORTHOGRAPHIC ? cam.yon - cam.hither : (cam.yon - cam.hither) / r.d.z;
     r.o = xform_point(cam.camera_to_world, r.o);
     r.d = xform_vector(cam.camera_to_world, r.d);
     return r;

@@ -195,7 +195,12 @@ Accelerator MakeAccelerator(const std::string &nameIn, const ParamSet &ps, bool 
 
 // ------------------------------------------------------------------ camera (perspective.cpp:83-115, camera.cpp:50-70)
 bool MakeCamera(const std::string &name, const ParamSet &ps, const Xform &world2cam, const Film &film, RtCamera *out) {
-    if (name != "perspective") { Error("Unable to load plugin \"%s\" (camera): only \"perspective\" is on the accelerated path", name.c_str()); return false; }
+    std::memset(out, 0, sizeof *out);
+    if (name == "perspective") out->type = RT_CAMERA_PERSPECTIVE;
+    else if (name == "orthographic") out->type = RT_CAMERA_ORTHOGRAPHIC;          // orthographic.cpp:80-112
+    else if (name == "environment") out->type = RT_CAMERA_ENVIRONMENT;            // environment.cpp:62-94
+    else { Error("Unable to load plugin \"%s\" (camera): \"perspective\", \"orthographic\" and \"environment\" are on the accelerated path", name.c_str()); return false; }
+    out->x_res = film.xResolution; out->y_res = film.yResolution;
     float hither = std::fmax(1e-4f, ps.FindOneFloat("hither", 1e-3f));
     float yon = std::fmin(ps.FindOneFloat("yon", 1e30f), 1e30f);
     float shutteropen = ps.FindOneFloat("shutteropen", 0.f);
@@ -208,9 +213,11 @@ bool MakeCamera(const std::string &name, const ParamSet &ps, const Xform &world2
     else { screen[0] = -1.f; screen[1] = 1.f; screen[2] = -1.f / frame; screen[3] = 1.f / frame; }
     int swi; const float *sw = ps.FindFloat("screenwindow", &swi);
     if (sw && swi == 4) std::memcpy(screen, sw, 4 * sizeof(float));
-    float fov = ps.FindOneFloat("fov", 90.);
+    float fov = out->type == RT_CAMERA_PERSPECTIVE ? ps.FindOneFloat("fov", 90.) : 90.f;
     ps.ReportUnused();
-    Xform cameraToScreen = Perspective(fov, hither, yon);
+    if (out->type == RT_CAMERA_ENVIRONMENT) lensradius = 0.f;                     // "(void) lensradius; // don't need this"
+    Xform cameraToScreen = out->type == RT_CAMERA_ORTHOGRAPHIC ? Scale(1.f, 1.f, 1.f / (yon - hither)) * Translate(0.f, 0.f, -hither)   // transform.cpp:177-180
+                                                               : Perspective(fov, hither, yon);
     Xform screenToRaster = Scale(float(film.xResolution), float(film.yResolution), 1.f) *
                            Scale(1.f / (screen[1] - screen[0]), 1.f / (screen[2] - screen[3]), 1.f) *
                            Translate(-screen[0], -screen[3], 0.f);

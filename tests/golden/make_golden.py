@@ -69,6 +69,11 @@ CONFIGS = {
                                                                                                               glass_sphere_tris=blob)),
     "vol_single_spot": dict(xres=24, yres=24, integrator="whitted", volume_integrator='"single" "float stepsize" [60]',
                             world_kwargs=dict(volume=' ', area_light=False, extra=SPOT)),
+    # orthographic / environment cameras: text substitution of the Camera line below
+    "ortho_whitted_lens": dict(xres=40, yres=32, integrator="whitted", xsamples=2, ysamples=1, jitter=True, lensradius=6.0, focaldistance=900.0),
+    "ortho_path": dict(xres=32, yres=32, integrator="path", xsamples=2, ysamples=2),
+    "env_whitted": dict(xres=48, yres=24, integrator="whitted", world_kwargs=dict(point_light=True)),
+    "env_path": dict(xres=32, yres=16, integrator="path", xsamples=2, ysamples=2, jitter=True),
     "whitted_orennayar_triangle": dict(xres=32, yres=32, integrator="whitted", pixel_filter="triangle",
                                        world_kwargs=dict(point_light=True)),
 }
@@ -100,6 +105,13 @@ def main():
         print(name, rgb.shape, "mean", float(rgb.mean()), {k: st[k] for k in ("closest_rays", "any_rays")})
     for name, kw in CONFIGS.items():
         text = scenes.cornell_scene(keyed=True, count=True, **kw)
+        if name.startswith("ortho_"):
+            text = text.replace('Camera "perspective" "float fov" [39.3]', 'Camera "orthographic" "float screenwindow" [-300 300 -290 290]')
+            assert "orthographic" in text
+        if name.startswith("env_"):
+            text = text.replace("LookAt 278 273 -800  278 273 0  0 1 0", "LookAt 278 273 200  278 273 600  0 1 0").replace(
+                'Camera "perspective" "float fov" [39.3]', 'Camera "environment"')
+            assert "environment" in text
         if name == "whitted_orennayar_triangle":
             text = text.replace('Material "matte" "color Kd" [0.73 0.73 0.73]', 'Material "matte" "color Kd" [0.73 0.73 0.73] "float sigma" [35]')
         rgb, alpha, st = pkg.run_reference(text, keyed=True)
