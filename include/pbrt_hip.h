@@ -33,14 +33,16 @@ extern "C" {
 
 typedef struct RtScene RtScene; /* opaque */
 
-/* ---- materials: materials/matte.cpp:46-64, glass.cpp:46-63, mirror.cpp:42-55 ---- */
-enum { RT_MAT_MATTE = 0, RT_MAT_MIRROR = 1, RT_MAT_GLASS = 2 };
+/* ---- materials: materials/matte.cpp:46-64, glass.cpp:46-63, mirror.cpp:42-55, plastic.cpp:47-69 ---- */
+enum { RT_MAT_MATTE = 0, RT_MAT_MIRROR = 1, RT_MAT_GLASS = 2, RT_MAT_PLASTIC = 3 };
 typedef struct RtMaterial {
     int32_t type;
-    float kd[3];   /* matte Kd  | mirror/glass Kr  (already .Clamp()'ed >= 0)   */
+    float kd[3];   /* matte/plastic Kd  | mirror/glass Kr  (already .Clamp()'ed >= 0) */
     float kt[3];   /* glass Kt                                                   */
     float sigma;   /* matte: Oren-Nayar sigma in degrees, clamped [0,90]; 0 = Lambertian */
     float ior;     /* glass "index"                                              */
+    float ks[3];   /* plastic Ks (.Clamp()'ed): Microfacet(Ks, FresnelDielectric(1.5, 1), Blinn(1/roughness)) */
+    float roughness; /* plastic "roughness"                                       */
 } RtMaterial;
 
 /* ---- lights: lights/point.cpp:49-69, lights/area.cpp:28-105, lights/spot.cpp:54-79, lights/distant.cpp:51-62 ---- */

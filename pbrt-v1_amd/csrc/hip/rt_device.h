@@ -16,6 +16,8 @@ struct DevMaterial {
     float on_a, on_b;  // Oren-Nayar A,B (reflection.h:268-277); on_b < 0 => Lambertian
     float ior;
     int has_r, has_t;  // glass.cpp:56-61: a lobe exists only if its colour is not black
+    float ks[3];       // plastic: Microfacet reflectance
+    float exponent;    // plastic: Blinn exponent = 1/roughness, capped at 1000 (reflection.h:313)
 };
 
 struct DevLight {

@@ -39,7 +39,7 @@ namespace rt {
 // MINW = minimum waves per SIMD the register allocator must make room for: 1 = natural allocation (~140 VGPRs, 3 waves/SIMD,
 // best when VALU-bound: tiny cache-resident scenes); 5 = cap at 96 VGPRs (spills to scratch) for 5 waves/SIMD, measured +20 %
 // on the memory-latency-bound 100k..1M-triangle scenes and -15 % on Cornell.
-template <bool COUNT, int INTEG, int ACCEL, bool VOL, int MINW>
+template <bool COUNT, int INTEG, int ACCEL, bool VOL, int MINW, bool GLOSSY>
 __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *__restrict__ scp,
                                                                        const DevFrame *__restrict__ frp) {
     __shared__ uint2 lds_stack[RT_STACK_LDS * RT_BLOCK];
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
         // ---- shade / regenerate: run every lane that is not waiting on a ray until it is (or is out of work)
         do {
             RT_PF(++pf_inner;)
-            advance_pass<COUNT, INTEG, VOL>(sc, fr, ln, gtid, &c_closest, &c_any, &c_bad, phase);
+            advance_pass<COUNT, INTEG, VOL, GLOSSY>(sc, fr, ln, gtid, &c_closest, &c_any, &c_bad, phase);
             const unsigned long long want = phase == 0 ? 0ull : __ballot(!ln.has_ray && ln.stage == ST_FETCH);
             if (want) {                                                   // wave-aggregated work fetch
                 const int leader = __ffsll((long long)want) - 1;
@@ -335,14 +335,20 @@ __global__ void camera_kernel(DevScene sc, DevFrame fr, unsigned long long first
 using namespace rt;
 
 // render_kernel instantiations, index = ((VOL*2 + ACCEL)*2 + COUNT)*3 + INTEG; +24..35: the high-occupancy flavour
-// (COUNT = false only), index = 24 + (VOL*2 + ACCEL)*3 + INTEG
+// (COUNT = false only), index = 24 + (VOL*2 + ACCEL)*3 + INTEG; +36..47: timed kernels with the glossy (plastic) lobes compiled
+// in, index = 36 + (VOL*2 + ACCEL)*3 + INTEG.  The counting twins always carry the glossy code (they are not timed); the
+// common timed kernels do not: powf and the second lobe cost ~17 VGPRs (path 150 -> 167, direct 176: one wave per SIMD less).
 typedef void (*RenderKernelFn)(const DevScene *, const DevFrame *);
-#define RT_K3(C, A, V, W) render_kernel<C, 0, A, V, W>, render_kernel<C, 1, A, V, W>, render_kernel<C, 2, A, V, W>
-static const RenderKernelFn g_render_kernels[36] = {
-    RT_K3(false, 0, false, RT_MIN_WAVES), RT_K3(true, 0, false, RT_MIN_WAVES), RT_K3(false, 1, false, RT_MIN_WAVES), RT_K3(true, 1, false, RT_MIN_WAVES),
-    RT_K3(false, 0, true, RT_MIN_WAVES),  RT_K3(true, 0, true, RT_MIN_WAVES),  RT_K3(false, 1, true, RT_MIN_WAVES),  RT_K3(true, 1, true, RT_MIN_WAVES),
-    RT_K3(false, 0, false, RT_HIGH_OCC_WAVES), RT_K3(false, 1, false, RT_HIGH_OCC_WAVES), RT_K3(false, 0, true, RT_HIGH_OCC_WAVES),
-    RT_K3(false, 1, true, RT_HIGH_OCC_WAVES)};
+#define RT_K3(C, A, V, W, G) render_kernel<C, 0, A, V, W, G>, render_kernel<C, 1, A, V, W, G>, render_kernel<C, 2, A, V, W, G>
+static const RenderKernelFn g_render_kernels[48] = {
+    RT_K3(false, 0, false, RT_MIN_WAVES, false), RT_K3(true, 0, false, RT_MIN_WAVES, true), RT_K3(false, 1, false, RT_MIN_WAVES, false),
+    RT_K3(true, 1, false, RT_MIN_WAVES, true),
+    RT_K3(false, 0, true, RT_MIN_WAVES, false),  RT_K3(true, 0, true, RT_MIN_WAVES, true),  RT_K3(false, 1, true, RT_MIN_WAVES, false),
+    RT_K3(true, 1, true, RT_MIN_WAVES, true),
+    RT_K3(false, 0, false, RT_HIGH_OCC_WAVES, false), RT_K3(false, 1, false, RT_HIGH_OCC_WAVES, false), RT_K3(false, 0, true, RT_HIGH_OCC_WAVES, false),
+    RT_K3(false, 1, true, RT_HIGH_OCC_WAVES, false),
+    RT_K3(false, 0, false, RT_MIN_WAVES, true), RT_K3(false, 1, false, RT_MIN_WAVES, true), RT_K3(false, 0, true, RT_MIN_WAVES, true),
+    RT_K3(false, 1, true, RT_MIN_WAVES, true)};
 #undef RT_K3
 
 static thread_local std::string g_err;
@@ -366,6 +372,7 @@ struct RtScene {
     KdTree tree;
     GridAccelData gridacc;
     int accel_kind = RT_ACCEL_KDTREE;
+    bool has_glossy = false;            // some material is plastic: use the kernels that carry the glossy lobes
     DevScene dev{};
     std::vector<void *> allocs;
     // film
@@ -376,7 +383,7 @@ struct RtScene {
     uint2 *spill = nullptr; size_t spill_entries = 0;
     float *frames = nullptr; size_t frames_floats = 0;
     unsigned grid = 0, n_threads = 0;
-    unsigned grids[36] = {0};          // resident grid per render_kernel<COUNT, INTEG> instantiation
+    unsigned grids[48] = {0};          // resident grid per render_kernel<COUNT, INTEG> instantiation
     DevScene *dev_scene = nullptr; DevFrame *dev_frame = nullptr;   // descriptors in HBM (read with scalar loads)
     float4 *samples = nullptr; size_t samples_cap = 0;          // per-shard sample buffer
     float ms_render = 0.f, ms_gather = 0.f; hipEvent_t ev2 = nullptr;
@@ -497,6 +504,10 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
         for (int c = 0; c < 3; ++c) { o.r[c] = m.kd[c]; o.t[c] = m.kt[c]; }
         o.has_r = (m.kd[0] != 0.f || m.kd[1] != 0.f || m.kd[2] != 0.f);
         o.has_t = (m.kt[0] != 0.f || m.kt[1] != 0.f || m.kt[2] != 0.f);
+        for (int c = 0; c < 3; ++c) o.ks[c] = m.ks[c];
+        o.exponent = 0.f;
+        if (m.type == RT_MAT_PLASTIC) { s->has_glossy = true; float e = 1.f / m.roughness; if (e > 1000.f || std::isnan(e)) e = 1000.f; o.exponent = e; }
+        if (m.type < RT_MAT_MATTE || m.type > RT_MAT_PLASTIC) return fail(RT_EINVAL, "rt_scene_create: unknown material type");
         if (m.type == RT_MAT_MATTE && m.sigma != 0.f) {
             float sigma = (3.14159265358979323846f / 180.f) * m.sigma;
             float sigma2 = sigma * sigma;
@@ -555,7 +566,7 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
     HIPCHK(hipGetDeviceProperties(&prop, s->device));
     {
         unsigned mx = 0;
-        for (int k = 0; k < 36; ++k) {
+        for (int k = 0; k < 48; ++k) {
             int per_cu = 0;
             HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)g_render_kernels[k], RT_BLOCK, 0));
             if (per_cu < 1) per_cu = 1;
@@ -875,6 +886,7 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
     fr.samples = s->samples;
     int variant = (((s->volume.present ? 1 : 0) * 2 + (s->accel_kind == RT_ACCEL_GRID ? 1 : 0)) * 2 + (s->counting ? 1 : 0)) * 3 + rd->integrator;
     if (fr.high_occupancy && !s->counting) variant = 24 + ((s->volume.present ? 1 : 0) * 2 + (s->accel_kind == RT_ACCEL_GRID ? 1 : 0)) * 3 + rd->integrator;
+    if (s->has_glossy && !s->counting) variant = 36 + ((s->volume.present ? 1 : 0) * 2 + (s->accel_kind == RT_ACCEL_GRID ? 1 : 0)) * 3 + rd->integrator;
     HIPCHK(hipMemcpyAsync(s->filter_dev, rd->filter_table, 256 * sizeof(float), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemcpyAsync(s->dev_frame, &fr, sizeof(DevFrame), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemsetAsync(s->work_counter, 0, sizeof(unsigned long long), s->stream));

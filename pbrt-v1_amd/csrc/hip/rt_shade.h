@@ -120,56 +120,122 @@ RT_DEV void concentric_disk(float u1, float u2, float &dx, float &dy) {
     dy = r * sinf(theta);
 }
 
+// Microfacet::f reflection.cpp:163-175 with Blinn::D (reflection.h:315-320), Microfacet::G (:293-301) and
+// FresnelDielectric(1.5, 1) (plastic.cpp:59-60)
+RT_DEV float min_std(float a, float b) { return (b < a) ? b : a; }            // std::min
+RT_DEV V3 microfacet_f(MatRef m, V3 wo, V3 wi) {
+    const float cosThetaO = fabsf(wo.z), cosThetaI = fabsf(wi.z);
+    if (cosThetaI == 0.f || cosThetaO == 0.f) return mk3(0.f);
+    V3 wh = wi + wo;
+    if (wh.x == 0.f && wh.y == 0.f && wh.z == 0.f) return mk3(0.f);
+    wh = normalize3(wh);
+    const float cosThetaH = dot3(wi, wh);
+    const float F = fresnel_dielectric(cosThetaH, 1.5f, 1.f);
+    const float D = (m.exponent + 2) * RT_INV_TWOPI * powf(fabsf(wh.z), m.exponent);
+    const float NdotWh = fabsf(wh.z), NdotWo = fabsf(wo.z), NdotWi = fabsf(wi.z), WOdotWh = absdot3(wo, wh);
+    const float G = min_std(1.f, min_std((2.f * NdotWh * NdotWo / WOdotWh), (2.f * NdotWh * NdotWi / WOdotWh)));
+    return div_s(((mat_color(m.ks) * D) * G) * mk3(F), 4.f * cosThetaI * cosThetaO);
+}
+// Blinn::Pdf reflection.cpp:263-272
+RT_DEV float blinn_pdf(float exponent, V3 wo, V3 wi) {
+    const V3 H = normalize3(wo + wi);
+    const float costheta = fabsf(H.z);
+    float p = ((exponent + 1.f) * powf(costheta, exponent)) / (2.f * RT_PI * 4.f * dot3(wo, H));
+    if (dot3(wo, H) <= 0.f) p = 0.f;
+    return p;
+}
+// BxDF::Pdf of the two non-specular lobes: reflection.cpp:227-230 (cosine) and Microfacet::Pdf :241-245
+RT_DEV float diffuse_pdf(V3 wo, V3 wi) { return (wo.z * wi.z > 0.f) ? fabsf(wi.z) * RT_INV_PI : 0.f; }
+RT_DEV float glossy_pdf(MatRef m, V3 wo, V3 wi) { return (wo.z * wi.z > 0.f) ? blinn_pdf(m.exponent, wo, wi) : 0.f; }
+
+// lobes in the order the material adds them: matte {diffuse}; plastic {diffuse, glossy} (plastic.cpp:66-67);
+// mirror {specular R}; glass {specular R, specular T} (glass.cpp:56-61, only the non-black ones)
+template <bool GLOSSY>
 RT_DEV int bsdf_num_components(MatRef m, int flags) {
     int n = 0;
-    if (m.type == RT_MAT_MATTE) { if (((BX_REFLECTION | BX_DIFFUSE) & flags) == (BX_REFLECTION | BX_DIFFUSE)) ++n; }
-    else {
+    if (m.type == RT_MAT_MATTE || (GLOSSY && m.type == RT_MAT_PLASTIC)) {
+        if (((BX_REFLECTION | BX_DIFFUSE) & flags) == (BX_REFLECTION | BX_DIFFUSE)) ++n;
+        if (GLOSSY && m.type == RT_MAT_PLASTIC && ((BX_REFLECTION | BX_GLOSSY) & flags) == (BX_REFLECTION | BX_GLOSSY)) ++n;
+    } else {
         if (m.has_r && ((BX_REFLECTION | BX_SPECULAR) & flags) == (BX_REFLECTION | BX_SPECULAR)) ++n;
         if (m.type == RT_MAT_GLASS && m.has_t && ((BX_TRANSMISSION | BX_SPECULAR) & flags) == (BX_TRANSMISSION | BX_SPECULAR)) ++n;
     }
     return n;
 }
-RT_DEV int bsdf_total_components(MatRef m) { return bsdf_num_components(m, BX_ALL); }
+template <bool GLOSSY> RT_DEV int bsdf_total_components(MatRef m) { return bsdf_num_components<GLOSSY>(m, BX_ALL); }
 
-// BSDF::f reflection.cpp:480-494 (flags = BSDF_ALL): only the diffuse lobe has a non-zero f
+// sum of f over the non-specular reflection lobes matching `flags`, in lobe order (BSDF::f's loop, reflection.cpp:489-492)
+template <bool GLOSSY>
+RT_DEV V3 bsdf_f_lobes(MatRef m, V3 wo, V3 wi, int flags) {
+    V3 f = mk3(0.f);
+    if (((BX_REFLECTION | BX_DIFFUSE) & flags) == (BX_REFLECTION | BX_DIFFUSE)) f = f + diffuse_f(m, wo, wi);
+    if (GLOSSY && m.type == RT_MAT_PLASTIC && ((BX_REFLECTION | BX_GLOSSY) & flags) == (BX_REFLECTION | BX_GLOSSY)) f = f + microfacet_f(m, wo, wi);
+    return f;
+}
+
+// BSDF::f reflection.cpp:480-494 (flags = BSDF_ALL): only the non-specular lobes have a non-zero f
+template <bool GLOSSY>
 RT_DEV V3 bsdf_f(MatRef m, const Vertex &v, V3 woW, V3 wiW) {
-    if (m.type != RT_MAT_MATTE) return mk3(0.f);
+    if (m.type != RT_MAT_MATTE && !(GLOSSY && m.type == RT_MAT_PLASTIC)) return mk3(0.f);
     V3 wi = to_local(v, wiW), wo = to_local(v, woW);
-    if (dot3(wiW, v.nn) * dot3(woW, v.nn) > 0) return mk3(0.f) + diffuse_f(m, wo, wi);   // BRDFs only
-    return mk3(0.f);                                                                    // BTDFs only: none
+    if (dot3(wiW, v.nn) * dot3(woW, v.nn) > 0) return bsdf_f_lobes<GLOSSY>(m, wo, wi, BX_ALL & ~BX_TRANSMISSION);   // BRDFs only
+    return mk3(0.f);                                                                                         // BTDFs only: none
 }
 
 // BSDF::Pdf reflection.cpp:458-470 (flags = BSDF_ALL)
+template <bool GLOSSY>
 RT_DEV float bsdf_pdf(MatRef m, const Vertex &v, V3 woW, V3 wiW) {
-    int nc = bsdf_total_components(m);
+    int nc = bsdf_total_components<GLOSSY>(m);
     if (nc == 0) return 0.f;
-    if (m.type != RT_MAT_MATTE) return 0.f / float(nc);
+    if (m.type != RT_MAT_MATTE && !(GLOSSY && m.type == RT_MAT_PLASTIC)) return 0.f / float(nc);
     V3 wo = to_local(v, woW), wi = to_local(v, wiW);
     float pdf = 0.f;
-    pdf += (wo.z * wi.z > 0.f) ? fabsf(wi.z) * RT_INV_PI : 0.f;      // BxDF::Pdf reflection.cpp:227-230
+    pdf += diffuse_pdf(wo, wi);
+    if (GLOSSY && m.type == RT_MAT_PLASTIC) pdf += glossy_pdf(m, wo, wi);
     return pdf / nc;
 }
 
 // BSDF::Sample_f reflection.cpp:402-457.  Returns f; pdf == 0 means "no sample".
+template <bool GLOSSY>
 RT_DEV V3 bsdf_sample_f(MatRef m, const Vertex &v, V3 woW, V3 &wiW, float u1, float u2, float u3,
                         float &pdf, int flags, int &sampled) {
     sampled = 0; pdf = 0.f;
-    int matching = bsdf_num_components(m, flags);
+    int matching = bsdf_num_components<GLOSSY>(m, flags);
     if (matching == 0) return mk3(0.f);
     int which = min(int(floorf(u3 * matching)), matching - 1);     // Floor2Int(double(u3*matching))
     V3 wo = to_local(v, woW);
     V3 wi, f;
-    if (m.type == RT_MAT_MATTE) {
-        // BxDF::Sample_f reflection.cpp:219-226 with CosineSampleHemisphere mc.h:38-44
-        float dx, dy; concentric_disk(u1, u2, dx, dy);
-        wi = mk3(dx, dy, sqrtf(fmaxf(0.f, 1.f - dx * dx - dy * dy)));
-        if (wo.z < 0.f) wi.z *= -1.f;
-        pdf = (wo.z * wi.z > 0.f) ? fabsf(wi.z) * RT_INV_PI : 0.f;
-        if (pdf == 0.f) return mk3(0.f);
-        sampled = BX_REFLECTION | BX_DIFFUSE;
+    if (m.type == RT_MAT_MATTE || (GLOSSY && m.type == RT_MAT_PLASTIC)) {
+        const bool diffuse_has = ((BX_REFLECTION | BX_DIFFUSE) & flags) == (BX_REFLECTION | BX_DIFFUSE);
+        const bool glossy_has = GLOSSY && m.type == RT_MAT_PLASTIC && ((BX_REFLECTION | BX_GLOSSY) & flags) == (BX_REFLECTION | BX_GLOSSY);
+        const bool pick_diffuse = !GLOSSY || (diffuse_has && which == 0);
+        if (pick_diffuse) {
+            // BxDF::Sample_f reflection.cpp:219-226 with CosineSampleHemisphere mc.h:38-44
+            float dx, dy; concentric_disk(u1, u2, dx, dy);
+            wi = mk3(dx, dy, sqrtf(fmaxf(0.f, 1.f - dx * dx - dy * dy)));
+            if (wo.z < 0.f) wi.z *= -1.f;
+            pdf = diffuse_pdf(wo, wi);
+            if (pdf == 0.f) return mk3(0.f);
+            sampled = BX_REFLECTION | BX_DIFFUSE;
+            if (glossy_has) pdf += glossy_pdf(m, wo, wi);                        // the other matching lobe, :436-443
+        } else {
+            // Microfacet::Sample_f reflection.cpp:235-240 with Blinn::Sample_f :246-262
+            const float costheta = powf(u1, 1.f / (m.exponent + 1));
+            const float sintheta = sqrtf(fmaxf(0.f, 1.f - costheta * costheta));
+            const float phi = u2 * 2.f * RT_PI;
+            V3 H = mk3(sintheta * cosf(phi), sintheta * sinf(phi), costheta);
+            if (!(wo.z * H.z > 0.f)) H = -H;
+            wi = -wo + H * (2.f * dot3(wo, H));
+            pdf = ((m.exponent + 1.f) * powf(costheta, m.exponent)) / (2.f * RT_PI * 4.f * dot3(wo, H));
+            if (dot3(wo, H) <= 0.f) pdf = 0.f;
+            if (pdf == 0.f) return mk3(0.f);
+            sampled = BX_REFLECTION | BX_GLOSSY;
+            if (diffuse_has) pdf += diffuse_pdf(wo, wi);
+        }
         wiW = to_world(v, wi);
+        if (matching > 1) pdf /= matching;
         f = mk3(0.f);
-        if (dot3(wiW, v.nn) * dot3(woW, v.nn) > 0) f = f + diffuse_f(m, wo, wi);
+        if (dot3(wiW, v.nn) * dot3(woW, v.nn) > 0) f = bsdf_f_lobes<GLOSSY>(m, wo, wi, flags & ~BX_TRANSMISSION);
         return f;
     }
     // specular lobes, in the order the material added them (glass.cpp:56-61, mirror.cpp:51-53)

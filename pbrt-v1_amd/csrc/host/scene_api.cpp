@@ -382,7 +382,7 @@ int PbrtApi::makeMaterial(const ParamSet &shapeParams) {
     auto clamp0 = [](Float3 c) { Float3 r = {c.x < 0.f ? 0.f : c.x, c.y < 0.f ? 0.f : c.y, c.z < 0.f ? 0.f : c.z}; return r; };
     RtMaterial m; std::memset(&m, 0, sizeof m);
     std::string name = gs.material;
-    if (name != "matte" && name != "mirror" && name != "glass") {
+    if (name != "matte" && name != "mirror" && name != "glass" && name != "plastic") {
         Error("Unable to load plugin \"%s\" (material); using \"matte\" (api.cpp:376-379)", name.c_str());
         name = "matte";
     }
@@ -393,6 +393,11 @@ int PbrtApi::makeMaterial(const ParamSet &shapeParams) {
         Float3 kd = clamp0(spectrumParam(shapeParams, mp, "Kd", Float3{1.f, 1.f, 1.f}));
         float sig = floatParam(shapeParams, mp, "sigma", 0.f); sig = sig < 0.f ? 0.f : (sig > 90.f ? 90.f : sig);
         m.type = RT_MAT_MATTE; m.kd[0] = kd.x; m.kd[1] = kd.y; m.kd[2] = kd.z; m.sigma = sig; m.ior = 1.f;
+    } else if (name == "plastic") {                                                 // plastic.cpp:47-77
+        Float3 kd = clamp0(spectrumParam(shapeParams, mp, "Kd", Float3{1.f, 1.f, 1.f}));
+        Float3 ks = clamp0(spectrumParam(shapeParams, mp, "Ks", Float3{1.f, 1.f, 1.f}));
+        m.type = RT_MAT_PLASTIC; m.kd[0] = kd.x; m.kd[1] = kd.y; m.kd[2] = kd.z; m.ks[0] = ks.x; m.ks[1] = ks.y; m.ks[2] = ks.z;
+        m.roughness = floatParam(shapeParams, mp, "roughness", .1f); m.ior = 1.f;
     } else if (name == "mirror") {                                                  // mirror.cpp:42-61
         Float3 kr = clamp0(spectrumParam(shapeParams, mp, "Kr", Float3{1.f, 1.f, 1.f}));
         m.type = RT_MAT_MIRROR; m.kd[0] = kr.x; m.kd[1] = kr.y; m.kd[2] = kr.z; m.ior = 1.f;

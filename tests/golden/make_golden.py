@@ -69,6 +69,10 @@ CONFIGS = {
                                                                                                               glass_sphere_tris=blob)),
     "vol_single_spot": dict(xres=24, yres=24, integrator="whitted", volume_integrator='"single" "float stepsize" [60]',
                             world_kwargs=dict(volume=' ', area_light=False, extra=SPOT)),
+    # plastic (Lambertian + Blinn microfacet lobes): text substitution of two Material lines below
+    "plastic_whitted": dict(xres=40, yres=40, integrator="whitted", world_kwargs=dict(point_light=True)),
+    "plastic_direct_ns2": dict(xres=32, yres=32, integrator="directlighting", xsamples=2, ysamples=1, jitter=True, world_kwargs=dict(light_nsamples=2)),
+    "plastic_path": dict(xres=32, yres=32, integrator="path", xsamples=2, ysamples=2, jitter=True, world_kwargs=dict(glass_sphere_tris=blob)),
     # orthographic / environment cameras: text substitution of the Camera line below
     "ortho_whitted_lens": dict(xres=40, yres=32, integrator="whitted", xsamples=2, ysamples=1, jitter=True, lensradius=6.0, focaldistance=900.0),
     "ortho_path": dict(xres=32, yres=32, integrator="path", xsamples=2, ysamples=2),
@@ -105,6 +109,10 @@ def main():
         print(name, rgb.shape, "mean", float(rgb.mean()), {k: st[k] for k in ("closest_rays", "any_rays")})
     for name, kw in CONFIGS.items():
         text = scenes.cornell_scene(keyed=True, count=True, **kw)
+        if name.startswith("plastic_"):
+            text = text.replace('Material "matte" "color Kd" [0.73 0.73 0.73]', 'Material "plastic" "color Kd" [0.5 0.5 0.55] "color Ks" [0.4 0.4 0.4] "float roughness" [0.08]')
+            text = text.replace('Material "matte" "color Kd" [0.14 0.45 0.091]', 'Material "plastic" "color Kd" [0.1 0.4 0.1] "color Ks" [0.6 0.5 0.5] "float roughness" [0.3]')
+            assert text.count('"plastic"') >= 2, text[:2000]
         if name.startswith("ortho_"):
             text = text.replace('Camera "perspective" "float fov" [39.3]', 'Camera "orthographic" "float screenwindow" [-300 300 -290 290]')
             assert "orthographic" in text
