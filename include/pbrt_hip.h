@@ -90,6 +90,17 @@ typedef struct RtAccelParams {
     int32_t build_threads;                                /* 0 = auto                  */
 } RtAccelParams;
 
+/* ---- quadrics: shapes/sphere.cpp:89-215.  A quadric is ONE primitive of the accelerator
+ * (Shape::CanIntersect, primitive.cpp:40-53).  In the primitive arrays below it occupies one slot whose tri_verts
+ * hold its world bound as a degenerate triangle {pMin, pMax, pMin} (Shape::WorldBound shape.h:57-59) and whose
+ * tri_flags has bit1 set; the k-th such slot is quadrics[k]. ---- */
+enum { RT_QUADRIC_SPHERE = 0 };
+typedef struct RtQuadric {
+    int32_t type;
+    float object_to_world[16], world_to_object[16]; /* Transform::m / ::mInv, row-major                      */
+    float radius, zmin, zmax, theta_min, theta_max, phi_max; /* as the Sphere ctor stores them (sphere.cpp:89-99) */
+} RtQuadric;
+
 /* Scene description = what MakeScene hands to Scene::Scene (core/scene.cpp:100-119),
  * flattened.  Triangles are in the order KdTreeAccel's FullyRefine produces
  * (kdtree.cpp:146-148: per mesh, last triangle first). Vertices are world space
@@ -99,7 +110,7 @@ typedef struct RtSceneDesc {
     const float *tri_verts;       /* [n_tris][9]  p1 p2 p3                                   */
     const uint16_t *tri_material; /* [n_tris] index into materials                             */
     const int32_t *tri_light;     /* [n_tris] area-light index (GetAreaLight) or -1           */
-    const uint8_t *tri_flags;     /* [n_tris] bit0 = flip geometric normal (shape.cpp:49-50)   */
+    const uint8_t *tri_flags;     /* [n_tris] bit0 = flip geometric normal (shape.cpp:49-50), bit1 = quadric slot */
     uint32_t n_materials;
     const RtMaterial *materials;
     uint32_t n_lights;
@@ -109,6 +120,8 @@ typedef struct RtSceneDesc {
     RtCamera camera;
     RtVolume volume;
     RtAccelParams accel;
+    uint32_t n_quadrics;          /* may be 0 / NULL                                           */
+    const RtQuadric *quadrics;
 } RtSceneDesc;
 
 /* ---- per-frame description ---- */

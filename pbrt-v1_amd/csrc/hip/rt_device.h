@@ -8,6 +8,13 @@ namespace rt {
 // One triangle = three 16-byte vectors (48 B, one 128-B line holds 2.67 of them):
 //   q0 = p1.x p1.y p1.z p2.x | q1 = p2.y p2.z p3.x p3.y | q2 = p3.z, bits(material | flags<<16), bits(light), 0
 struct DevTri { float4 q0, q1, q2; };
+// a quadric occupies one primitive slot: bits has RT_PRIM_QUADRIC set and q0.x holds the index into DevScene::quadrics
+#define RT_PRIM_QUADRIC (1u << 17)
+struct DevQuadric {          // Sphere (shapes/sphere.cpp:89-99): transforms as Transform::m / ::mInv, row-major
+    float w2o[16], o2w[16];
+    float radius, zmin, zmax, theta_min, theta_max, phi_max;
+    int type, pad;
+};
 
 struct DevMaterial {
     int type;
@@ -38,6 +45,7 @@ struct DimReq { unsigned f_base, u_base; unsigned short n; unsigned short dims; 
 
 struct DevScene {
     const DevTri *tris;
+    const DevQuadric *quadrics;  // read only by the EXT kernels
     const float4 *tri_shade;   // per triangle 2 x float4, read once per HIT: {nn.xyz, material|flip<<16} {sn.xyz, area-light index}:
                                // the geometric normal and BSDF tangent are constants of the triangle, precomputed on the host with
                                // the reference's expressions (rt_shade.h tri_frame) instead of two normalisations per vertex
@@ -68,6 +76,7 @@ struct DevFrame {
     float *accum;                // 5 planes
     float4 *samples;             // per-shard sample buffer, 2 x float4 per work item
     int shard_index, shard_count, tile_pixels;
+    int dbg_x, dbg_y;            // -DRT_DEBUG_PIXEL builds: print the vertices of the samples of this pixel
     int exit_thresh;             // leave the shared traversal loop when <= this many lanes still traverse (0 = never)
     int phase_sync;             // path integrator: alternate the two halves of the state machine between sweeps (rt_integrate.h)
     int high_occupancy;          // host-side choice of the 5-waves/SIMD kernel flavour (not read by the device)

@@ -341,14 +341,14 @@ RT_DEV V3 scene_transmittance(const DevScene &sc, Lane &ln, V3 o, V3 d, float mi
 
 // ---- EstimateDirect (core/transport.cpp:123-194), split at its two ray casts ------------------------------
 // BSDF-sampling half; returns with either a MIS ray in flight (ST_MIS_DONE) or ST_ED_DONE.
-template <bool GLOSSY>
+template <bool EXT>
 RT_DEV void estimate_direct_bsdf(const DevScene &sc, Lane &ln) {
     LightRef Lt = RT_LIGHT(sc, ln.cur_light);
     ln.stage = ST_ED_DONE;
     if (light_is_delta(Lt)) return;                                             // IsDeltaLight()
     MatRef m = RT_MAT(sc, ln.v.mat);
     V3 wi; float bsdfPdf; int sampled;
-    V3 f = bsdf_sample_f<GLOSSY>(m, ln.v, ln.v.wo, wi, ln.bs1, ln.bs2, ln.bcs, bsdfPdf, BX_ALL & ~BX_SPECULAR, sampled);
+    V3 f = bsdf_sample_f<EXT>(m, ln.v, ln.v.wo, wi, ln.bs1, ln.bs2, ln.bcs, bsdfPdf, BX_ALL & ~BX_SPECULAR, sampled);
     if (!is_black(f) && bsdfPdf > 0.f) {
         float lightPdf = area_light_pdf(sc, Lt, ln.v.p, wi);
         if (lightPdf > 0.f) {
@@ -362,7 +362,7 @@ RT_DEV void estimate_direct_bsdf(const DevScene &sc, Lane &ln) {
 }
 
 // light-sampling half
-template <bool GLOSSY>
+template <bool EXT>
 RT_DEV void estimate_direct_begin(const DevScene &sc, Lane &ln, int light, float ls1, float ls2) {
     ln.cur_light = light;
     ln.Ld = mk3(0.f);
@@ -381,11 +381,11 @@ RT_DEV void estimate_direct_begin(const DevScene &sc, Lane &ln, int light, float
         sd = ps - ln.v.p; smax = 1.f - RT_RAY_EPSILON;
     }
     if (lightPdf > 0.f && !is_black(Li)) {
-        V3 f = bsdf_f<GLOSSY>(m, ln.v, ln.v.wo, wi);
+        V3 f = bsdf_f<EXT>(m, ln.v, ln.v.wo, wi);
         if (!is_black(f)) {
             if (light_is_delta(Lt)) ln.pend = div_s((f * Li) * absdot3(wi, ln.v.nn), lightPdf);
             else {
-                float bsdfPdf = bsdf_pdf<GLOSSY>(m, ln.v, ln.v.wo, wi);
+                float bsdfPdf = bsdf_pdf<EXT>(m, ln.v, ln.v.wo, wi);
                 float fw = 1 * lightPdf, gw = 1 * bsdfPdf;
                 float weight = (fw * fw) / (fw * fw + gw * gw);
                 ln.pend = div_s(((f * Li) * absdot3(wi, ln.v.nn)) * weight, lightPdf);
@@ -399,7 +399,7 @@ RT_DEV void estimate_direct_begin(const DevScene &sc, Lane &ln, int light, float
 }
 
 // The body of ONE stage.  Returns when the lane has a ray in flight or has changed stage.
-template <bool COUNT, int INTEG, bool VOL, bool GLOSSY, int STAGE>
+template <bool COUNT, int INTEG, bool VOL, bool EXT, int STAGE>
 RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigned gtid,
                        unsigned *c_closest, unsigned *c_any, unsigned *c_bad) {
     if constexpr (STAGE == ST_VERTEX) {
@@ -410,7 +410,12 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
                 if (ln.depth == 0) ln.alpha = (ln.L.x != 0.f || ln.L.y != 0.f || ln.L.z != 0.f) ? 1.f : 0.f;
                 ln.stage = ST_RETURN; return;
             }
-            make_vertex(sc, ln.tv, ln.v);
+            make_vertex<EXT>(sc, ln.tv, ln.v);
+#ifdef RT_DEBUG_PIXEL
+            if (int(floorf(ln.image_x)) == fr.dbg_x && int(floorf(ln.image_y)) == fr.dbg_y)
+                printf("DEV depth %d prim %d t %.9g o %.9g %.9g %.9g d %.9g %.9g %.9g p %.9g %.9g %.9g nn %.9g %.9g %.9g sn %.9g %.9g %.9g\n", ln.depth, ln.tv.hit_prim, ln.tv.maxt,
+                       ln.tv.o.x, ln.tv.o.y, ln.tv.o.z, ln.tv.d.x, ln.tv.d.y, ln.tv.d.z, ln.v.p.x, ln.v.p.y, ln.v.p.z, ln.v.nn.x, ln.v.nn.y, ln.v.nn.z, ln.v.sn.x, ln.v.sn.y, ln.v.sn.z);
+#endif
             if (ln.depth == 0) { ln.alpha = 1.f; if (VOL) vol_ray_ptr(fr, 0, gtid)[7 * size_t(fr.n_threads)] = ln.tv.maxt; }   // r.maxt = ray.maxt
             else if (VOL) ln.thr = ln.thr * scene_transmittance<VOL>(sc, ln, ln.tv.o, ln.tv.d, ln.tv.mint, ln.tv.maxt);           // path.cpp:89
             if ((ln.depth == 0 || ln.specular) && ln.v.light >= 0)              // path.cpp:91-92
@@ -421,7 +426,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
                 if (ln.depth == 0) ln.alpha = 0.f;
                 ln.stage = ST_RETURN; return;
             }
-            make_vertex(sc, ln.tv, ln.v);
+            make_vertex<EXT>(sc, ln.tv, ln.v);
             if (ln.depth == 0) ln.alpha = 1.f;
             if (VOL) vol_ray_ptr(fr, ln.fsp, gtid)[7 * size_t(fr.n_threads)] = ln.tv.maxt;       // the hit shortens this level's ray
             ln.L = mk3(0.f);
@@ -453,7 +458,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
                 ln.bs1 = ln.rng.next_float(); ln.bs2 = ln.rng.next_float(); ln.bcs = ln.rng.next_float();
             }
             int lightNum = min(int(floorf(un * nLights)), nLights - 1);
-            estimate_direct_begin<GLOSSY>(sc, ln, lightNum, ls1, ls2);
+            estimate_direct_begin<EXT>(sc, ln, lightNum, ls1, ls2);
             return;
         }
         if (INTEG == RT_INTEGRATOR_DIRECT) {
@@ -464,7 +469,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
             const float ls1 = dim_value(fr, ln, rl, ln.lj, 0), ls2 = dim_value(fr, ln, rl, ln.lj, 1);
             ln.bs1 = dim_value(fr, ln, rb, ln.lj, 0); ln.bs2 = dim_value(fr, ln, rb, ln.lj, 1);
             ln.bcs = dim_value(fr, ln, rc, ln.lj, 0);
-            estimate_direct_begin<GLOSSY>(sc, ln, ln.li, ls1, ls2);
+            estimate_direct_begin<EXT>(sc, ln, ln.li, ls1, ls2);
             return;
         }
         // Whitted: one sample per light, unweighted (whitted.cpp:73-81)
@@ -486,7 +491,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
             }
             (void)cur;
             if (is_black(Li)) return;
-            V3 f = bsdf_f<GLOSSY>(m, ln.v, ln.v.wo, wi);
+            V3 f = bsdf_f<EXT>(m, ln.v, ln.v.wo, wi);
             if (is_black(f)) return;
             ln.pend = (f * Li) * absdot3(wi, ln.v.nn);
             launch_ray(ln, sc, ln.v.p, sd, RT_RAY_EPSILON, smax, true, ST_SHADOW_DONE);
@@ -506,7 +511,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
         return;
     }
     if constexpr (STAGE == ST_ED_BSDF) {
-        estimate_direct_bsdf<GLOSSY>(sc, ln);
+        estimate_direct_bsdf<EXT>(sc, ln);
         return;
     }
     if constexpr (STAGE == ST_MIS_DONE) {
@@ -550,7 +555,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
             bcs = dim_value(fr, ln, fr.one_d[3 * k + 2], 0, 0);
         } else { bs1 = ln.rng.next_float(); bs2 = ln.rng.next_float(); bcs = ln.rng.next_float(); }
         V3 wi; float pdf; int flags;
-        V3 f = bsdf_sample_f<GLOSSY>(m, ln.v, ln.v.wo, wi, bs1, bs2, bcs, pdf, BX_ALL, flags);
+        V3 f = bsdf_sample_f<EXT>(m, ln.v, ln.v.wo, wi, bs1, bs2, bcs, pdf, BX_ALL, flags);
         if (is_black(f) || pdf == 0.f) { ln.stage = ST_RETURN; return; }
         ln.specular = (flags & BX_SPECULAR) != 0;
         ln.thr = ln.thr * div_s(f * absdot3(wi, ln.v.nn), pdf);
@@ -568,7 +573,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
         MatRef m = RT_MAT(sc, ln.v.mat);
         float u3 = ln.rng.next_float(), u2 = ln.rng.next_float(), u1 = ln.rng.next_float();
         V3 wi; float pdf; int flags;
-        V3 f = bsdf_sample_f<GLOSSY>(m, ln.v, ln.v.wo, wi, u1, u2, u3, pdf, BX_REFLECTION | BX_SPECULAR, flags);
+        V3 f = bsdf_sample_f<EXT>(m, ln.v, ln.v.wo, wi, u1, u2, u3, pdf, BX_REFLECTION | BX_SPECULAR, flags);
         if (!is_black(f) && pdf > 0.f) f = div_s(f, pdf);                       // reflection.cpp:399
         const float ad = absdot3(wi, ln.v.nn);
         if (!is_black(f) && ad > 0.f) {
@@ -585,7 +590,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
         MatRef m = RT_MAT(sc, ln.v.mat);
         float u3 = ln.rng.next_float(), u2 = ln.rng.next_float(), u1 = ln.rng.next_float();
         V3 wi; float pdf; int flags;
-        V3 f = bsdf_sample_f<GLOSSY>(m, ln.v, ln.v.wo, wi, u1, u2, u3, pdf, BX_TRANSMISSION | BX_SPECULAR, flags);
+        V3 f = bsdf_sample_f<EXT>(m, ln.v, ln.v.wo, wi, u1, u2, u3, pdf, BX_TRANSMISSION | BX_SPECULAR, flags);
         if (!is_black(f) && pdf > 0.f) f = div_s(f, pdf);
         const float ad = absdot3(wi, ln.v.nn);
         if (!is_black(f) && ad > 0.f) {
@@ -718,15 +723,15 @@ RT_DEV bool stage_in_phase(int stage, int phase) {
     const bool first = stage == ST_VERTEX || stage == ST_DIRECT_NEXT;
     return phase == 0 ? first : !first;
 }
-template <bool COUNT, int INTEG, bool VOL, bool GLOSSY>
+template <bool COUNT, int INTEG, bool VOL, bool EXT>
 RT_DEV void advance_pass(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigned gtid,
                          unsigned *c_closest, unsigned *c_any, unsigned *c_bad, int phase) {
 #ifdef RT_PROFILE_STAGES
 #define RT_RUN(S) { const unsigned long long m_ = __ballot(!ln.has_ray && ln.stage == S); if (m_) { const unsigned long long t_ = __builtin_readcyclecounter(); \
-        if (!ln.has_ray && ln.stage == S) stage_body<COUNT, INTEG, VOL, GLOSSY, S>(sc, fr, ln, gtid, c_closest, c_any, c_bad); \
+        if (!ln.has_ray && ln.stage == S) stage_body<COUNT, INTEG, VOL, EXT, S>(sc, fr, ln, gtid, c_closest, c_any, c_bad); \
         if (__lane_id() == 0) { atomicAdd(&g_pf_stage[2 * S], __builtin_readcyclecounter() - t_); atomicAdd(&g_pf_stage[2 * S + 1], (unsigned long long)__popcll(m_) | (1ull << 40)); } } }
 #else
-#define RT_RUN(S) if (!ln.has_ray && ln.stage == S) stage_body<COUNT, INTEG, VOL, GLOSSY, S>(sc, fr, ln, gtid, c_closest, c_any, c_bad)
+#define RT_RUN(S) if (!ln.has_ray && ln.stage == S) stage_body<COUNT, INTEG, VOL, EXT, S>(sc, fr, ln, gtid, c_closest, c_any, c_bad)
 #endif
     if (phase != 0) {
         RT_RUN(ST_MIS_DONE);

@@ -39,7 +39,7 @@ namespace rt {
 // MINW = minimum waves per SIMD the register allocator must make room for: 1 = natural allocation (~140 VGPRs, 3 waves/SIMD,
 // best when VALU-bound: tiny cache-resident scenes); 5 = cap at 96 VGPRs (spills to scratch) for 5 waves/SIMD, measured +20 %
 // on the memory-latency-bound 100k..1M-triangle scenes and -15 % on Cornell.
-template <bool COUNT, int INTEG, int ACCEL, bool VOL, int MINW, bool GLOSSY>
+template <bool COUNT, int INTEG, int ACCEL, bool VOL, int MINW, bool EXT>
 __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *__restrict__ scp,
                                                                        const DevFrame *__restrict__ frp) {
     __shared__ uint2 lds_stack[RT_STACK_LDS * RT_BLOCK];
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
         // ---- shade / regenerate: run every lane that is not waiting on a ray until it is (or is out of work)
         do {
             RT_PF(++pf_inner;)
-            advance_pass<COUNT, INTEG, VOL, GLOSSY>(sc, fr, ln, gtid, &c_closest, &c_any, &c_bad, phase);
+            advance_pass<COUNT, INTEG, VOL, EXT>(sc, fr, ln, gtid, &c_closest, &c_any, &c_bad, phase);
             const unsigned long long want = phase == 0 ? 0ull : __ballot(!ln.has_ray && ln.stage == ST_FETCH);
             if (want) {                                                   // wave-aggregated work fetch
                 const int leader = __ffsll((long long)want) - 1;
@@ -118,10 +118,10 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
             if (!am) break;
             RT_PF(++pf_rounds; pf_act += __popcll(am);)
             if (fr.exit_thresh > 0 && __popcll(am) <= fr.exit_thresh && __any(!act && ln.stage != ST_EXIT)) break;
-            if (fr.trav_mode == 1) accel_round<COUNT, ACCEL>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc);
-            else if (fr.trav_mode == 2) accel_round_batched<COUNT, ACCEL>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc);
-            else if (POOL && fr.trav_mode == 3) accel_round_pooled<COUNT, ACCEL>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc, pool);
-            else if (act) accel_step<COUNT, ACCEL>(ln.tv, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc);
+            if (fr.trav_mode == 1) accel_round<COUNT, ACCEL, EXT>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc);
+            else if (fr.trav_mode == 2) accel_round_batched<COUNT, ACCEL, EXT>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc);
+            else if (POOL && fr.trav_mode == 3) accel_round_pooled<COUNT, ACCEL, EXT>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc, pool);
+            else if (act) accel_step<COUNT, ACCEL, EXT>(ln.tv, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc);
         }
         if (ln.has_ray && !ln.tv.active) ln.has_ray = false;
         RT_PF(pf_trav += __builtin_readcyclecounter() - pf_t0;)
@@ -305,8 +305,8 @@ __global__ __launch_bounds__(RT_BLOCK) void trace_kernel(DevScene sc, const RtRa
         Ray r; r.o = mk3(rays[i].o[0], rays[i].o[1], rays[i].o[2]); r.d = mk3(rays[i].d[0], rays[i].d[1], rays[i].d[2]);
         r.mint = rays[i].mint; r.maxt = rays[i].maxt;
         Trav tv;
-        if (sc.accel_kind == RT_ACCEL_GRID) { grid_begin(tv, sc, r, any != 0); while (tv.active) grid_step<true>(tv, sc, tc); }
-        else { trav_begin(tv, sc, r, any != 0); while (tv.active) trav_step<true>(tv, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, spill), n_threads, gtid, tc); }
+        if (sc.accel_kind == RT_ACCEL_GRID) { grid_begin(tv, sc, r, any != 0); while (tv.active) grid_step<true, true>(tv, sc, tc); }
+        else { trav_begin(tv, sc, r, any != 0); while (tv.active) trav_step<true, true>(tv, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, spill), n_threads, gtid, tc); }
         if (any) occ[i] = tv.hit_prim >= 0 ? 1 : 0;
         else { hits[i].prim = tv.hit_prim; hits[i].t = tv.hit_prim >= 0 ? tv.maxt : 0.f; hits[i].b1 = tv.b1; hits[i].b2 = tv.b2; }
     }
@@ -372,7 +372,7 @@ struct RtScene {
     KdTree tree;
     GridAccelData gridacc;
     int accel_kind = RT_ACCEL_KDTREE;
-    bool has_glossy = false;            // some material is plastic: use the kernels that carry the glossy lobes
+    bool has_ext = false;               // plastic materials or quadrics present: use the kernels that carry that code (EXT)
     DevScene dev{};
     std::vector<void *> allocs;
     // film
@@ -467,11 +467,18 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
 
     // triangles -> 48-byte records
     std::vector<DevTri> tris(d->n_tris);
+    uint32_t n_quadric_slots = 0;
     for (uint32_t i = 0; i < d->n_tris; ++i) {
         const float *v = d->tri_verts + size_t(9) * i;
         uint32_t bits = uint32_t(d->tri_material[i]) | (uint32_t(d->tri_flags[i] & 1u) << 16);
         int32_t light = d->tri_light[i];
         float fb, fl; std::memcpy(&fb, &bits, 4); std::memcpy(&fl, &light, 4);
+        if (d->tri_flags[i] & 2u) {                       // quadric slot: {index, -, -} | bits | light
+            bits |= RT_PRIM_QUADRIC; std::memcpy(&fb, &bits, 4);
+            float fi; std::memcpy(&fi, &n_quadric_slots, 4); ++n_quadric_slots;
+            tris[i].q0 = make_float4(fi, 0.f, 0.f, 0.f); tris[i].q1 = make_float4(0.f, 0.f, 0.f, 0.f); tris[i].q2 = make_float4(0.f, fb, fl, 0.f);
+            continue;
+        }
         tris[i].q0 = make_float4(v[0], v[1], v[2], v[3]);
         tris[i].q1 = make_float4(v[4], v[5], v[6], v[7]);
         tris[i].q2 = make_float4(v[8], fb, fl, 0.f);
@@ -479,10 +486,12 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
     // per-triangle shading constants: tri_frame() (rt_shade.h) evaluated once on the host with the same float
     // expressions (this file is compiled -ffp-contract=off for the host too; sqrt and divide are IEEE on both sides)
     std::vector<float4> shade(size_t(2) * d->n_tris);
+    if (n_quadric_slots != d->n_quadrics || (d->n_quadrics && !d->quadrics)) return fail(RT_EINVAL, "rt_scene_create: quadric slots do not match n_quadrics");
+    s->has_ext = s->has_ext || d->n_quadrics > 0;
     for (uint32_t i = 0; i < d->n_tris; ++i) {
-        float nn[3], sn[3];
-        host_tri_frame(d->tri_verts + size_t(9) * i, (d->tri_flags[i] & 1u) != 0, nn, sn);
-        uint32_t bits = uint32_t(d->tri_material[i]) | (uint32_t(d->tri_flags[i] & 1u) << 16);
+        float nn[3] = {0.f, 0.f, 0.f}, sn[3] = {0.f, 0.f, 0.f};
+        if (!(d->tri_flags[i] & 2u)) host_tri_frame(d->tri_verts + size_t(9) * i, (d->tri_flags[i] & 1u) != 0, nn, sn);
+        uint32_t bits = uint32_t(d->tri_material[i]) | (uint32_t(d->tri_flags[i] & 1u) << 16) | ((d->tri_flags[i] & 2u) ? RT_PRIM_QUADRIC : 0u);
         int32_t light = d->tri_light[i];
         float fb, fl; std::memcpy(&fb, &bits, 4); std::memcpy(&fl, &light, 4);
         shade[2 * i] = make_float4(nn[0], nn[1], nn[2], fb);
@@ -491,6 +500,17 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
     int rc;
     if ((rc = upload(s, shade.data(), shade.size(), &s->dev.tri_shade))) return rc;
     if ((rc = upload(s, tris.data(), tris.size(), &s->dev.tris))) return rc;
+    {
+        std::vector<DevQuadric> dq(d->n_quadrics);
+        for (uint32_t i = 0; i < d->n_quadrics; ++i) {
+            const RtQuadric &q = d->quadrics[i]; DevQuadric &o = dq[i];
+            if (q.type != RT_QUADRIC_SPHERE) return fail(RT_EINVAL, "rt_scene_create: unknown quadric type");
+            std::memcpy(o.w2o, q.world_to_object, sizeof o.w2o); std::memcpy(o.o2w, q.object_to_world, sizeof o.o2w);
+            o.radius = q.radius; o.zmin = q.zmin; o.zmax = q.zmax; o.theta_min = q.theta_min; o.theta_max = q.theta_max; o.phi_max = q.phi_max;
+            o.type = q.type; o.pad = 0;
+        }
+        if ((rc = upload(s, dq.data(), dq.size(), &s->dev.quadrics))) return rc;
+    }
     const uint2 *nodes_dev = nullptr;
     if ((rc = upload(s, reinterpret_cast<const uint2 *>(s->tree.nodes.data()), s->tree.nodes.size(), &nodes_dev))) return rc;
     s->dev.nodes = nodes_dev;
@@ -506,7 +526,7 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
         o.has_t = (m.kt[0] != 0.f || m.kt[1] != 0.f || m.kt[2] != 0.f);
         for (int c = 0; c < 3; ++c) o.ks[c] = m.ks[c];
         o.exponent = 0.f;
-        if (m.type == RT_MAT_PLASTIC) { s->has_glossy = true; float e = 1.f / m.roughness; if (e > 1000.f || std::isnan(e)) e = 1000.f; o.exponent = e; }
+        if (m.type == RT_MAT_PLASTIC) { s->has_ext = true; float e = 1.f / m.roughness; if (e > 1000.f || std::isnan(e)) e = 1000.f; o.exponent = e; }
         if (m.type < RT_MAT_MATTE || m.type > RT_MAT_PLASTIC) return fail(RT_EINVAL, "rt_scene_create: unknown material type");
         if (m.type == RT_MAT_MATTE && m.sigma != 0.f) {
             float sigma = (3.14159265358979323846f / 180.f) * m.sigma;
@@ -753,6 +773,8 @@ static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool nee
         if (const char *e = std::getenv("PBRT_HIP_HIGH_OCC")) fr.high_occupancy = std::atoi(e);
         if (const char *e = std::getenv("PBRT_HIP_TRAV_MODE")) fr.trav_mode = std::atoi(e);
         if (const char *e = std::getenv("PBRT_HIP_EXIT_THRESH")) fr.exit_thresh = std::atoi(e);
+        fr.dbg_x = fr.dbg_y = -1000000;
+        if (const char *e = std::getenv("PBRT_HIP_DEBUG_PIXEL")) std::sscanf(e, "%d,%d", &fr.dbg_x, &fr.dbg_y);
         fr.phase_sync = tiny ? 1 : 0;                          // C2: 63.6 vs 82.4 ms; 100k/1M soups (early-exit rounds): 8 % slower
         if (const char *e = std::getenv("PBRT_HIP_PHASE_SYNC")) fr.phase_sync = std::atoi(e);
         if (fr.trav_mode == 3 && fr.high_occupancy) fr.trav_mode = 1;   // the high-occupancy kernels carry no pooled-leaf scratch
@@ -886,7 +908,7 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
     fr.samples = s->samples;
     int variant = (((s->volume.present ? 1 : 0) * 2 + (s->accel_kind == RT_ACCEL_GRID ? 1 : 0)) * 2 + (s->counting ? 1 : 0)) * 3 + rd->integrator;
     if (fr.high_occupancy && !s->counting) variant = 24 + ((s->volume.present ? 1 : 0) * 2 + (s->accel_kind == RT_ACCEL_GRID ? 1 : 0)) * 3 + rd->integrator;
-    if (s->has_glossy && !s->counting) variant = 36 + ((s->volume.present ? 1 : 0) * 2 + (s->accel_kind == RT_ACCEL_GRID ? 1 : 0)) * 3 + rd->integrator;
+    if (s->has_ext && !s->counting) variant = 36 + ((s->volume.present ? 1 : 0) * 2 + (s->accel_kind == RT_ACCEL_GRID ? 1 : 0)) * 3 + rd->integrator;
     HIPCHK(hipMemcpyAsync(s->filter_dev, rd->filter_table, 256 * sizeof(float), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemcpyAsync(s->dev_frame, &fr, sizeof(DevFrame), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemsetAsync(s->work_counter, 0, sizeof(unsigned long long), s->stream));

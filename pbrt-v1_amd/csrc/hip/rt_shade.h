@@ -7,7 +7,7 @@
 namespace rt {
 
 // BxDFType bits (core/reflection.h:52-68)
-enum { BX_REFLECTION = 1, BX_TRANSMISSION = 2, BX_DIFFUSE = 4, BX_GLOSSY = 8, BX_SPECULAR = 16,
+enum { BX_REFLECTION = 1, BX_TRANSMISSION = 2, BX_DIFFUSE = 4, BX_EXT = 8, BX_SPECULAR = 16,
        BX_ALL = 31 };
 
 struct Vertex {
@@ -36,15 +36,48 @@ RT_DEV void tri_frame(V3 p1, V3 p2, V3 p3, bool flip, V3 &nn, V3 &dpdu) {
     if (flip) nn = nn * -1.f;
 }
 
+// DifferentialGeometry + BSDF frame of a sphere hit (sphere.cpp:141-209, shape.cpp:37-51, reflection.cpp:471-479): the hit
+// point is re-derived exactly as Sphere::Intersect did (same object-space ray, t = the accepted hit parameter)
+RT_DEV void sphere_frame(const DevScene &sc, unsigned qi, bool flip, const Trav &tv, Vertex &v) {
+    const DevQuadric RT_G &q = RT_GPTR(const DevQuadric, sc.quadrics)[qi];
+    const V3 o = xform_point(q.w2o, tv.o), d = xform_vector(q.w2o, tv.d);
+    const V3 phit = o + d * tv.maxt;
+    const float radius = q.radius, phiMax = q.phi_max, thetaMin = q.theta_min, thetaMax = q.theta_max;
+    const float theta = acosf(clampf(phit.z / radius, -1.f, 1.f));
+    float cosphi, sinphi; V3 dpdu, dpdv;
+    const float zradius = sqrtf(phit.x * phit.x + phit.y * phit.y);
+    if (zradius == 0) {
+        cosphi = 0; sinphi = 1;
+        dpdv = mk3(phit.z * cosphi, phit.z * sinphi, -radius * sinf(theta)) * (thetaMax - thetaMin);
+        dpdu = cross3(dpdv, phit);
+    } else {
+        const float invzradius = 1.f / zradius;
+        cosphi = phit.x * invzradius; sinphi = phit.y * invzradius;
+        dpdu = mk3(-phiMax * phit.y, phiMax * phit.x, 0.f);
+        dpdv = mk3(phit.z * cosphi, phit.z * sinphi, -radius * sinf(theta)) * (thetaMax - thetaMin);
+    }
+    v.p = xform_point(q.o2w, phit);
+    const V3 dpduW = xform_vector(q.o2w, dpdu), dpdvW = xform_vector(q.o2w, dpdv);
+    v.nn = normalize3(cross3(dpduW, dpdvW));
+    if (flip) v.nn = v.nn * -1.f;
+    v.sn = normalize3(dpduW);
+}
+template <bool EXT>
 RT_DEV void make_vertex(const DevScene &sc, const Trav &tv, Vertex &v) {
     const float4 RT_G *q = RT_GPTR(const float4, sc.tri_shade) + size_t(2) * unsigned(tv.hit_prim);
     const float4 a = q[0], b = q[1];
-    v.p = tv.o + tv.d * tv.maxt;                         // ray(t), geometry.h:210
-    v.nn = mk3(a.x, a.y, a.z);                           // tri_frame(), precomputed per triangle on the host
-    v.sn = mk3(b.x, b.y, b.z);
+    const unsigned bits = __float_as_uint(a.w);
+    if (EXT && (bits & RT_PRIM_QUADRIC)) {
+        const unsigned qi = __float_as_uint(RT_GPTR(const DevTri, sc.tris)[unsigned(tv.hit_prim)].q0.x);
+        sphere_frame(sc, qi, (bits & 0x10000u) != 0, tv, v);
+    } else {
+        v.p = tv.o + tv.d * tv.maxt;                     // ray(t), geometry.h:210
+        v.nn = mk3(a.x, a.y, a.z);                       // tri_frame(), precomputed per triangle on the host
+        v.sn = mk3(b.x, b.y, b.z);
+    }
     v.tn = cross3(v.nn, v.sn);
     v.wo = -tv.d;
-    v.mat = int(__float_as_uint(a.w) & 0xffffu);
+    v.mat = int(bits & 0xffffu);
     v.light = __float_as_int(b.w);
 }
 // geometric normal (orientation flip applied) and area-light index of a primitive
@@ -150,65 +183,65 @@ RT_DEV float glossy_pdf(MatRef m, V3 wo, V3 wi) { return (wo.z * wi.z > 0.f) ? b
 
 // lobes in the order the material adds them: matte {diffuse}; plastic {diffuse, glossy} (plastic.cpp:66-67);
 // mirror {specular R}; glass {specular R, specular T} (glass.cpp:56-61, only the non-black ones)
-template <bool GLOSSY>
+template <bool EXT>
 RT_DEV int bsdf_num_components(MatRef m, int flags) {
     int n = 0;
-    if (m.type == RT_MAT_MATTE || (GLOSSY && m.type == RT_MAT_PLASTIC)) {
+    if (m.type == RT_MAT_MATTE || (EXT && m.type == RT_MAT_PLASTIC)) {
         if (((BX_REFLECTION | BX_DIFFUSE) & flags) == (BX_REFLECTION | BX_DIFFUSE)) ++n;
-        if (GLOSSY && m.type == RT_MAT_PLASTIC && ((BX_REFLECTION | BX_GLOSSY) & flags) == (BX_REFLECTION | BX_GLOSSY)) ++n;
+        if (EXT && m.type == RT_MAT_PLASTIC && ((BX_REFLECTION | BX_EXT) & flags) == (BX_REFLECTION | BX_EXT)) ++n;
     } else {
         if (m.has_r && ((BX_REFLECTION | BX_SPECULAR) & flags) == (BX_REFLECTION | BX_SPECULAR)) ++n;
         if (m.type == RT_MAT_GLASS && m.has_t && ((BX_TRANSMISSION | BX_SPECULAR) & flags) == (BX_TRANSMISSION | BX_SPECULAR)) ++n;
     }
     return n;
 }
-template <bool GLOSSY> RT_DEV int bsdf_total_components(MatRef m) { return bsdf_num_components<GLOSSY>(m, BX_ALL); }
+template <bool EXT> RT_DEV int bsdf_total_components(MatRef m) { return bsdf_num_components<EXT>(m, BX_ALL); }
 
 // sum of f over the non-specular reflection lobes matching `flags`, in lobe order (BSDF::f's loop, reflection.cpp:489-492)
-template <bool GLOSSY>
+template <bool EXT>
 RT_DEV V3 bsdf_f_lobes(MatRef m, V3 wo, V3 wi, int flags) {
     V3 f = mk3(0.f);
     if (((BX_REFLECTION | BX_DIFFUSE) & flags) == (BX_REFLECTION | BX_DIFFUSE)) f = f + diffuse_f(m, wo, wi);
-    if (GLOSSY && m.type == RT_MAT_PLASTIC && ((BX_REFLECTION | BX_GLOSSY) & flags) == (BX_REFLECTION | BX_GLOSSY)) f = f + microfacet_f(m, wo, wi);
+    if (EXT && m.type == RT_MAT_PLASTIC && ((BX_REFLECTION | BX_EXT) & flags) == (BX_REFLECTION | BX_EXT)) f = f + microfacet_f(m, wo, wi);
     return f;
 }
 
 // BSDF::f reflection.cpp:480-494 (flags = BSDF_ALL): only the non-specular lobes have a non-zero f
-template <bool GLOSSY>
+template <bool EXT>
 RT_DEV V3 bsdf_f(MatRef m, const Vertex &v, V3 woW, V3 wiW) {
-    if (m.type != RT_MAT_MATTE && !(GLOSSY && m.type == RT_MAT_PLASTIC)) return mk3(0.f);
+    if (m.type != RT_MAT_MATTE && !(EXT && m.type == RT_MAT_PLASTIC)) return mk3(0.f);
     V3 wi = to_local(v, wiW), wo = to_local(v, woW);
-    if (dot3(wiW, v.nn) * dot3(woW, v.nn) > 0) return bsdf_f_lobes<GLOSSY>(m, wo, wi, BX_ALL & ~BX_TRANSMISSION);   // BRDFs only
+    if (dot3(wiW, v.nn) * dot3(woW, v.nn) > 0) return bsdf_f_lobes<EXT>(m, wo, wi, BX_ALL & ~BX_TRANSMISSION);   // BRDFs only
     return mk3(0.f);                                                                                         // BTDFs only: none
 }
 
 // BSDF::Pdf reflection.cpp:458-470 (flags = BSDF_ALL)
-template <bool GLOSSY>
+template <bool EXT>
 RT_DEV float bsdf_pdf(MatRef m, const Vertex &v, V3 woW, V3 wiW) {
-    int nc = bsdf_total_components<GLOSSY>(m);
+    int nc = bsdf_total_components<EXT>(m);
     if (nc == 0) return 0.f;
-    if (m.type != RT_MAT_MATTE && !(GLOSSY && m.type == RT_MAT_PLASTIC)) return 0.f / float(nc);
+    if (m.type != RT_MAT_MATTE && !(EXT && m.type == RT_MAT_PLASTIC)) return 0.f / float(nc);
     V3 wo = to_local(v, woW), wi = to_local(v, wiW);
     float pdf = 0.f;
     pdf += diffuse_pdf(wo, wi);
-    if (GLOSSY && m.type == RT_MAT_PLASTIC) pdf += glossy_pdf(m, wo, wi);
+    if (EXT && m.type == RT_MAT_PLASTIC) pdf += glossy_pdf(m, wo, wi);
     return pdf / nc;
 }
 
 // BSDF::Sample_f reflection.cpp:402-457.  Returns f; pdf == 0 means "no sample".
-template <bool GLOSSY>
+template <bool EXT>
 RT_DEV V3 bsdf_sample_f(MatRef m, const Vertex &v, V3 woW, V3 &wiW, float u1, float u2, float u3,
                         float &pdf, int flags, int &sampled) {
     sampled = 0; pdf = 0.f;
-    int matching = bsdf_num_components<GLOSSY>(m, flags);
+    int matching = bsdf_num_components<EXT>(m, flags);
     if (matching == 0) return mk3(0.f);
     int which = min(int(floorf(u3 * matching)), matching - 1);     // Floor2Int(double(u3*matching))
     V3 wo = to_local(v, woW);
     V3 wi, f;
-    if (m.type == RT_MAT_MATTE || (GLOSSY && m.type == RT_MAT_PLASTIC)) {
+    if (m.type == RT_MAT_MATTE || (EXT && m.type == RT_MAT_PLASTIC)) {
         const bool diffuse_has = ((BX_REFLECTION | BX_DIFFUSE) & flags) == (BX_REFLECTION | BX_DIFFUSE);
-        const bool glossy_has = GLOSSY && m.type == RT_MAT_PLASTIC && ((BX_REFLECTION | BX_GLOSSY) & flags) == (BX_REFLECTION | BX_GLOSSY);
-        const bool pick_diffuse = !GLOSSY || (diffuse_has && which == 0);
+        const bool glossy_has = EXT && m.type == RT_MAT_PLASTIC && ((BX_REFLECTION | BX_EXT) & flags) == (BX_REFLECTION | BX_EXT);
+        const bool pick_diffuse = !EXT || (diffuse_has && which == 0);
         if (pick_diffuse) {
             // BxDF::Sample_f reflection.cpp:219-226 with CosineSampleHemisphere mc.h:38-44
             float dx, dy; concentric_disk(u1, u2, dx, dy);
@@ -229,13 +262,13 @@ RT_DEV V3 bsdf_sample_f(MatRef m, const Vertex &v, V3 woW, V3 &wiW, float u1, fl
             pdf = ((m.exponent + 1.f) * powf(costheta, m.exponent)) / (2.f * RT_PI * 4.f * dot3(wo, H));
             if (dot3(wo, H) <= 0.f) pdf = 0.f;
             if (pdf == 0.f) return mk3(0.f);
-            sampled = BX_REFLECTION | BX_GLOSSY;
+            sampled = BX_REFLECTION | BX_EXT;
             if (diffuse_has) pdf += diffuse_pdf(wo, wi);
         }
         wiW = to_world(v, wi);
         if (matching > 1) pdf /= matching;
         f = mk3(0.f);
-        if (dot3(wiW, v.nn) * dot3(woW, v.nn) > 0) f = bsdf_f_lobes<GLOSSY>(m, wo, wi, flags & ~BX_TRANSMISSION);
+        if (dot3(wiW, v.nn) * dot3(woW, v.nn) > 0) f = bsdf_f_lobes<EXT>(m, wo, wi, flags & ~BX_TRANSMISSION);
         return f;
     }
     // specular lobes, in the order the material added them (glass.cpp:56-61, mirror.cpp:51-53)

@@ -99,6 +99,57 @@ RT_DEV bool tri_test(V3 p1, V3 p2, V3 p3, V3 o, V3 d, float mint, float maxt, fl
     return true;
 }
 
+
+// ---- quadrics: Sphere::Intersect / IntersectP up to the accepted hit parameter (shapes/sphere.cpp:104-140, :216-250) ----
+RT_DEV bool quadratic(float A, float B, float C, float &t0, float &t1) {   // pbrt.h:645-659
+    const float discrim = B * B - 4.f * A * C;
+    if (discrim < 0.f) return false;
+    const float rootDiscrim = sqrtf(discrim);
+    float q;
+    if (B < 0) q = -.5f * (B - rootDiscrim);
+    else q = -.5f * (B + rootDiscrim);
+    t0 = q / A;
+    t1 = C / q;
+    if (t0 > t1) { const float tmp = t0; t0 = t1; t1 = tmp; }
+    return true;
+}
+RT_DEV bool sphere_test(const DevScene &sc, unsigned qi, V3 ow, V3 dw, float mint, float maxt, float &t_out) {
+    const DevQuadric RT_G &q = RT_GPTR(const DevQuadric, sc.quadrics)[qi];
+    const V3 o = xform_point(q.w2o, ow), d = xform_vector(q.w2o, dw);           // WorldToObject(r, &ray) transform.h:128-135
+    const float radius = q.radius, zmin = q.zmin, zmax = q.zmax, phiMax = q.phi_max;
+    const float A = d.x * d.x + d.y * d.y + d.z * d.z;
+    const float B = 2 * (d.x * o.x + d.y * o.y + d.z * o.z);
+    const float C = o.x * o.x + o.y * o.y + o.z * o.z - radius * radius;
+    float t0, t1;
+    if (!quadratic(A, B, C, t0, t1)) return false;
+    if (t0 > maxt || t1 < mint) return false;
+    float thit = t0;
+    if (t0 < mint) { thit = t1; if (thit > maxt) return false; }
+    V3 phit = o + d * thit;
+    float phi = atan2f(phit.y, phit.x);
+    if (phi < 0.f) phi += 2.f * RT_PI;
+    if ((zmin > -radius && phit.z < zmin) || (zmax < radius && phit.z > zmax) || phi > phiMax) {
+        if (thit == t1) return false;
+        if (t1 > maxt) return false;
+        thit = t1;
+        phit = o + d * thit;
+        phi = atan2f(phit.y, phit.x);
+        if (phi < 0.f) phi += 2.f * RT_PI;
+        if (phit.z < zmin || phit.z > zmax || phi > phiMax) return false;
+    }
+    t_out = thit;
+    return true;
+}
+// one primitive of a leaf / voxel list: GeometricPrimitive::Intersect(P) (primitive.cpp:103-134) over a triangle or,
+// in the EXT kernels, a quadric slot
+template <bool EXT>
+RT_DEV bool prim_test(const DevScene &sc, unsigned prim, V3 o, V3 d, float mint, float maxt, float &t, float &b1, float &b2) {
+    const DevTri RT_G *gt = RT_GPTR(const DevTri, sc.tris) + prim;
+    const float4 q0 = gt->q0, q1 = gt->q1, q2 = gt->q2;
+    if (EXT && (__float_as_uint(q2.y) & RT_PRIM_QUADRIC)) { b1 = 0.f; b2 = 0.f; return sphere_test(sc, __float_as_uint(q0.x), o, d, mint, maxt, t); }
+    return tri_test(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), mk3(q1.z, q1.w, q2.x), o, d, mint, maxt, t, b1, b2);
+}
+
 // ---- todo stack --------------------------------------------------------------------------------------------------
 // The LDS ring holds the TOP RT_STACK_LDS entries (slot = index mod RT_STACK_LDS); when it is full the OLDEST entry moves to
 // HBM, and a pop below the ring's base reads that entry back.  Pushes and pops cluster at the top of the stack, so a deep
@@ -150,7 +201,7 @@ RT_DEV void trav_begin(Trav &tv, const DevScene &sc, const Ray &r, bool any) {
 }
 
 // one node visit
-template <bool COUNT>
+template <bool COUNT, bool EXT>
 RT_DEV void trav_step(Trav &tv, const DevScene &sc, uint2 RT_L *lds_stack, uint2 RT_G *spill, unsigned n_threads,
                       unsigned gtid, TravCounters &cnt) {
     if (!tv.any && tv.maxt < tv.tmin) { tv.active = false; return; }      // kdtree.cpp:330
@@ -183,10 +234,8 @@ RT_DEV void trav_step(Trav &tv, const DevScene &sc, uint2 RT_L *lds_stack, uint2
         tv.mb3 = tv.mb2; tv.mb2 = tv.mb1; tv.mb1 = tv.mb0; tv.mb0 = prim;
 #endif
         if (COUNT) ++cnt.tris;
-        V3 p1, p2, p3; unsigned bits; int light;
-        tri_verts(sc.tris, prim, p1, p2, p3, bits, light);
         float t, b1, b2;
-        if (tri_test(p1, p2, p3, tv.o, tv.d, tv.mint, tv.maxt, t, b1, b2)) {
+        if (prim_test<EXT>(sc, prim, tv.o, tv.d, tv.mint, tv.maxt, t, b1, b2)) {
             if (tv.any) { tv.hit_prim = 0; tv.active = false; return; }    // kdtree.cpp:432-434
             tv.maxt = t; tv.hit_prim = int(prim); tv.b1 = b1; tv.b2 = b2;  // primitive.cpp:120
         }
@@ -244,7 +293,7 @@ RT_DEV void grid_begin(Trav &tv, const DevScene &sc, const Ray &r, bool any) {
 }
 
 // one voxel visit
-template <bool COUNT>
+template <bool COUNT, bool EXT>
 RT_DEV void grid_step(Trav &tv, const DevScene &sc, TravCounters &cnt) {
     const uint2 vx = RT_GPTR(const uint2, sc.nodes)[(size_t(tv.gpos[2]) * sc.nvox[1] + tv.gpos[1]) * sc.nvox[0] + tv.gpos[0]];
     if (COUNT) ++cnt.nodes;
@@ -256,10 +305,8 @@ RT_DEV void grid_step(Trav &tv, const DevScene &sc, TravCounters &cnt) {
         tv.mb3 = tv.mb2; tv.mb2 = tv.mb1; tv.mb1 = tv.mb0; tv.mb0 = prim;
 #endif
         if (COUNT) ++cnt.tris;
-        V3 p1, p2, p3; unsigned bits; int light;
-        tri_verts(sc.tris, prim, p1, p2, p3, bits, light);
         float t, b1, b2;
-        if (tri_test(p1, p2, p3, tv.o, tv.d, tv.mint, tv.maxt, t, b1, b2)) {
+        if (prim_test<EXT>(sc, prim, tv.o, tv.d, tv.mint, tv.maxt, t, b1, b2)) {
             if (tv.any) { tv.hit_prim = 0; tv.active = false; return; }
             tv.maxt = t; tv.hit_prim = int(prim); tv.b1 = b1; tv.b2 = b2;
         }
@@ -306,7 +353,7 @@ RT_DEV void kd_descend(Trav &tv, const DevScene &sc, uint2 RT_L *lds_stack, uint
     }
 }
 // one primitive of the current leaf / voxel list
-template <bool COUNT, bool GRID>
+template <bool COUNT, bool GRID, bool EXT>
 RT_DEV void leaf_test_one(Trav &tv, const DevScene &sc, TravCounters &cnt) {
     const bool single = !GRID && tv.ln_ == 1;
     const unsigned prim = single ? tv.ly : RT_GPTR(const unsigned, sc.leaf_refs)[tv.ly + tv.li];
@@ -317,10 +364,8 @@ RT_DEV void leaf_test_one(Trav &tv, const DevScene &sc, TravCounters &cnt) {
     tv.mb3 = tv.mb2; tv.mb2 = tv.mb1; tv.mb1 = tv.mb0; tv.mb0 = prim;
 #endif
     if (COUNT) ++cnt.tris;
-    V3 p1, p2, p3; unsigned bits; int light;
-    tri_verts(sc.tris, prim, p1, p2, p3, bits, light);
     float t, b1, b2;
-    if (tri_test(p1, p2, p3, tv.o, tv.d, tv.mint, tv.maxt, t, b1, b2)) {
+    if (prim_test<EXT>(sc, prim, tv.o, tv.d, tv.mint, tv.maxt, t, b1, b2)) {
         if (tv.any) { tv.hit_prim = 0; tv.active = false; return; }
         tv.maxt = t; tv.hit_prim = int(prim); tv.b1 = b1; tv.b2 = b2;
     }
@@ -355,7 +400,7 @@ RT_DEV void grid_voxel_done(Trav &tv, const DevScene &sc) {               // gri
 }
 
 // One lock-step round for the whole wave: descend -> test -> pop.  `mine` = this lane carries a live traversal.
-template <bool COUNT, int ACCEL>
+template <bool COUNT, int ACCEL, bool EXT>
 RT_DEV void accel_round(Trav &tv, bool mine, const DevScene &sc, uint2 RT_L *lds_stack, uint2 RT_G *spill, unsigned n_threads,
                         unsigned gtid, TravCounters &cnt) {
     RT_PFT(unsigned long long t0 = __builtin_readcyclecounter();)
@@ -368,7 +413,7 @@ RT_DEV void accel_round(Trav &tv, bool mine, const DevScene &sc, uint2 RT_L *lds
     RT_PFT(unsigned long long t1 = __builtin_readcyclecounter(); cnt.c_desc += t1 - t0;)
     while (__any(mine && tv.active && tv.at_leaf && tv.li < tv.ln_)) {
         RT_PFT(++cnt.n_iter;)
-        if (mine && tv.active && tv.at_leaf && tv.li < tv.ln_) leaf_test_one<COUNT, ACCEL == RT_ACCEL_GRID>(tv, sc, cnt);
+        if (mine && tv.active && tv.at_leaf && tv.li < tv.ln_) leaf_test_one<COUNT, ACCEL == RT_ACCEL_GRID, EXT>(tv, sc, cnt);
     }
     RT_PFT(cnt.c_leaf += __builtin_readcyclecounter() - t1;)
     if (mine && tv.active && tv.at_leaf) {
@@ -410,7 +455,7 @@ RT_DEV unsigned wave_scan_max(unsigned v) {
     return v;
 }
 #undef RT_DPP_STEP
-template <bool COUNT, bool GRID>
+template <bool COUNT, bool GRID, bool EXT>
 RT_DEV void leaf_phase_pooled(Trav &tv, bool need, const DevScene &sc, PoolLds pl, TravCounters &cnt) {
     const int lane = int(__lane_id());
     const unsigned n = need ? tv.ln_ : 0u;
@@ -441,9 +486,7 @@ RT_DEV void leaf_phase_pooled(Trav &tv, bool need, const DevScene &sc, PoolLds p
             oany = (opk & 0x80000000u) != 0;
             const bool osingle = !GRID && (opk & 0x7fffffffu) == 1u;
             prim = osingle ? oly : RT_GPTR(const unsigned, sc.leaf_refs)[oly + k];
-            V3 p1, p2, p3; unsigned bits; int light;
-            tri_verts(sc.tris, prim, p1, p2, p3, bits, light);
-            hit = tri_test(p1, p2, p3, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), r0.w, r1.w, t, b1, b2);
+            hit = prim_test<EXT>(sc, prim, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), r0.w, r1.w, t, b1, b2);
             if (hit) {
                 key = oany ? (unsigned long long)k : ((unsigned long long)ordered_bits(t + 0.f) << 32) | (unsigned long long)(0xFFFFFFFEu - k);
                 atomicMin((unsigned long long *)(pl.key + owner), key);
@@ -469,7 +512,7 @@ RT_DEV void leaf_phase_pooled(Trav &tv, bool need, const DevScene &sc, PoolLds p
     }
 }
 // lock-step round with the leaf phase pooled when that is cheaper than max(n) per-lane iterations
-template <bool COUNT, int ACCEL>
+template <bool COUNT, int ACCEL, bool EXT>
 RT_DEV void accel_round_pooled(Trav &tv, bool mine, const DevScene &sc, uint2 RT_L *lds_stack, uint2 RT_G *spill, unsigned n_threads,
                                unsigned gtid, TravCounters &cnt, PoolLds pl) {
     RT_PFT(unsigned long long t0 = __builtin_readcyclecounter();)
@@ -489,11 +532,11 @@ RT_DEV void accel_round_pooled(Trav &tv, bool mine, const DevScene &sc, uint2 RT
     const unsigned chunks = (T + 63u) >> 6;
     if (m >= 8 || (m >= 2 && chunks * 7u + 3u < m * 5u)) {
         RT_PFT(++cnt.n_pooled; cnt.n_chunks += chunks;)
-        leaf_phase_pooled<COUNT, ACCEL == RT_ACCEL_GRID>(tv, need, sc, pl, cnt);
+        leaf_phase_pooled<COUNT, ACCEL == RT_ACCEL_GRID, EXT>(tv, need, sc, pl, cnt);
     } else
         while (__any(mine && tv.active && tv.at_leaf && tv.li < tv.ln_)) {
             RT_PFT(++cnt.n_iter;)
-            if (mine && tv.active && tv.at_leaf && tv.li < tv.ln_) leaf_test_one<COUNT, ACCEL == RT_ACCEL_GRID>(tv, sc, cnt);
+            if (mine && tv.active && tv.at_leaf && tv.li < tv.ln_) leaf_test_one<COUNT, ACCEL == RT_ACCEL_GRID, EXT>(tv, sc, cnt);
         }
     RT_PFT(cnt.c_leaf += __builtin_readcyclecounter() - t1;)
     if (mine && tv.active && tv.at_leaf) {
@@ -508,7 +551,7 @@ RT_DEV void accel_round_pooled(Trav &tv, bool mine, const DevScene &sc, uint2 RT
 #ifndef RT_BATCH_K
 #define RT_BATCH_K 16
 #endif
-template <bool COUNT, int ACCEL>
+template <bool COUNT, int ACCEL, bool EXT>
 RT_DEV void accel_round_batched(Trav &tv, bool mine, const DevScene &sc, uint2 RT_L *lds_stack, uint2 RT_G *spill, unsigned n_threads,
                                 unsigned gtid, TravCounters &cnt) {
     const bool act = mine && tv.active;
@@ -520,7 +563,7 @@ RT_DEV void accel_round_batched(Trav &tv, bool mine, const DevScene &sc, uint2 R
         else kd_descend<COUNT>(tv, sc, lds_stack, spill, n_threads, gtid, cnt);
     }
     if (nl && (nl >= RT_BATCH_K || nd == 0)) {
-        if (leafw) leaf_test_one<COUNT, ACCEL == RT_ACCEL_GRID>(tv, sc, cnt);
+        if (leafw) leaf_test_one<COUNT, ACCEL == RT_ACCEL_GRID, EXT>(tv, sc, cnt);
     }
     if (mine && tv.active && tv.at_leaf && tv.li >= tv.ln_) {
         if (ACCEL == RT_ACCEL_GRID) grid_voxel_done(tv, sc); else kd_leaf_done(tv, lds_stack, spill, n_threads, gtid);
@@ -532,10 +575,10 @@ template <int ACCEL>
 RT_DEV void accel_begin(Trav &tv, const DevScene &sc, const Ray &r, bool any) {
     if (ACCEL == RT_ACCEL_GRID) grid_begin(tv, sc, r, any); else trav_begin(tv, sc, r, any);
 }
-template <bool COUNT, int ACCEL>
+template <bool COUNT, int ACCEL, bool EXT>
 RT_DEV void accel_step(Trav &tv, const DevScene &sc, uint2 RT_L *lds_stack, uint2 RT_G *spill, unsigned n_threads, unsigned gtid,
                        TravCounters &cnt) {
-    if (ACCEL == RT_ACCEL_GRID) grid_step<COUNT>(tv, sc, cnt); else trav_step<COUNT>(tv, sc, lds_stack, spill, n_threads, gtid, cnt);
+    if (ACCEL == RT_ACCEL_GRID) grid_step<COUNT, EXT>(tv, sc, cnt); else trav_step<COUNT, EXT>(tv, sc, lds_stack, spill, n_threads, gtid, cnt);
 }
 
 }  // namespace rt

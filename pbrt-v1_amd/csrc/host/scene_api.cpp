@@ -239,6 +239,7 @@ void SceneDescription::finalize_pointers() {
     scene.n_materials = uint32_t(materials.size()); scene.materials = materials.data();
     scene.n_lights = uint32_t(lights.size()); scene.lights = lights.data();
     scene.n_light_tris = uint32_t(light_tris.size() / 9); scene.light_tris = light_tris.data();
+    scene.n_quadrics = uint32_t(quadrics.size()); scene.quadrics = quadrics.empty() ? nullptr : quadrics.data();
 }
 
 PbrtApi::PbrtApi() : state(STATE_OPTIONS), nVolumes(0), inObject(false) {
@@ -414,8 +415,9 @@ int PbrtApi::makeMaterial(const ParamSet &shapeParams) {
 void PbrtApi::Shape(const std::string &n, const ParamList &p) {                     // api.cpp:354-396
     if (!verifyWorld("Shape")) return;
     ParamSet ps(p);
+    if (n == "sphere") { quadricShape(ps); return; }
     if (n != "trianglemesh") {
-        Error("Unable to load plugin \"%s\" (shape): only \"trianglemesh\" is on the accelerated path (SURVEY.md rows 12-13)", n.c_str());
+        Error("Unable to load plugin \"%s\" (shape): \"trianglemesh\" and \"sphere\" are on the accelerated path (SURVEY.md rows 12-13)", n.c_str());
         return;
     }
     // CreateShape shapes/trianglemesh.cpp:350-406
@@ -460,6 +462,42 @@ void PbrtApi::Shape(const std::string &n, const ParamList &p) {                 
     meshes.push_back(std::move(mesh));
 }
 
+// CreateShape shapes/sphere.cpp:255-264 + Sphere ctor :89-99 + Shape::WorldBound (shape.h:57-59, transform.cpp:148-159)
+void PbrtApi::quadricShape(const ParamSet &ps) {
+    if (inObject) { Error("Object instancing is not on the accelerated path (SURVEY.md row 9); shape ignored"); return; }
+    auto clampf = [](float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); };
+    const float radius = ps.FindOneFloat("radius", 1.f);
+    const float z0 = ps.FindOneFloat("zmin", -radius), z1 = ps.FindOneFloat("zmax", radius);
+    const float pm = ps.FindOneFloat("phimax", 360.f);
+    ps.ReportUnused();
+    RtQuadric q; std::memset(&q, 0, sizeof q);
+    q.type = RT_QUADRIC_SPHERE;
+    std::memcpy(q.object_to_world, ctm.m.m, sizeof q.object_to_world);
+    std::memcpy(q.world_to_object, ctm.inv.m, sizeof q.world_to_object);
+    q.radius = radius;
+    q.zmin = clampf(std::fmin(z0, z1), -radius, radius);
+    q.zmax = clampf(std::fmax(z0, z1), -radius, radius);
+    q.theta_min = acosf(clampf(q.zmin / radius, -1.f, 1.f));
+    q.theta_max = acosf(clampf(q.zmax / radius, -1.f, 1.f));
+    q.phi_max = pbrthip::radians(clampf(pm, 0.0f, 360.0f));
+    // world bound of BBox(Point(-radius, -radius, zmin), Point(radius, radius, zmax))
+    const float lo[3] = {-radius, -radius, q.zmin}, hi[3] = {radius, radius, q.zmax};
+    float bmin[3] = {INFINITY, INFINITY, INFINITY}, bmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int c = 0; c < 8; ++c) {
+        const float pt[3] = {(c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]};
+        float w[3]; ctm.point(pt, w);
+        for (int a = 0; a < 3; ++a) { bmin[a] = std::fmin(bmin[a], w[a]); bmax[a] = std::fmax(bmax[a], w[a]); }
+    }
+    Mesh mesh;
+    mesh.flags = uint8_t(((gs.reverseOrientation ^ ctm.swaps_handedness()) ? 1 : 0) | 2);
+    mesh.verts = {bmin[0], bmin[1], bmin[2], bmax[0], bmax[1], bmax[2], bmin[0], bmin[1], bmin[2]};
+    mesh.light = -1;
+    if (!gs.areaLight.empty()) Error("Area lights on quadrics are not on the accelerated path; the sphere is rendered as a non-emitting surface");
+    mesh.material = makeMaterial(ps);
+    quadrics.push_back(q);
+    meshes.push_back(std::move(mesh));
+}
+
 void PbrtApi::Volume(const std::string &n, const ParamList &p) {                    // api.cpp:403-409, homogeneous.cpp:76-88
     if (!verifyWorld("Volume")) return;
     ParamSet ps(p);
@@ -485,7 +523,7 @@ void PbrtApi::ObjectEnd() { if (!verifyWorld("ObjectEnd")) return; inObject = fa
 void PbrtApi::ObjectInstance(const std::string &n) { if (verifyWorld("ObjectInstance")) Error("Object instancing is not on the accelerated path; instance \"%s\" ignored", n.c_str()); }
 
 void PbrtApi::resetWorld() {
-    meshes.clear(); materials.clear(); lights.clear(); light_tris.clear();
+    meshes.clear(); materials.clear(); lights.clear(); light_tris.clear(); quadrics.clear();
     std::memset(&volume, 0, sizeof volume); nVolumes = 0;
 }
 
@@ -515,7 +553,7 @@ void PbrtApi::WorldEnd() {                                                      
         }
     }
     if (materials.size() > 65535) Error("more than 65535 material instances");
-    sd->materials = materials; sd->lights = lights; sd->light_tris = light_tris;
+    sd->materials = materials; sd->lights = lights; sd->light_tris = light_tris; sd->quadrics = quadrics;
     sd->scene.volume = volume; sd->scene.accel = acc.params;
     RtRenderDesc &r = sd->render;
     r.integrator = si.kind; r.max_depth = si.maxDepth; r.strategy = si.strategy;

@@ -44,7 +44,7 @@ struct Accelerator { RtAccelParams params; };
 struct SceneDescription {
     // flattened arrays referenced by `scene`
     std::vector<float> tri_verts; std::vector<uint16_t> tri_material; std::vector<int32_t> tri_light; std::vector<uint8_t> tri_flags;
-    std::vector<RtMaterial> materials; std::vector<RtLight> lights; std::vector<float> light_tris;
+    std::vector<RtMaterial> materials; std::vector<RtLight> lights; std::vector<float> light_tris; std::vector<RtQuadric> quadrics;
     RtSceneDesc scene; RtRenderDesc render;
     Film film;
     bool valid = false;
@@ -119,13 +119,16 @@ class PbrtApi : public DirectiveSink {
     } gs;
     std::vector<GraphicsState> gsStack; std::vector<Xform> xfStack;
     // world being accumulated
-    struct Mesh { std::vector<float> verts; int material; int light; uint8_t flags; };   // 9 floats per triangle, API order
+    struct Mesh { std::vector<float> verts; int material; int light; uint8_t flags; };   // 9 floats per triangle, API order;
+                                                                                        // flags bit1: a quadric (one slot = its world bound)
+    std::vector<RtQuadric> quadrics;
     std::vector<Mesh> meshes;
     std::vector<RtMaterial> materials; std::vector<RtLight> lights; std::vector<float> light_tris;
     RtVolume volume; int nVolumes;
     bool inObject;
     bool verifyOptions(const char *fn); bool verifyWorld(const char *fn);
     int makeMaterial(const ParamSet &shapeParams);
+    void quadricShape(const ParamSet &ps);
     Float3 spectrumParam(const ParamSet &geom, const ParamSet &mat, const std::string &n, Float3 d);
     float floatParam(const ParamSet &geom, const ParamSet &mat, const std::string &n, float d);
     void resetWorld();

@@ -25,6 +25,11 @@ SPOT_XF = ('AttributeBegin\nTranslate 30 0 10\nRotate 20 0 1 0\nLightSource "spo
            'AttributeEnd\n')
 DISTANT_XF = 'AttributeBegin\nRotate -35 1 0 0.2\nScale 2 2 2\nLightSource "distant" "point from" [0 1 0] "point to" [0 0 0] "color L" [2 2 1.5]\nAttributeEnd\n'
 
+SPHERES = ('AttributeBegin\nMaterial "matte" "color Kd" [.7 .6 .2]\nTranslate 150 112 350\nShape "sphere" "float radius" [100]\nAttributeEnd\n'
+           'AttributeBegin\nMaterial "glass" "float index" [1.5]\nTranslate 400 120 200\nRotate 30 1 0 0\nScale 1 1.3 1\nShape "sphere" "float radius" [80]\nAttributeEnd\n'
+           'AttributeBegin\nMaterial "mirror"\nTranslate 300 330 420\nRotate -70 1 0.2 0\nShape "sphere" "float radius" [90] "float zmin" [-60] "float zmax" [70] "float phimax" [250]\nAttributeEnd\n'
+           'AttributeBegin\nMaterial "plastic" "color Kd" [.2 .3 .7] "float roughness" [.15]\nReverseOrientation\nTranslate 120 380 250\nScale -1 1 1\nShape "sphere" "float radius" [60]\nAttributeEnd\n')
+
 CONFIGS = {
     # name: cornell_scene kwargs  (all keyed RNG + counted rays)
     "whitted_point": dict(xres=48, yres=48, integrator="whitted", world_kwargs=dict(point_light=True, area_light=False)),
@@ -69,6 +74,11 @@ CONFIGS = {
                                                                                                               glass_sphere_tris=blob)),
     "vol_single_spot": dict(xres=24, yres=24, integrator="whitted", volume_integrator='"single" "float stepsize" [60]',
                             world_kwargs=dict(volume=' ', area_light=False, extra=SPOT)),
+    # spheres (full, clipped, transformed, reversed), matte / glass / mirror / plastic
+    "sphere_whitted": dict(xres=48, yres=48, integrator="whitted", world_kwargs=dict(point_light=True, extra=SPHERES)),
+    "sphere_direct": dict(xres=40, yres=40, integrator="directlighting", xsamples=2, ysamples=1, jitter=True, world_kwargs=dict(extra=SPHERES)),
+    "sphere_path_grid": dict(xres=32, yres=32, integrator="path", xsamples=2, ysamples=2, accelerator="grid", world_kwargs=dict(extra=SPHERES)),
+    "sphere_path_soup": dict(xres=32, yres=32, integrator="path", xsamples=2, ysamples=2, jitter=True, soup_tris=500, world_kwargs=dict(extra=SPHERES)),
     # plastic (Lambertian + Blinn microfacet lobes): text substitution of two Material lines below
     "plastic_whitted": dict(xres=40, yres=40, integrator="whitted", world_kwargs=dict(point_light=True)),
     "plastic_direct_ns2": dict(xres=32, yres=32, integrator="directlighting", xsamples=2, ysamples=1, jitter=True, world_kwargs=dict(light_nsamples=2)),

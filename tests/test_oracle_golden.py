@@ -126,3 +126,26 @@ def test_oracle_trace_against_probe_records(pkg, oracle):
         seg["mint"] = 1e-3; seg["maxt"] = np.float32(1.0) - np.float32(1e-3)
         occ, _ = oracle.trace(ps, seg, True, nodes, refs, bounds)
         assert np.array_equal(occ.astype(bool), rec[hit, 18] > 0)
+
+
+def test_one_ulp_libm_sensitivity_probe(pkg, oracle):
+    """The probe the GPU parity test uses for ill-conditioned scenes: with cosf one ulp different, the reference algorithm's
+    own film barely moves on the Cornell path fixture but moves on ~5 % of the pixels of the transformed-sphere fixture
+    (self-intersections at RAY_EPSILON, see tests/test_gpu_parity.py)."""
+    import ctypes as C
+    L = oracle.lib()
+    L.oracle_set_perturb.restype = None; L.oracle_set_perturb.argtypes = [C.c_int]
+    out = {}
+    for name in ("path_box_4spp", "sphere_path_soup"):
+        g = load_golden(name)
+        ps = pkg.ParsedScene(text=g["scene"])
+        nodes, refs, bounds, info = ps.kdtree()
+        a = oracle.render(ps, nodes, refs, bounds, info=info)[0]
+        L.oracle_set_perturb(1)
+        try:
+            b = oracle.render(ps, nodes, refs, bounds, info=info)[0]
+        finally:
+            L.oracle_set_perturb(0)
+        out[name] = film_metrics(b, a)
+        assert film_metrics(a, g["rgb"])["maxabs"] <= 1e-6          # unperturbed: still the reference's film
+    assert out["path_box_4spp"]["frac"] >= 0.995 and out["sphere_path_soup"]["frac"] < 0.99, out
