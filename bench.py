@@ -210,7 +210,7 @@ def main():
                                            "here; VALU issue under divergence is (%s)" % (100.0 * out["roofline"]["traffic"] / alg_bytes, busy))
             else:
                 out["roofline"]["note"] = ("fabric traffic %.2f-%.2fx the algorithmic bytes: 64-byte sectors fetched for 8-byte nodes, plus the "
-                                           "register-spill scratch of the 96-VGPR high-occupancy flavour (WRITE_SIZE %.0f GB/launch vs 0.5 GB of "
+                                           "register-spill scratch of the 128-VGPR high-occupancy flavour (WRITE_SIZE %.0f GB/launch vs 0.5 GB of "
                                            "sample records); L2 hit rate %.0f%%; %s" % (out["roofline"]["traffic_lower_bound"] / alg_bytes,
                                            out["roofline"]["traffic"] / alg_bytes, pj["WRITE_SIZE_KB"] * 1024 / 1e9, 100 * pj["derived"]["L2_hit_rate"], busy))
         if world == 1 and not args.no_cpu_baseline:

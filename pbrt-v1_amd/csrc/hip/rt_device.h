@@ -6,7 +6,8 @@
 namespace rt {
 
 // One triangle = three 16-byte vectors (48 B, one 128-B line holds 2.67 of them):
-//   q0 = p1.x p1.y p1.z p2.x | q1 = p2.y p2.z p3.x p3.y | q2 = p3.z, bits(material | flags<<16), bits(light), 0
+//   q0 = p1.x p1.y p1.z e1.x | q1 = e1.y e1.z e2.x e2.y | q2 = e2.z, bits(material | flags<<16), bits(light), 0
+//   with e1 = p2 - p1, e2 = p3 - p1 (the first two operations of Triangle::Intersect, done once on the host)
 struct DevTri { float4 q0, q1, q2; };
 // a quadric occupies one primitive slot: bits has RT_PRIM_QUADRIC set and q0.x holds the index into DevScene::quadrics
 #define RT_PRIM_QUADRIC (1u << 17)

@@ -25,8 +25,11 @@ namespace rt {
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 1
 #endif
+// waves per SIMD of the high-occupancy flavour: 4 = 128 VGPRs.  5 (96 VGPRs) was marginally faster at one point but its
+// spill placement swings with every code change (measured 108 -> 153 ms on the 1 M-triangle path frame for the same
+// algorithm); 4 is stable: 101 ms there, 138 ms on the 100 k soup.
 #ifndef RT_HIGH_OCC_WAVES
-#define RT_HIGH_OCC_WAVES 5
+#define RT_HIGH_OCC_WAVES 4
 #endif
 #ifndef RT_EXIT_THRESH
 #define RT_EXIT_THRESH 0
@@ -36,9 +39,9 @@ namespace rt {
 #endif
 // Scene and frame descriptors are read through pointers (uniform addresses -> scalar loads on demand) instead of
 // being passed by value: the by-value form pinned >100 SGPRs and spilled them.
-// MINW = minimum waves per SIMD the register allocator must make room for: 1 = natural allocation (~140 VGPRs, 3 waves/SIMD,
-// best when VALU-bound: tiny cache-resident scenes); 5 = cap at 96 VGPRs (spills to scratch) for 5 waves/SIMD, measured +20 %
-// on the memory-latency-bound 100k..1M-triangle scenes and -15 % on Cornell.
+// MINW = minimum waves per SIMD the register allocator must make room for: 1 = natural allocation (~160 VGPRs, 3 waves/SIMD,
+// best when VALU-bound: tiny cache-resident scenes); RT_HIGH_OCC_WAVES = 4 caps at 128 VGPRs (some spills to scratch) for
+// 4 waves/SIMD: +20 % on the memory-latency-bound 100k..1M-triangle scenes, -15 % on Cornell.
 template <bool COUNT, int INTEG, int ACCEL, bool VOL, int MINW, bool EXT>
 __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *__restrict__ scp,
                                                                        const DevFrame *__restrict__ frp) {
@@ -479,9 +482,10 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
             tris[i].q0 = make_float4(fi, 0.f, 0.f, 0.f); tris[i].q1 = make_float4(0.f, 0.f, 0.f, 0.f); tris[i].q2 = make_float4(0.f, fb, fl, 0.f);
             continue;
         }
-        tris[i].q0 = make_float4(v[0], v[1], v[2], v[3]);
-        tris[i].q1 = make_float4(v[4], v[5], v[6], v[7]);
-        tris[i].q2 = make_float4(v[8], fb, fl, 0.f);
+        const float e1[3] = {v[3] - v[0], v[4] - v[1], v[5] - v[2]}, e2[3] = {v[6] - v[0], v[7] - v[1], v[8] - v[2]};
+        tris[i].q0 = make_float4(v[0], v[1], v[2], e1[0]);
+        tris[i].q1 = make_float4(e1[1], e1[2], e2[0], e2[1]);
+        tris[i].q2 = make_float4(e2[2], fb, fl, 0.f);
     }
     // per-triangle shading constants: tri_frame() (rt_shade.h) evaluated once on the host with the same float
     // expressions (this file is compiled -ffp-contract=off for the host too; sqrt and divide are IEEE on both sides)

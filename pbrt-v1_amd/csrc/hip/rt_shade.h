@@ -344,7 +344,7 @@ RT_DEV float area_light_pdf(const DevScene &sc, LightRef L, V3 p, V3 wi) {
     for (unsigned k = 0; k < L.n_tris; ++k) {
         V3 p1, p2, p3; light_tri(sc, L.first_tri + k, p1, p2, p3);
         float t, b1, b2;
-        if (tri_test(p1, p2, p3, p, wi, RT_RAY_EPSILON, RT_INF, t, b1, b2)) {
+        if (tri_test(p1, p2 - p1, p3 - p1, p, wi, RT_RAY_EPSILON, RT_INF, t, b1, b2)) {
             any = true; thit = t;
             const float RT_G *ltr = RT_GPTR(const float, sc.light_tris) + size_t(L.first_tri + k) * 16;
             nl = mk3(ltr[12], ltr[13], ltr[14]);             // tri_frame() of the emitter triangle, precomputed

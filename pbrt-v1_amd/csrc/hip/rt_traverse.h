@@ -72,17 +72,9 @@ struct TravCounters {
 #define RT_PFT(x)
 #endif
 
-RT_DEV void tri_verts(const DevTri *tris, unsigned prim, V3 &p1, V3 &p2, V3 &p3, unsigned &bits, int &light) {
-    const DevTri RT_G *gt = RT_GPTR(const DevTri, tris) + prim;
-    const float4 q0 = gt->q0, q1 = gt->q1, q2 = gt->q2;
-    p1 = mk3(q0.x, q0.y, q0.z); p2 = mk3(q0.w, q1.x, q1.y); p3 = mk3(q1.z, q1.w, q2.x);
-    bits = __float_as_uint(q2.y); light = __float_as_int(q2.z);
-}
-
-// Triangle::Intersect up to the acceptance test (trianglemesh.cpp:213-246); exact comparison forms.
-RT_DEV bool tri_test(V3 p1, V3 p2, V3 p3, V3 o, V3 d, float mint, float maxt, float &t_out, float &b1_out, float &b2_out) {
-    V3 e1 = p2 - p1;
-    V3 e2 = p3 - p1;
+// Triangle::Intersect up to the acceptance test (trianglemesh.cpp:213-246); exact comparison forms.  The record holds p1 and
+// the two edges e1 = p2 - p1, e2 = p3 - p1, subtracted once on the host (the same float operation, so bit-identical).
+RT_DEV bool tri_test(V3 p1, V3 e1, V3 e2, V3 o, V3 d, float mint, float maxt, float &t_out, float &b1_out, float &b2_out) {
     V3 s1 = cross3(d, e2);
     float divisor = dot3(s1, e1);
     if (divisor == 0.f) return false;
@@ -98,7 +90,6 @@ RT_DEV bool tri_test(V3 p1, V3 p2, V3 p3, V3 o, V3 d, float mint, float maxt, fl
     t_out = t; b1_out = b1; b2_out = b2;
     return true;
 }
-
 
 // ---- quadrics: Sphere::Intersect / IntersectP up to the accepted hit parameter (shapes/sphere.cpp:104-140, :216-250) ----
 RT_DEV bool quadratic(float A, float B, float C, float &t0, float &t1) {   // pbrt.h:645-659

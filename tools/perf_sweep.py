@@ -26,6 +26,13 @@ def run(tag, defs=(), env=None, workload="c2", steps=2, extra=()):
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "a"
+    if which == "s":
+        for w in (4, 5):
+            run("highocc%d_p1m" % w, ["-DRT_HIGH_OCC_WAVES=%d" % w], workload="p1000000")
+            run("highocc%d_p100k" % w, ["-DRT_HIGH_OCC_WAVES=%d" % w], workload="p100000")
+        run("lowocc_p1m", env={"PBRT_HIP_HIGH_OCC": "0"}, workload="p1000000")
+        run("lowocc_p100k", env={"PBRT_HIP_HIGH_OCC": "0"}, workload="p100000")
+        return
     if which == "r":
         for w in (5, 6, 7, 8):
             run("highocc%d_p1m" % w, ["-DRT_HIGH_OCC_WAVES=%d" % w], workload="p1000000")
