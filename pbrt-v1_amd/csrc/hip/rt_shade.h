@@ -36,15 +36,25 @@ RT_DEV void tri_frame(V3 p1, V3 p2, V3 p3, bool flip, V3 &nn, V3 &dpdu) {
     if (flip) nn = nn * -1.f;
 }
 
-// DifferentialGeometry + BSDF frame of a sphere hit (sphere.cpp:141-209, shape.cpp:37-51, reflection.cpp:471-479): the hit
+// DifferentialGeometry + BSDF frame of a quadric hit (sphere.cpp:141-209, disk.cpp:85-103, cylinder.cpp:108-142, shape.cpp:37-51,
+// reflection.cpp:471-479): the hit
 // point is re-derived exactly as Sphere::Intersect did (same object-space ray, t = the accepted hit parameter)
 RT_DEV void sphere_frame(const DevScene &sc, unsigned qi, bool flip, const Trav &tv, Vertex &v) {
     const DevQuadric RT_G &q = RT_GPTR(const DevQuadric, sc.quadrics)[qi];
     const V3 o = xform_point(q.w2o, tv.o), d = xform_vector(q.w2o, tv.d);
     const V3 phit = o + d * tv.maxt;
     const float radius = q.radius, phiMax = q.phi_max, thetaMin = q.theta_min, thetaMax = q.theta_max;
-    const float theta = acosf(clampf(phit.z / radius, -1.f, 1.f));
     float cosphi, sinphi; V3 dpdu, dpdv;
+    if (q.type == RT_QUADRIC_DISK) {                                            // disk.cpp:85-93 (zmax = innerRadius)
+        const float dist2 = phit.x * phit.x + phit.y * phit.y;
+        const float vv = 1.f - ((sqrtf(dist2) - q.zmax) / (radius - q.zmax));
+        dpdu = mk3(-phiMax * phit.y, phiMax * phit.x, 0.f) * (phiMax * RT_INV_TWOPI);
+        dpdv = mk3(-phit.x / (1 - vv), -phit.y / (1 - vv), 0.f) * ((radius - q.zmax) / radius);
+    } else if (q.type == RT_QUADRIC_CYLINDER) {                                 // cylinder.cpp:112-115
+        dpdu = mk3(-phiMax * phit.y, phiMax * phit.x, 0.f);
+        dpdv = mk3(0.f, 0.f, q.zmax - q.zmin);
+    } else {
+    const float theta = acosf(clampf(phit.z / radius, -1.f, 1.f));
     const float zradius = sqrtf(phit.x * phit.x + phit.y * phit.y);
     if (zradius == 0) {
         cosphi = 0; sinphi = 1;
@@ -55,6 +65,7 @@ RT_DEV void sphere_frame(const DevScene &sc, unsigned qi, bool flip, const Trav 
         cosphi = phit.x * invzradius; sinphi = phit.y * invzradius;
         dpdu = mk3(-phiMax * phit.y, phiMax * phit.x, 0.f);
         dpdv = mk3(phit.z * cosphi, phit.z * sinphi, -radius * sinf(theta)) * (thetaMax - thetaMin);
+    }
     }
     v.p = xform_point(q.o2w, phit);
     const V3 dpduW = xform_vector(q.o2w, dpdu), dpdvW = xform_vector(q.o2w, dpdv);

@@ -91,7 +91,8 @@ RT_DEV bool tri_test(V3 p1, V3 e1, V3 e2, V3 o, V3 d, float mint, float maxt, fl
     return true;
 }
 
-// ---- quadrics: Sphere::Intersect / IntersectP up to the accepted hit parameter (shapes/sphere.cpp:104-140, :216-250) ----
+// ---- quadrics: {Sphere,Disk,Cylinder}::Intersect / IntersectP up to the accepted hit parameter (shapes/sphere.cpp:104-140,
+// disk.cpp:64-84, cylinder.cpp:65-107) ----
 RT_DEV bool quadratic(float A, float B, float C, float &t0, float &t1) {   // pbrt.h:645-659
     const float discrim = B * B - 4.f * A * C;
     if (discrim < 0.f) return false;
@@ -104,13 +105,27 @@ RT_DEV bool quadratic(float A, float B, float C, float &t0, float &t1) {   // pb
     if (t0 > t1) { const float tmp = t0; t0 = t1; t1 = tmp; }
     return true;
 }
-RT_DEV bool sphere_test(const DevScene &sc, unsigned qi, V3 ow, V3 dw, float mint, float maxt, float &t_out) {
+RT_DEV bool quadric_test(const DevScene &sc, unsigned qi, V3 ow, V3 dw, float mint, float maxt, float &t_out) {
     const DevQuadric RT_G &q = RT_GPTR(const DevQuadric, sc.quadrics)[qi];
     const V3 o = xform_point(q.w2o, ow), d = xform_vector(q.w2o, dw);           // WorldToObject(r, &ray) transform.h:128-135
     const float radius = q.radius, zmin = q.zmin, zmax = q.zmax, phiMax = q.phi_max;
-    const float A = d.x * d.x + d.y * d.y + d.z * d.z;
-    const float B = 2 * (d.x * o.x + d.y * o.y + d.z * o.z);
-    const float C = o.x * o.x + o.y * o.y + o.z * o.z - radius * radius;
+    if (q.type == RT_QUADRIC_DISK) {                                            // Disk::Intersect(P) disk.cpp:64-123: zmin = height, zmax = innerRadius
+        if (double(fabsf(d.z)) < 1e-7) return false;
+        const float thit = (zmin - o.z) / d.z;
+        if (thit < mint || thit > maxt) return false;
+        const V3 phit = o + d * thit;
+        const float dist2 = phit.x * phit.x + phit.y * phit.y;
+        if (dist2 > radius * radius || dist2 < zmax * zmax) return false;
+        float phi = atan2f(phit.y, phit.x);
+        if (phi < 0) phi = float(double(phi) + 2. * double(RT_PI));             // "phi += 2. * M_PI": a double sum
+        if (phi > phiMax) return false;
+        t_out = thit;
+        return true;
+    }
+    const bool cyl = q.type == RT_QUADRIC_CYLINDER;                             // Cylinder::Intersect(P) cylinder.cpp:65-107
+    const float A = cyl ? d.x * d.x + d.y * d.y : d.x * d.x + d.y * d.y + d.z * d.z;
+    const float B = cyl ? 2 * (d.x * o.x + d.y * o.y) : 2 * (d.x * o.x + d.y * o.y + d.z * o.z);
+    const float C = cyl ? o.x * o.x + o.y * o.y - radius * radius : o.x * o.x + o.y * o.y + o.z * o.z - radius * radius;
     float t0, t1;
     if (!quadratic(A, B, C, t0, t1)) return false;
     if (t0 > maxt || t1 < mint) return false;
@@ -119,9 +134,11 @@ RT_DEV bool sphere_test(const DevScene &sc, unsigned qi, V3 ow, V3 dw, float min
     V3 phit = o + d * thit;
     float phi = atan2f(phit.y, phit.x);
     if (phi < 0.f) phi += 2.f * RT_PI;
-    if ((zmin > -radius && phit.z < zmin) || (zmax < radius && phit.z > zmax) || phi > phiMax) {
+    const bool clipped = cyl ? (phit.z < zmin || phit.z > zmax || phi > phiMax)
+                             : ((zmin > -radius && phit.z < zmin) || (zmax < radius && phit.z > zmax) || phi > phiMax);
+    if (clipped) {
         if (thit == t1) return false;
-        if (t1 > maxt) return false;
+        if (t1 > maxt) return false;                  // (the cylinder assigns thit = t1 before this test: same outcome)
         thit = t1;
         phit = o + d * thit;
         phi = atan2f(phit.y, phit.x);
@@ -137,7 +154,7 @@ template <bool EXT>
 RT_DEV bool prim_test(const DevScene &sc, unsigned prim, V3 o, V3 d, float mint, float maxt, float &t, float &b1, float &b2) {
     const DevTri RT_G *gt = RT_GPTR(const DevTri, sc.tris) + prim;
     const float4 q0 = gt->q0, q1 = gt->q1, q2 = gt->q2;
-    if (EXT && (__float_as_uint(q2.y) & RT_PRIM_QUADRIC)) { b1 = 0.f; b2 = 0.f; return sphere_test(sc, __float_as_uint(q0.x), o, d, mint, maxt, t); }
+    if (EXT && (__float_as_uint(q2.y) & RT_PRIM_QUADRIC)) { b1 = 0.f; b2 = 0.f; return quadric_test(sc, __float_as_uint(q0.x), o, d, mint, maxt, t); }
     return tri_test(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), mk3(q1.z, q1.w, q2.x), o, d, mint, maxt, t, b1, b2);
 }
 

@@ -415,9 +415,9 @@ int PbrtApi::makeMaterial(const ParamSet &shapeParams) {
 void PbrtApi::Shape(const std::string &n, const ParamList &p) {                     // api.cpp:354-396
     if (!verifyWorld("Shape")) return;
     ParamSet ps(p);
-    if (n == "sphere") { quadricShape(ps); return; }
+    if (n == "sphere" || n == "disk" || n == "cylinder") { quadricShape(n, ps); return; }
     if (n != "trianglemesh") {
-        Error("Unable to load plugin \"%s\" (shape): \"trianglemesh\" and \"sphere\" are on the accelerated path (SURVEY.md rows 12-13)", n.c_str());
+        Error("Unable to load plugin \"%s\" (shape): \"trianglemesh\", \"sphere\", \"disk\" and \"cylinder\" are on the accelerated path (SURVEY.md rows 12-13)", n.c_str());
         return;
     }
     // CreateShape shapes/trianglemesh.cpp:350-406
@@ -462,26 +462,44 @@ void PbrtApi::Shape(const std::string &n, const ParamList &p) {                 
     meshes.push_back(std::move(mesh));
 }
 
-// CreateShape shapes/sphere.cpp:255-264 + Sphere ctor :89-99 + Shape::WorldBound (shape.h:57-59, transform.cpp:148-159)
-void PbrtApi::quadricShape(const ParamSet &ps) {
+// CreateShape + ctor of shapes/sphere.cpp:255-264,:89-99, disk.cpp:131-138,:51-59, cylinder.cpp:183-190,:52-59 and
+// Shape::WorldBound (shape.h:57-59, transform.cpp:148-159)
+void PbrtApi::quadricShape(const std::string &name, const ParamSet &ps) {
     if (inObject) { Error("Object instancing is not on the accelerated path (SURVEY.md row 9); shape ignored"); return; }
     auto clampf = [](float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); };
-    const float radius = ps.FindOneFloat("radius", 1.f);
-    const float z0 = ps.FindOneFloat("zmin", -radius), z1 = ps.FindOneFloat("zmax", radius);
-    const float pm = ps.FindOneFloat("phimax", 360.f);
-    ps.ReportUnused();
     RtQuadric q; std::memset(&q, 0, sizeof q);
-    q.type = RT_QUADRIC_SPHERE;
     std::memcpy(q.object_to_world, ctm.m.m, sizeof q.object_to_world);
     std::memcpy(q.world_to_object, ctm.inv.m, sizeof q.world_to_object);
-    q.radius = radius;
-    q.zmin = clampf(std::fmin(z0, z1), -radius, radius);
-    q.zmax = clampf(std::fmax(z0, z1), -radius, radius);
-    q.theta_min = acosf(clampf(q.zmin / radius, -1.f, 1.f));
-    q.theta_max = acosf(clampf(q.zmax / radius, -1.f, 1.f));
-    q.phi_max = pbrthip::radians(clampf(pm, 0.0f, 360.0f));
-    // world bound of BBox(Point(-radius, -radius, zmin), Point(radius, radius, zmax))
-    const float lo[3] = {-radius, -radius, q.zmin}, hi[3] = {radius, radius, q.zmax};
+    float lo[3], hi[3];
+    if (name == "sphere") {
+        const float radius = ps.FindOneFloat("radius", 1.f);
+        const float z0 = ps.FindOneFloat("zmin", -radius), z1 = ps.FindOneFloat("zmax", radius);
+        const float pm = ps.FindOneFloat("phimax", 360.f);
+        q.type = RT_QUADRIC_SPHERE;
+        q.radius = radius;
+        q.zmin = clampf(std::fmin(z0, z1), -radius, radius);
+        q.zmax = clampf(std::fmax(z0, z1), -radius, radius);
+        q.theta_min = acosf(clampf(q.zmin / radius, -1.f, 1.f));
+        q.theta_max = acosf(clampf(q.zmax / radius, -1.f, 1.f));
+        q.phi_max = pbrthip::radians(clampf(pm, 0.0f, 360.0f));
+        lo[0] = -radius; lo[1] = -radius; lo[2] = q.zmin; hi[0] = radius; hi[1] = radius; hi[2] = q.zmax;
+    } else if (name == "disk") {
+        const float height = ps.FindOneFloat("height", 0.f), radius = ps.FindOneFloat("radius", 1.f);
+        const float inner = ps.FindOneFloat("innerradius", 0.f), pm = ps.FindOneFloat("phimax", 360.f);
+        q.type = RT_QUADRIC_DISK;
+        q.radius = radius; q.zmin = height; q.zmax = inner;
+        q.phi_max = pbrthip::radians(clampf(pm, 0.0f, 360.0f));
+        lo[0] = -radius; lo[1] = -radius; lo[2] = height; hi[0] = radius; hi[1] = radius; hi[2] = height;
+    } else {
+        const float radius = ps.FindOneFloat("radius", 1.f);
+        const float z0 = ps.FindOneFloat("zmin", -1.f), z1 = ps.FindOneFloat("zmax", 1.f), pm = ps.FindOneFloat("phimax", 360.f);
+        q.type = RT_QUADRIC_CYLINDER;
+        q.radius = radius; q.zmin = std::fmin(z0, z1); q.zmax = std::fmax(z0, z1);
+        q.phi_max = pbrthip::radians(clampf(pm, 0.0f, 360.0f));
+        lo[0] = -radius; lo[1] = -radius; lo[2] = q.zmin; hi[0] = radius; hi[1] = radius; hi[2] = q.zmax;
+    }
+    ps.ReportUnused();
+    // world bound of the object bound BBox(lo, hi)
     float bmin[3] = {INFINITY, INFINITY, INFINITY}, bmax[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int c = 0; c < 8; ++c) {
         const float pt[3] = {(c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]};
@@ -492,7 +510,7 @@ void PbrtApi::quadricShape(const ParamSet &ps) {
     mesh.flags = uint8_t(((gs.reverseOrientation ^ ctm.swaps_handedness()) ? 1 : 0) | 2);
     mesh.verts = {bmin[0], bmin[1], bmin[2], bmax[0], bmax[1], bmax[2], bmin[0], bmin[1], bmin[2]};
     mesh.light = -1;
-    if (!gs.areaLight.empty()) Error("Area lights on quadrics are not on the accelerated path; the sphere is rendered as a non-emitting surface");
+    if (!gs.areaLight.empty()) Error("Area lights on quadrics are not on the accelerated path; the shape is rendered as a non-emitting surface");
     mesh.material = makeMaterial(ps);
     quadrics.push_back(q);
     meshes.push_back(std::move(mesh));

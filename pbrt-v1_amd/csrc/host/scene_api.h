@@ -128,7 +128,7 @@ class PbrtApi : public DirectiveSink {
     bool inObject;
     bool verifyOptions(const char *fn); bool verifyWorld(const char *fn);
     int makeMaterial(const ParamSet &shapeParams);
-    void quadricShape(const ParamSet &ps);
+    void quadricShape(const std::string &name, const ParamSet &ps);
     Float3 spectrumParam(const ParamSet &geom, const ParamSet &mat, const std::string &n, Float3 d);
     float floatParam(const ParamSet &geom, const ParamSet &mat, const std::string &n, float d);
     void resetWorld();

@@ -30,6 +30,12 @@ SPHERES = ('AttributeBegin\nMaterial "matte" "color Kd" [.7 .6 .2]\nTranslate 15
            'AttributeBegin\nMaterial "mirror"\nTranslate 300 330 420\nRotate -70 1 0.2 0\nShape "sphere" "float radius" [90] "float zmin" [-60] "float zmax" [70] "float phimax" [250]\nAttributeEnd\n'
            'AttributeBegin\nMaterial "plastic" "color Kd" [.2 .3 .7] "float roughness" [.15]\nReverseOrientation\nTranslate 120 380 250\nScale -1 1 1\nShape "sphere" "float radius" [60]\nAttributeEnd\n')
 
+QUADRICS = ('AttributeBegin\nMaterial "matte" "color Kd" [.7 .6 .2]\nTranslate 150 0 330\nRotate -90 1 0 0\nShape "cylinder" "float radius" [70] "float zmin" [0] "float zmax" [180]\n'
+            'Translate 0 0 180\nShape "disk" "float radius" [70]\nAttributeEnd\n'
+            'AttributeBegin\nMaterial "mirror"\nTranslate 400 200 380\nRotate 35 0 1 0\nRotate 60 1 0 0\nShape "disk" "float radius" [110] "float innerradius" [40] "float phimax" [300] "float height" [10]\nAttributeEnd\n'
+            'AttributeBegin\nMaterial "glass" "float index" [1.4]\nTranslate 380 90 180\nRotate 20 0 0 1\nScale 1 .8 1\nShape "cylinder" "float radius" [60] "float zmin" [-50] "float zmax" [70] "float phimax" [270]\nAttributeEnd\n'
+            'AttributeBegin\nMaterial "plastic" "color Kd" [.2 .3 .7]\nReverseOrientation\nTranslate 100 400 250\nRotate 45 1 1 0\nShape "cylinder" "float radius" [40] "float zmin" [-60] "float zmax" [60]\nAttributeEnd\n')
+
 CONFIGS = {
     # name: cornell_scene kwargs  (all keyed RNG + counted rays)
     "whitted_point": dict(xres=48, yres=48, integrator="whitted", world_kwargs=dict(point_light=True, area_light=False)),
@@ -79,6 +85,10 @@ CONFIGS = {
     "sphere_direct": dict(xres=40, yres=40, integrator="directlighting", xsamples=2, ysamples=1, jitter=True, world_kwargs=dict(extra=SPHERES)),
     "sphere_path_grid": dict(xres=32, yres=32, integrator="path", xsamples=2, ysamples=2, accelerator="grid", world_kwargs=dict(extra=SPHERES)),
     "sphere_path_soup": dict(xres=32, yres=32, integrator="path", xsamples=2, ysamples=2, jitter=True, soup_tris=500, world_kwargs=dict(extra=SPHERES)),
+    # disks and cylinders (full, annular, partial phi, transformed, reversed)
+    "quadrics_whitted": dict(xres=48, yres=48, integrator="whitted", world_kwargs=dict(point_light=True, extra=QUADRICS)),
+    "quadrics_direct_grid": dict(xres=40, yres=40, integrator="directlighting", xsamples=2, ysamples=1, jitter=True, accelerator="grid", world_kwargs=dict(extra=QUADRICS)),
+    "quadrics_path": dict(xres=32, yres=32, integrator="path", xsamples=2, ysamples=2, world_kwargs=dict(extra=QUADRICS)),
     # plastic (Lambertian + Blinn microfacet lobes): text substitution of two Material lines below
     "plastic_whitted": dict(xres=40, yres=40, integrator="whitted", world_kwargs=dict(point_light=True)),
     "plastic_direct_ns2": dict(xres=32, yres=32, integrator="directlighting", xsamples=2, ysamples=1, jitter=True, world_kwargs=dict(light_nsamples=2)),

@@ -78,7 +78,7 @@ def test_primitive_order_is_kdtree_refinement_order(pkg):
 
 
 def test_unsupported_plugins_are_errors_not_silent(pkg):
-    ps = pkg.ParsedScene(text=BASE % ("", 'LightSource "point"\nShape "cylinder" "float radius" [1]\n' + TRI))
+    ps = pkg.ParsedScene(text=BASE % ("", 'LightSource "point"\nShape "cone" "float radius" [1]\n' + TRI))
     assert ps.errors >= 1 and ps.n_tris == 1
     ps = pkg.ParsedScene(text=BASE % ('Camera "fisheye"', 'LightSource "point"\n' + TRI))
     assert not ps.valid
@@ -91,11 +91,12 @@ def test_unsupported_plugins_are_errors_not_silent(pkg):
 def test_f4_plugins_are_accepted(pkg):
     """sphere, spot / distant, plastic, orthographic / environment parse without errors."""
     world = ('LightSource "spot" "point from" [0 5 0] "point to" [0 0 0]\nLightSource "distant"\nMaterial "plastic" "float roughness" [.2]\n'
-             'AttributeBegin\nTranslate 1 2 3\nShape "sphere" "float radius" [2] "float zmax" [1]\nAttributeEnd\n' + TRI)
+             'AttributeBegin\nTranslate 1 2 3\nShape "sphere" "float radius" [2] "float zmax" [1]\nAttributeEnd\n'
+             'Shape "disk" "float radius" [.5] "float height" [1]\nShape "cylinder" "float radius" [.25]\n' + TRI)
     for cam in ('Camera "orthographic"', 'Camera "environment"', ""):
         ps = pkg.ParsedScene(text=BASE % (cam, world))
         assert ps.valid and ps.errors == 0
-        assert ps.n_tris == 2 and ps.n_lights == 2            # the sphere is one primitive slot
+        assert ps.n_tris == 4 and ps.n_lights == 2            # every quadric is one primitive slot
         v = ps.tri_verts()[0]                                 # its slot = world bound {pMin, pMax, pMin}
         assert np.allclose(v[0], [-1, 0, 1]) and np.allclose(v[1], [3, 4, 4]) and np.array_equal(v[0], v[2])
 
