@@ -33,8 +33,8 @@ extern "C" {
 
 typedef struct RtScene RtScene; /* opaque */
 
-/* ---- materials: materials/matte.cpp:46-64, glass.cpp:46-63, mirror.cpp:42-55, plastic.cpp:47-69 ---- */
-enum { RT_MAT_MATTE = 0, RT_MAT_MIRROR = 1, RT_MAT_GLASS = 2, RT_MAT_PLASTIC = 3 };
+/* ---- materials: materials/matte.cpp:46-64, glass.cpp:46-63, mirror.cpp:42-55, plastic.cpp:47-69, uber.cpp:52-89 ---- */
+enum { RT_MAT_MATTE = 0, RT_MAT_MIRROR = 1, RT_MAT_GLASS = 2, RT_MAT_PLASTIC = 3, RT_MAT_UBER = 4 };
 typedef struct RtMaterial {
     int32_t type;
     float kd[3];   /* matte/plastic Kd  | mirror/glass Kr  (already .Clamp()'ed >= 0) */
@@ -42,7 +42,9 @@ typedef struct RtMaterial {
     float sigma;   /* matte: Oren-Nayar sigma in degrees, clamped [0,90]; 0 = Lambertian */
     float ior;     /* glass "index"                                              */
     float ks[3];   /* plastic Ks (.Clamp()'ed): Microfacet(Ks, FresnelDielectric(1.5, 1), Blinn(1/roughness)) */
-    float roughness; /* plastic "roughness"                                       */
+    float roughness; /* plastic / uber "roughness"                                */
+    float kr[3];   /* uber: op*Kr (SpecularReflection, FresnelDielectric(1.5, 1)).  For uber kd = op*Kd, ks = op*Ks,
+                    * kt = 1 - op (SpecularTransmission(1 - op, 1, 1), present iff op != 1), ior = 1; lobe order T, D, G, R */
 } RtMaterial;
 
 /* ---- lights: lights/point.cpp:49-69, lights/area.cpp:28-105, lights/spot.cpp:54-79, lights/distant.cpp:51-62 ---- */

@@ -25,7 +25,9 @@ struct DevMaterial {
     float ior;
     int has_r, has_t;  // glass.cpp:56-61: a lobe exists only if its colour is not black
     float ks[3];       // plastic: Microfacet reflectance
-    float exponent;    // plastic: Blinn exponent = 1/roughness, capped at 1000 (reflection.h:313)
+    float exponent;    // plastic / uber: Blinn exponent = 1/roughness, capped at 1000 (reflection.h:313)
+    float kr[3];       // uber: SpecularReflection reflectance (Fresnel 1.5 / 1)
+    int has_g, has_kr; // uber: glossy / specular-reflection lobes present (non-black, uber.cpp:71-86)
 };
 
 struct DevLight {

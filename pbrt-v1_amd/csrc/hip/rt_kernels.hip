@@ -530,8 +530,10 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
         o.has_t = (m.kt[0] != 0.f || m.kt[1] != 0.f || m.kt[2] != 0.f);
         for (int c = 0; c < 3; ++c) o.ks[c] = m.ks[c];
         o.exponent = 0.f;
-        if (m.type == RT_MAT_PLASTIC) { s->has_ext = true; float e = 1.f / m.roughness; if (e > 1000.f || std::isnan(e)) e = 1000.f; o.exponent = e; }
-        if (m.type < RT_MAT_MATTE || m.type > RT_MAT_PLASTIC) return fail(RT_EINVAL, "rt_scene_create: unknown material type");
+        for (int c = 0; c < 3; ++c) o.kr[c] = m.kr[c];
+        o.has_g = (m.ks[0] != 0.f || m.ks[1] != 0.f || m.ks[2] != 0.f); o.has_kr = (m.kr[0] != 0.f || m.kr[1] != 0.f || m.kr[2] != 0.f);
+        if (m.type == RT_MAT_PLASTIC || m.type == RT_MAT_UBER) { s->has_ext = true; float e = 1.f / m.roughness; if (e > 1000.f || std::isnan(e)) e = 1000.f; o.exponent = e; }
+        if (m.type < RT_MAT_MATTE || m.type > RT_MAT_UBER) return fail(RT_EINVAL, "rt_scene_create: unknown material type");
         if (m.type == RT_MAT_MATTE && m.sigma != 0.f) {
             float sigma = (3.14159265358979323846f / 180.f) * m.sigma;
             float sigma2 = sigma * sigma;

@@ -7,7 +7,7 @@
 namespace rt {
 
 // BxDFType bits (core/reflection.h:52-68)
-enum { BX_REFLECTION = 1, BX_TRANSMISSION = 2, BX_DIFFUSE = 4, BX_EXT = 8, BX_SPECULAR = 16,
+enum { BX_REFLECTION = 1, BX_TRANSMISSION = 2, BX_DIFFUSE = 4, BX_GLOSSY = 8, BX_SPECULAR = 16,
        BX_ALL = 31 };
 
 struct Vertex {
@@ -194,12 +194,24 @@ RT_DEV float glossy_pdf(MatRef m, V3 wo, V3 wi) { return (wo.z * wi.z > 0.f) ? b
 
 // lobes in the order the material adds them: matte {diffuse}; plastic {diffuse, glossy} (plastic.cpp:66-67);
 // mirror {specular R}; glass {specular R, specular T} (glass.cpp:56-61, only the non-black ones)
+// non-specular lobes of a material: matte {D}; plastic {D, G}; uber {D if op*Kd != 0, G if op*Ks != 0} (uber.cpp:67-79)
+template <bool EXT> RT_DEV bool mat_has_diffuse(MatRef m) { return m.type == RT_MAT_MATTE || (EXT && (m.type == RT_MAT_PLASTIC || (m.type == RT_MAT_UBER && m.has_r))); }
+template <bool EXT> RT_DEV bool mat_has_glossy(MatRef m) { return EXT && (m.type == RT_MAT_PLASTIC || (m.type == RT_MAT_UBER && m.has_g)); }
+RT_DEV bool flags_match(int type, int flags) { return (type & flags) == type; }
+
 template <bool EXT>
 RT_DEV int bsdf_num_components(MatRef m, int flags) {
     int n = 0;
+    if (EXT && m.type == RT_MAT_UBER) {               // lobe order T, D, G, R (uber.cpp:62-87)
+        if (m.has_t && flags_match(BX_TRANSMISSION | BX_SPECULAR, flags)) ++n;
+        if (m.has_r && flags_match(BX_REFLECTION | BX_DIFFUSE, flags)) ++n;
+        if (m.has_g && flags_match(BX_REFLECTION | BX_GLOSSY, flags)) ++n;
+        if (m.has_kr && flags_match(BX_REFLECTION | BX_SPECULAR, flags)) ++n;
+        return n;
+    }
     if (m.type == RT_MAT_MATTE || (EXT && m.type == RT_MAT_PLASTIC)) {
         if (((BX_REFLECTION | BX_DIFFUSE) & flags) == (BX_REFLECTION | BX_DIFFUSE)) ++n;
-        if (EXT && m.type == RT_MAT_PLASTIC && ((BX_REFLECTION | BX_EXT) & flags) == (BX_REFLECTION | BX_EXT)) ++n;
+        if (EXT && m.type == RT_MAT_PLASTIC && ((BX_REFLECTION | BX_GLOSSY) & flags) == (BX_REFLECTION | BX_GLOSSY)) ++n;
     } else {
         if (m.has_r && ((BX_REFLECTION | BX_SPECULAR) & flags) == (BX_REFLECTION | BX_SPECULAR)) ++n;
         if (m.type == RT_MAT_GLASS && m.has_t && ((BX_TRANSMISSION | BX_SPECULAR) & flags) == (BX_TRANSMISSION | BX_SPECULAR)) ++n;
@@ -212,15 +224,15 @@ template <bool EXT> RT_DEV int bsdf_total_components(MatRef m) { return bsdf_num
 template <bool EXT>
 RT_DEV V3 bsdf_f_lobes(MatRef m, V3 wo, V3 wi, int flags) {
     V3 f = mk3(0.f);
-    if (((BX_REFLECTION | BX_DIFFUSE) & flags) == (BX_REFLECTION | BX_DIFFUSE)) f = f + diffuse_f(m, wo, wi);
-    if (EXT && m.type == RT_MAT_PLASTIC && ((BX_REFLECTION | BX_EXT) & flags) == (BX_REFLECTION | BX_EXT)) f = f + microfacet_f(m, wo, wi);
+    if (mat_has_diffuse<EXT>(m) && flags_match(BX_REFLECTION | BX_DIFFUSE, flags)) f = f + diffuse_f(m, wo, wi);
+    if (mat_has_glossy<EXT>(m) && flags_match(BX_REFLECTION | BX_GLOSSY, flags)) f = f + microfacet_f(m, wo, wi);
     return f;
 }
 
 // BSDF::f reflection.cpp:480-494 (flags = BSDF_ALL): only the non-specular lobes have a non-zero f
 template <bool EXT>
 RT_DEV V3 bsdf_f(MatRef m, const Vertex &v, V3 woW, V3 wiW) {
-    if (m.type != RT_MAT_MATTE && !(EXT && m.type == RT_MAT_PLASTIC)) return mk3(0.f);
+    if (!mat_has_diffuse<EXT>(m) && !mat_has_glossy<EXT>(m)) return mk3(0.f);
     V3 wi = to_local(v, wiW), wo = to_local(v, woW);
     if (dot3(wiW, v.nn) * dot3(woW, v.nn) > 0) return bsdf_f_lobes<EXT>(m, wo, wi, BX_ALL & ~BX_TRANSMISSION);   // BRDFs only
     return mk3(0.f);                                                                                         // BTDFs only: none
@@ -231,11 +243,11 @@ template <bool EXT>
 RT_DEV float bsdf_pdf(MatRef m, const Vertex &v, V3 woW, V3 wiW) {
     int nc = bsdf_total_components<EXT>(m);
     if (nc == 0) return 0.f;
-    if (m.type != RT_MAT_MATTE && !(EXT && m.type == RT_MAT_PLASTIC)) return 0.f / float(nc);
+    if (!mat_has_diffuse<EXT>(m) && !mat_has_glossy<EXT>(m)) return 0.f / float(nc);
     V3 wo = to_local(v, woW), wi = to_local(v, wiW);
     float pdf = 0.f;
-    pdf += diffuse_pdf(wo, wi);
-    if (EXT && m.type == RT_MAT_PLASTIC) pdf += glossy_pdf(m, wo, wi);
+    if (mat_has_diffuse<EXT>(m)) pdf += diffuse_pdf(wo, wi);
+    if (mat_has_glossy<EXT>(m)) pdf += glossy_pdf(m, wo, wi);
     return pdf / nc;
 }
 
@@ -249,11 +261,20 @@ RT_DEV V3 bsdf_sample_f(MatRef m, const Vertex &v, V3 woW, V3 &wiW, float u1, fl
     int which = min(int(floorf(u3 * matching)), matching - 1);     // Floor2Int(double(u3*matching))
     V3 wo = to_local(v, woW);
     V3 wi, f;
-    if (m.type == RT_MAT_MATTE || (EXT && m.type == RT_MAT_PLASTIC)) {
-        const bool diffuse_has = ((BX_REFLECTION | BX_DIFFUSE) & flags) == (BX_REFLECTION | BX_DIFFUSE);
-        const bool glossy_has = EXT && m.type == RT_MAT_PLASTIC && ((BX_REFLECTION | BX_EXT) & flags) == (BX_REFLECTION | BX_EXT);
-        const bool pick_diffuse = !EXT || (diffuse_has && which == 0);
-        if (pick_diffuse) {
+    const bool diffuse_has = mat_has_diffuse<EXT>(m) && flags_match(BX_REFLECTION | BX_DIFFUSE, flags);
+    const bool glossy_has = mat_has_glossy<EXT>(m) && flags_match(BX_REFLECTION | BX_GLOSSY, flags);
+    // which lobe `which` designates: matte / plastic {D, G}; uber {T, D, G, R}; mirror / glass {R, T}
+    int pick = 0;                                                   // 1 = diffuse, 2 = glossy, 3 = specular R, 4 = specular T
+    if (EXT && m.type == RT_MAT_UBER) {
+        int idx = which;
+        const bool mT = m.has_t && flags_match(BX_TRANSMISSION | BX_SPECULAR, flags), mR = m.has_kr && flags_match(BX_REFLECTION | BX_SPECULAR, flags);
+        if (mT && idx-- == 0) pick = 4;
+        else if (diffuse_has && idx-- == 0) pick = 1;
+        else if (glossy_has && idx-- == 0) pick = 2;
+        else if (mR) pick = 3;
+    } else if (diffuse_has || glossy_has) pick = (!glossy_has || (diffuse_has && which == 0)) ? 1 : 2;   // glossy_has is constant false without EXT
+    if (pick == 1 || pick == 2) {
+        if (pick == 1) {
             // BxDF::Sample_f reflection.cpp:219-226 with CosineSampleHemisphere mc.h:38-44
             float dx, dy; concentric_disk(u1, u2, dx, dy);
             wi = mk3(dx, dy, sqrtf(fmaxf(0.f, 1.f - dx * dx - dy * dy)));
@@ -261,7 +282,7 @@ RT_DEV V3 bsdf_sample_f(MatRef m, const Vertex &v, V3 woW, V3 &wiW, float u1, fl
             pdf = diffuse_pdf(wo, wi);
             if (pdf == 0.f) return mk3(0.f);
             sampled = BX_REFLECTION | BX_DIFFUSE;
-            if (glossy_has) pdf += glossy_pdf(m, wo, wi);                        // the other matching lobe, :436-443
+            if (glossy_has) pdf += glossy_pdf(m, wo, wi);                        // the other matching non-specular lobe, :436-443
         } else {
             // Microfacet::Sample_f reflection.cpp:235-240 with Blinn::Sample_f :246-262
             const float costheta = powf(u1, 1.f / (m.exponent + 1));
@@ -273,7 +294,7 @@ RT_DEV V3 bsdf_sample_f(MatRef m, const Vertex &v, V3 woW, V3 &wiW, float u1, fl
             pdf = ((m.exponent + 1.f) * powf(costheta, m.exponent)) / (2.f * RT_PI * 4.f * dot3(wo, H));
             if (dot3(wo, H) <= 0.f) pdf = 0.f;
             if (pdf == 0.f) return mk3(0.f);
-            sampled = BX_REFLECTION | BX_EXT;
+            sampled = BX_REFLECTION | BX_GLOSSY;
             if (diffuse_has) pdf += diffuse_pdf(wo, wi);
         }
         wiW = to_world(v, wi);
@@ -284,13 +305,14 @@ RT_DEV V3 bsdf_sample_f(MatRef m, const Vertex &v, V3 woW, V3 &wiW, float u1, fl
     }
     // specular lobes, in the order the material added them (glass.cpp:56-61, mirror.cpp:51-53)
     bool reflect_has = m.has_r && ((BX_REFLECTION | BX_SPECULAR) & flags) == (BX_REFLECTION | BX_SPECULAR);
-    bool pick_reflect = reflect_has && which == 0;
+    bool pick_reflect = (EXT && m.type == RT_MAT_UBER) ? pick == 3 : (reflect_has && which == 0);
     if (pick_reflect) {
         // SpecularReflection::Sample_f reflection.cpp:96-103
         wi = mk3(-wo.x, -wo.y, wo.z);
         pdf = 1.f;
-        float F = (m.type == RT_MAT_GLASS) ? fresnel_dielectric(wo.z, 1.f, m.ior) : 1.f;
-        f = div_s(mk3(F) * mat_color(m.r), fabsf(wi.z));
+        const bool uber = EXT && m.type == RT_MAT_UBER;
+        float F = (m.type == RT_MAT_GLASS) ? fresnel_dielectric(wo.z, 1.f, m.ior) : (uber ? fresnel_dielectric(wo.z, 1.5f, 1.f) : 1.f);
+        f = div_s(mk3(F) * (uber ? mat_color(m.kr) : mat_color(m.r)), fabsf(wi.z));
         sampled = BX_REFLECTION | BX_SPECULAR;
     } else {
         // SpecularTransmission::Sample_f reflection.cpp:104-127

@@ -383,7 +383,7 @@ int PbrtApi::makeMaterial(const ParamSet &shapeParams) {
     auto clamp0 = [](Float3 c) { Float3 r = {c.x < 0.f ? 0.f : c.x, c.y < 0.f ? 0.f : c.y, c.z < 0.f ? 0.f : c.z}; return r; };
     RtMaterial m; std::memset(&m, 0, sizeof m);
     std::string name = gs.material;
-    if (name != "matte" && name != "mirror" && name != "glass" && name != "plastic") {
+    if (name != "matte" && name != "mirror" && name != "glass" && name != "plastic" && name != "uber") {
         Error("Unable to load plugin \"%s\" (material); using \"matte\" (api.cpp:376-379)", name.c_str());
         name = "matte";
     }
@@ -399,6 +399,17 @@ int PbrtApi::makeMaterial(const ParamSet &shapeParams) {
         Float3 ks = clamp0(spectrumParam(shapeParams, mp, "Ks", Float3{1.f, 1.f, 1.f}));
         m.type = RT_MAT_PLASTIC; m.kd[0] = kd.x; m.kd[1] = kd.y; m.kd[2] = kd.z; m.ks[0] = ks.x; m.ks[1] = ks.y; m.ks[2] = ks.z;
         m.roughness = floatParam(shapeParams, mp, "roughness", .1f); m.ior = 1.f;
+    } else if (name == "uber") {                                                    // uber.cpp:52-100
+        Float3 kd = clamp0(spectrumParam(shapeParams, mp, "Kd", Float3{1.f, 1.f, 1.f}));
+        Float3 ks = clamp0(spectrumParam(shapeParams, mp, "Ks", Float3{1.f, 1.f, 1.f}));
+        Float3 kr = clamp0(spectrumParam(shapeParams, mp, "Kr", Float3{0.f, 0.f, 0.f}));
+        Float3 op = clamp0(spectrumParam(shapeParams, mp, "opacity", Float3{1.f, 1.f, 1.f}));
+        m.type = RT_MAT_UBER; m.ior = 1.f;
+        m.kt[0] = -op.x + 1.f; m.kt[1] = -op.y + 1.f; m.kt[2] = -op.z + 1.f;        // SpecularTransmission(-op + Spectrum(1.), 1., 1.)
+        m.kd[0] = op.x * kd.x; m.kd[1] = op.y * kd.y; m.kd[2] = op.z * kd.z;
+        m.ks[0] = op.x * ks.x; m.ks[1] = op.y * ks.y; m.ks[2] = op.z * ks.z;
+        m.kr[0] = op.x * kr.x; m.kr[1] = op.y * kr.y; m.kr[2] = op.z * kr.z;
+        m.roughness = floatParam(shapeParams, mp, "roughness", .1f);
     } else if (name == "mirror") {                                                  // mirror.cpp:42-61
         Float3 kr = clamp0(spectrumParam(shapeParams, mp, "Kr", Float3{1.f, 1.f, 1.f}));
         m.type = RT_MAT_MIRROR; m.kd[0] = kr.x; m.kd[1] = kr.y; m.kd[2] = kr.z; m.ior = 1.f;

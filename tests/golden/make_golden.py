@@ -93,6 +93,10 @@ CONFIGS = {
     "plastic_whitted": dict(xres=40, yres=40, integrator="whitted", world_kwargs=dict(point_light=True)),
     "plastic_direct_ns2": dict(xres=32, yres=32, integrator="directlighting", xsamples=2, ysamples=1, jitter=True, world_kwargs=dict(light_nsamples=2)),
     "plastic_path": dict(xres=32, yres=32, integrator="path", xsamples=2, ysamples=2, jitter=True, world_kwargs=dict(glass_sphere_tris=blob)),
+    # uber (T, D, G, R lobes): text substitution of two Material lines below
+    "uber_whitted": dict(xres=40, yres=40, integrator="whitted", world_kwargs=dict(point_light=True)),
+    "uber_direct": dict(xres=32, yres=32, integrator="directlighting", xsamples=2, ysamples=1, jitter=True),
+    "uber_path": dict(xres=32, yres=32, integrator="path", xsamples=2, ysamples=2, jitter=True, maxdepth=6),
     # orthographic / environment cameras: text substitution of the Camera line below
     "ortho_whitted_lens": dict(xres=40, yres=32, integrator="whitted", xsamples=2, ysamples=1, jitter=True, lensradius=6.0, focaldistance=900.0),
     "ortho_path": dict(xres=32, yres=32, integrator="path", xsamples=2, ysamples=2),
@@ -133,6 +137,11 @@ def main():
             text = text.replace('Material "matte" "color Kd" [0.73 0.73 0.73]', 'Material "plastic" "color Kd" [0.5 0.5 0.55] "color Ks" [0.4 0.4 0.4] "float roughness" [0.08]')
             text = text.replace('Material "matte" "color Kd" [0.14 0.45 0.091]', 'Material "plastic" "color Kd" [0.1 0.4 0.1] "color Ks" [0.6 0.5 0.5] "float roughness" [0.3]')
             assert text.count('"plastic"') >= 2, text[:2000]
+        if name.startswith("uber_"):
+            text = text.replace('Material "matte" "color Kd" [0.73 0.73 0.73]', 'Material "uber" "color Kd" [0.5 0.5 0.55] "color Ks" [0.3 0.3 0.3] "color Kr" [0.2 0.25 0.2] "float roughness" [0.12]')
+            text = text.replace('Material "matte" "color Kd" [0.14 0.45 0.091]', 'Material "uber" "color Kd" [0.1 0.4 0.1] "color Ks" [0 0 0] "color opacity" [0.6 0.7 0.6]')
+            text = text.replace('Material "matte" "color Kd" [0.63 0.065 0.05]', 'Material "uber" "color Kd" [0 0 0] "color Ks" [0.5 0.4 0.4] "color Kr" [0.4 0.1 0.1] "color opacity" [1 1 0.5] "float roughness" [0.3]')
+            assert text.count('"uber"') >= 3, text[:3000]
         if name.startswith("ortho_"):
             text = text.replace('Camera "perspective" "float fov" [39.3]', 'Camera "orthographic" "float screenwindow" [-300 300 -290 290]')
             assert "orthographic" in text

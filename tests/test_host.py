@@ -82,7 +82,7 @@ def test_unsupported_plugins_are_errors_not_silent(pkg):
     assert ps.errors >= 1 and ps.n_tris == 1
     ps = pkg.ParsedScene(text=BASE % ('Camera "fisheye"', 'LightSource "point"\n' + TRI))
     assert not ps.valid
-    ps = pkg.ParsedScene(text=BASE % ("", 'Material "uber"\nLightSource "point"\n' + TRI))
+    ps = pkg.ParsedScene(text=BASE % ("", 'Material "substrate"\nLightSource "point"\n' + TRI))
     assert ps.errors >= 1 and ps.n_materials == 1        # falls back to matte (api.cpp:376-379)
     ps = pkg.ParsedScene(text=BASE % ("", 'LightSource "goniometric"\n' + TRI))
     assert ps.errors >= 1 and ps.n_lights == 0
