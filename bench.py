@@ -115,7 +115,8 @@ def main():
 
     text, label, crop = workload(args.workload)
     ps = pkg.ParsedScene(text=text)
-    ps.set_shard(rank, world, args.tile_pixels)
+    emu = int(os.environ.get("PBRT_BENCH_EMULATE_WORLD", "0"))      # debugging aid: time rank 0's share of an N-rank job on one GPU
+    ps.set_shard(rank, emu if (emu > 1 and world == 1) else world, args.tile_pixels)
     ds = pkg.DeviceScene(ps, device=local_rank)
     info = ds.accel_info()
     film = torch.zeros((5, ps.height, ps.width), dtype=torch.float32, device="cuda")
