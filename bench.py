@@ -124,13 +124,17 @@ def main():
     ds.set_stream(stream.cuda_stream)
     ds.bind_film(film.data_ptr())
 
+    # the host side of the boundary: the resolved film lands in page-locked buffers that are reused every frame
+    host_rgb = torch.empty((ps.height, ps.width, 3), dtype=torch.float32, pin_memory=True).numpy() if rank == 0 else None
+    host_alpha = torch.empty((ps.height, ps.width), dtype=torch.float32, pin_memory=True).numpy() if rank == 0 else None
+
     def step():
         film.zero_()
         ds.render(sync=False)
         if dist is not None:
             dist.all_reduce(film, op=dist.ReduceOp.SUM)
         if rank == 0:
-            return ds.film()          # ImageFilm::WriteImage normalisation (synchronises)
+            return ds.film(out=(host_rgb, host_alpha))          # ImageFilm::WriteImage normalisation (synchronises)
         return None
 
     def fence():

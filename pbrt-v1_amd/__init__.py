@@ -320,9 +320,17 @@ class DeviceScene:
         _chk(hip_lib().rt_film_read(self._s, out.ctypes.data))
         return out
 
-    def film(self, premultiply: bool | None = None):
-        rgb = np.zeros((self.parsed.height, self.parsed.width, 3), np.float32)
-        alpha = np.zeros((self.parsed.height, self.parsed.width), np.float32)
+    def film(self, premultiply: bool | None = None, out=None):
+        """rt_film_resolve: the film as ImageFilm::WriteImage hands it to the image writer.  `out` = (rgb[H,W,3], alpha[H,W])
+        float32 C-contiguous arrays to fill (e.g. views of page-locked memory, reused across frames); allocated if omitted."""
+        h, w = self.parsed.height, self.parsed.width
+        if out is None:
+            rgb = np.empty((h, w, 3), np.float32); alpha = np.empty((h, w), np.float32)
+        else:
+            rgb, alpha = out
+            if rgb.shape != (h, w, 3) or alpha.shape != (h, w) or rgb.dtype != np.float32 or alpha.dtype != np.float32 \
+                    or not rgb.flags.c_contiguous or not alpha.flags.c_contiguous:
+                raise ValueError("film(out=...): need C-contiguous float32 arrays of shape (H,W,3) and (H,W)")
         pm = self.parsed.premultiply if premultiply is None else premultiply
         _chk(hip_lib().rt_film_resolve(self._s, int(pm), rgb.ctypes.data, alpha.ctypes.data))
         return rgb, alpha

@@ -188,13 +188,15 @@ __global__ __launch_bounds__(256) void film_gather_kernel(const DevFrame *__rest
             __syncthreads();
             // one thread per column resolves where that sample pixel's records live in this shard's buffer (64-bit tile
             // arithmetic once per column, not once per staged float4)
+            bool mine_col = false;
             if (int(threadIdx.x) < ncols) {
                 const unsigned long long pixel = (unsigned long long)(sy - fr.y_start) * ew + (cx + int(threadIdx.x) - fr.x_start);
                 const unsigned long long tile = pixel / fr.tile_pixels;
                 const bool mine = int(tile % fr.shard_count) == fr.shard_index;
                 colbase[threadIdx.x] = mine ? ((tile / fr.shard_count) * per_tile + (pixel % fr.tile_pixels) * fr.spp) * 2 : ~0ull;
+                mine_col = mine;
             }
-            __syncthreads();
+            if (!__syncthreads_or(mine_col)) continue;        // this shard owns no sample pixel of this row chunk (7 of 8 chunks at 8 ranks)
             const int per_col = fr.spp * 2;
             int c = int(threadIdx.x) / per_col, k = int(threadIdx.x) - c * per_col;
             for (; c < ncols;) {
