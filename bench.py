@@ -63,6 +63,14 @@ def workload(name: str):
     return text, label, crop
 
 
+def ref_runner():
+    """oracle/ref_runner.py (test infrastructure: runs the compiled reference in oracle/_ref)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("pbrt_ref_runner", os.path.join(ROOT, "oracle", "ref_runner.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    return m
+
+
 def cpu_baseline(pkg, name: str, crop, budget_s: float = 25.0):
     """Time the compiled reference (single thread) on a crop window of the same frame."""
     from pbrt_v1_amd import scenes
@@ -73,7 +81,7 @@ def cpu_baseline(pkg, name: str, crop, budget_s: float = 25.0):
     text = re.sub(r'Accelerator "(\w+)"', r'Accelerator "countaccel" "string inner" ["\1"]', text)
     try:
         t0 = time.time()
-        _, _, st = pkg.run_reference(text, keyed=False, timeout=600)
+        _, _, st = ref_runner().run_reference(text, keyed=False, timeout=600)
         rays = st["closest_rays"] + st["any_rays"]
         return {"value": round(rays / st["render_s"] / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "reference",
                 "sample": "oracle/_ref/pbrt_ref (reference built with its own flags -O2 -msse2 -mfpmath=sse, 1 thread, MT19937) on "

@@ -390,51 +390,3 @@ def render_text(scene_text: str, device: int = -1):
     ms = ds.last_ms()[0]
     ds.close()
     return rgb, alpha, cnt, ms
-
-
-# --------------------------------------------------------------------------- reference film dumps
-def load_ref_film(path: str):
-    """Read a float film dumped by oracle/ref/ref_driver.cpp (WriteRGBAImage tap)."""
-    b = open(path, "rb").read()
-    if b[:8] != b"PBRTFILM":
-        raise ValueError("not a PBRTFILM dump: " + path)
-    h = np.frombuffer(b[8:32], np.int32)
-    n = int(h[0]) * int(h[1])
-    rgb = np.frombuffer(b[32:32 + 12 * n], np.float32).reshape(h[1], h[0], 3).copy()
-    alpha = np.frombuffer(b[32 + 12 * n:32 + 16 * n], np.float32).reshape(h[1], h[0]).copy()
-    return rgb, alpha, h
-
-
-REF_DIR = os.path.join(_HERE, "..", "oracle", "_ref")
-
-
-def run_reference(scene_text: str, keyed: bool = True, workdir: str | None = None, timeout: float = 3600):
-    """Run the compiled reference (oracle/_ref) on a scene; returns (rgb, alpha, stats dict).
-    TEST/BENCH infrastructure only -- never on the product path."""
-    import json
-    import tempfile
-    exe = os.path.join(REF_DIR, "pbrt_ref_keyed" if keyed else "pbrt_ref")
-    if not os.path.exists(exe):
-        raise FileNotFoundError(exe)
-    d = workdir or tempfile.mkdtemp(prefix="pbrtref_")
-    sp = os.path.join(d, "scene.pbrt")
-    fp = os.path.join(d, "film.bin")
-    with open(sp, "w") as f:
-        f.write(scene_text)
-    env = dict(os.environ, PBRT_SEARCHPATH=os.path.join(REF_DIR, "bin"))
-    r = subprocess.run([exe, "--out", fp, sp], env=env, capture_output=True, text=True, timeout=timeout, cwd=d)
-    if r.returncode != 0:
-        raise RuntimeError("reference run failed: %s\n%s" % (r.stdout[-2000:], r.stderr[-2000:]))
-    lines = r.stdout.strip().splitlines()
-    stats = json.loads(lines[-1])
-    # the reference's own StatsPrint block (core/util.cpp:228-262), e.g. "Interior kd-tree nodes made   1625"
-    table = {}
-    if "Statistics:" in lines:
-        for ln in lines[lines.index("Statistics:") + 1:-1]:
-            if ln.startswith("    ") and len(ln.split()) >= 2:
-                key = " ".join(ln.split()[:-1]) if not ln.rstrip().endswith(")") else " ".join(ln.split()[:-2])
-                val = ln.split()[-1] if not ln.rstrip().endswith(")") else ln.split()[-2]
-                table[key] = val
-    stats["stats"] = table
-    rgb, alpha, _ = load_ref_film(fp)
-    return rgb, alpha, stats

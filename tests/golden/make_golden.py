@@ -15,6 +15,9 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as g
 pkg = g.load_package()
 from pbrt_v1_amd import scenes
+import importlib.util
+_spec = importlib.util.spec_from_file_location("pbrt_ref_runner", os.path.join(ROOT, "oracle", "ref_runner.py"))
+REF = importlib.util.module_from_spec(_spec); _spec.loader.exec_module(REF)
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 blob = scenes.icosphere((200, 120, 250), 90, 1)
@@ -128,7 +131,7 @@ def main():
         for k in list(CONFIGS):
             if k not in only: del CONFIGS[k]
     for name, text in EDGE_SCENES.items():
-        rgb, alpha, st = pkg.run_reference(text, keyed=True)
+        rgb, alpha, st = REF.run_reference(text, keyed=True)
         np.savez_compressed(os.path.join(OUT, name + ".npz"), scene=np.array(text), rgb=rgb, alpha=alpha, stats=np.array(json.dumps(st)))
         print(name, rgb.shape, "mean", float(rgb.mean()), {k: st[k] for k in ("closest_rays", "any_rays")})
     for name, kw in CONFIGS.items():
@@ -151,7 +154,7 @@ def main():
             assert "environment" in text
         if name == "whitted_orennayar_triangle":
             text = text.replace('Material "matte" "color Kd" [0.73 0.73 0.73]', 'Material "matte" "color Kd" [0.73 0.73 0.73] "float sigma" [35]')
-        rgb, alpha, st = pkg.run_reference(text, keyed=True)
+        rgb, alpha, st = REF.run_reference(text, keyed=True)
         np.savez_compressed(os.path.join(OUT, name + ".npz"), scene=np.array(text), rgb=rgb, alpha=alpha, stats=np.array(json.dumps(st)))
         print(name, rgb.shape, "mean", float(rgb.mean()), {k: st[k] for k in ("closest_rays", "any_rays")}, st.get("stats", {}))
     # probe fixtures: camera rays + hits
@@ -161,7 +164,7 @@ def main():
         dump = os.path.join(d, "rays.bin")
         text = scenes.cornell_scene(keyed=True, count=True, integrator="probe",
                                     integrator_params='"string dump" ["%s"] "point target" [278 540 280]' % dump, **kw)
-        rgb, alpha, st = pkg.run_reference(text, keyed=True, workdir=d)
+        rgb, alpha, st = REF.run_reference(text, keyed=True, workdir=d)
         rec = np.fromfile(dump, np.float32).reshape(-1, 20)
         # the scene stored in the fixture names no dump file (the product ignores the probe integrator's params)
         text = text.replace(dump, "probe_rays.bin")

@@ -5,13 +5,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import __graft_entry__ as g
 pkg = g.load_package()
+REF = g.load_ref_runner()
 from pbrt_v1_amd import scenes
 
 def compare(name, text, keyed=True):
     t0 = time.time()
     rgb, alpha, cnt, ms = pkg.render_text(text)
     t1 = time.time()
-    ref_rgb, ref_alpha, st = pkg.run_reference(text, keyed=keyed)
+    ref_rgb, ref_alpha, st = REF.run_reference(text, keyed=keyed)
     t2 = time.time()
     d = rgb - ref_rgb
     l2 = np.sqrt((d ** 2).sum(-1))
