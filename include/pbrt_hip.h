@@ -61,6 +61,8 @@ typedef struct RtLight {
     float dir[3];                /* distant: lightDir = Normalize(LightToWorld(from - to)) (distant.cpp:51-56) */
     float world_to_light[9];     /* spot: upper-left 3x3 of WorldToLight, row-major (Falloff, spot.cpp:68-79)   */
     float cos_total_width, cos_falloff_start;   /* spot.cpp:58-59 */
+    int32_t quadric_plus1;       /* area light whose shape is a quadric (AreaLight keeps a CanIntersect shape as is,
+                                  * area.cpp:38-39): 1 + index into RtSceneDesc::quadrics, n_tris = 0; 0 = triangle set */
 } RtLight;
 
 /* ---- camera: core/camera.cpp:50-70, cameras/perspective.cpp:51-82, orthographic.cpp:48-79, environment.cpp:47-61 ---- */

@@ -39,6 +39,7 @@ struct DevLight {
     int reverse_orientation, flip_normal;
     float area;        // ShapeSet::area / Triangle::Area() (shape.h:123-131, trianglemesh.cpp:329-335)
     float dir[3];      // distant
+    int quadric;       // area light on a quadric: index into DevScene::quadrics, else -1 (read by the EXT kernels)
     float w2l[9];      // spot: WorldToLight 3x3
     float cos_total, cos_falloff;
 };

@@ -350,7 +350,7 @@ RT_DEV void estimate_direct_bsdf(const DevScene &sc, Lane &ln) {
     V3 wi; float bsdfPdf; int sampled;
     V3 f = bsdf_sample_f<EXT>(m, ln.v, ln.v.wo, wi, ln.bs1, ln.bs2, ln.bcs, bsdfPdf, BX_ALL & ~BX_SPECULAR, sampled);
     if (!is_black(f) && bsdfPdf > 0.f) {
-        float lightPdf = area_light_pdf(sc, Lt, ln.v.p, wi);
+        float lightPdf = area_light_pdf<EXT>(sc, Lt, ln.v.p, wi);
         if (lightPdf > 0.f) {
             float fw = 1 * bsdfPdf, gw = 1 * lightPdf;                            // PowerHeuristic mc.h:55-59
             float weight = (fw * fw) / (fw * fw + gw * gw);
@@ -374,9 +374,9 @@ RT_DEV void estimate_direct_begin(const DevScene &sc, Lane &ln, int light, float
         lightPdf = 1.f;
     } else {                                                                    // area.cpp:58-68
         V3 ns;
-        V3 ps = area_sample_point(sc, Lt, ls1, ls2, ln.rng, ns);
+        V3 ps = area_sample_point<EXT>(sc, Lt, ln.v.p, ls1, ls2, ln.rng, ns);
         wi = normalize3(ps - ln.v.p);
-        lightPdf = area_light_pdf(sc, Lt, ln.v.p, wi);
+        lightPdf = area_light_pdf<EXT>(sc, Lt, ln.v.p, wi);
         Li = area_L(Lt, ns, -wi);
         sd = ps - ln.v.p; smax = 1.f - RT_RAY_EPSILON;
     }
@@ -483,9 +483,9 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
             else {                                                              // area.cpp:96-105
                 float u2 = ln.rng.next_float();     // g++ evaluates the two RandomFloat() arguments right to left
                 float u1 = ln.rng.next_float();
-                V3 ns; V3 ps = area_sample_point(sc, Lt, u1, u2, ln.rng, ns);
+                V3 ns; V3 ps = area_sample_point<EXT>(sc, Lt, ln.v.p, u1, u2, ln.rng, ns);
                 wi = normalize3(ps - ln.v.p);
-                float pdf = area_light_pdf(sc, Lt, ln.v.p, wi);
+                float pdf = area_light_pdf<EXT>(sc, Lt, ln.v.p, wi);
                 Li = (pdf == 0.f) ? mk3(0.f) : div_s(area_L(Lt, ns, -wi), pdf);
                 sd = ps - ln.v.p; smax = 1.f - RT_RAY_EPSILON;
             }
@@ -518,7 +518,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
         if (COUNT) ++*c_closest;
         if (ln.tv.hit_prim >= 0) {                                              // transport.cpp:180-184
             V3 nh; int light;
-            prim_normal_light(sc, unsigned(ln.tv.hit_prim), nh, light);
+            prim_normal_light<EXT>(sc, ln.tv, nh, light);
             if (light == ln.cur_light) {
                 if (dot3(nh, -ln.tv.d) > 0)                                    // isect.Le(-wi) non-black; transport.cpp:188-190
                     ln.Ld = ln.Ld + ln.pend * scene_transmittance<VOL>(sc, ln, ln.tv.o, ln.tv.d, ln.tv.mint, ln.tv.maxt);
@@ -666,8 +666,8 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
                     V3 wo, L, sd; float pdf, smax;
                     if (light_is_delta(Lt)) { L = delta_light_sample(Lt, p, wo, sd, smax); pdf = 1.f; }
                     else {
-                        V3 ns; V3 ps = area_sample_point(sc, Lt, u1, u2, ln.rng, ns);
-                        wo = normalize3(ps - p); pdf = area_light_pdf(sc, Lt, p, wo); L = area_L(Lt, ns, -wo);
+                        V3 ns; V3 ps = area_sample_point<EXT>(sc, Lt, p, u1, u2, ln.rng, ns);
+                        wo = normalize3(ps - p); pdf = area_light_pdf<EXT>(sc, Lt, p, wo); L = area_L(Lt, ns, -wo);
                         sd = ps - p; smax = 1.f - RT_RAY_EPSILON;
                     }
                     if (!is_black(L) && pdf > 0.f) {

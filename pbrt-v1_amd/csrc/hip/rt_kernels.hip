@@ -557,6 +557,8 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
         for (int c = 0; c < 3; ++c) o.dir[c] = L.dir[c];
         for (int c = 0; c < 9; ++c) o.w2l[c] = L.world_to_light[c];
         o.cos_total = L.cos_total_width; o.cos_falloff = L.cos_falloff_start;
+        o.quadric = L.quadric_plus1 - 1;
+        if (L.quadric_plus1 < 0 || uint32_t(L.quadric_plus1) > d->n_quadrics) return fail(RT_EINVAL, "rt_scene_create: light refers to a quadric out of range");
         if (L.type < RT_LIGHT_POINT || L.type > RT_LIGHT_DISTANT) return fail(RT_EINVAL, "rt_scene_create: unknown light type");
         if (L.type != RT_LIGHT_AREA) continue;
         if (size_t(L.first_tri) + L.n_tris > d->n_light_tris) return fail(RT_EINVAL, "rt_scene_create: light triangle range out of bounds");

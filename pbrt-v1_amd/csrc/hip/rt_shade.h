@@ -39,10 +39,10 @@ RT_DEV void tri_frame(V3 p1, V3 p2, V3 p3, bool flip, V3 &nn, V3 &dpdu) {
 // DifferentialGeometry + BSDF frame of a quadric hit (sphere.cpp:141-209, disk.cpp:85-103, cylinder.cpp:108-142, shape.cpp:37-51,
 // reflection.cpp:471-479): the hit
 // point is re-derived exactly as Sphere::Intersect did (same object-space ray, t = the accepted hit parameter)
-RT_DEV void sphere_frame(const DevScene &sc, unsigned qi, bool flip, const Trav &tv, Vertex &v) {
+RT_DEV void quadric_frame(const DevScene &sc, unsigned qi, bool flip, V3 ow, V3 dw, float thit, V3 &vp, V3 &vnn, V3 &vsn) {
     const DevQuadric RT_G &q = RT_GPTR(const DevQuadric, sc.quadrics)[qi];
-    const V3 o = xform_point(q.w2o, tv.o), d = xform_vector(q.w2o, tv.d);
-    const V3 phit = o + d * tv.maxt;
+    const V3 o = xform_point(q.w2o, ow), d = xform_vector(q.w2o, dw);
+    const V3 phit = o + d * thit;
     const float radius = q.radius, phiMax = q.phi_max, thetaMin = q.theta_min, thetaMax = q.theta_max;
     float cosphi, sinphi; V3 dpdu, dpdv;
     if (q.type == RT_QUADRIC_DISK) {                                            // disk.cpp:85-93 (zmax = innerRadius)
@@ -67,11 +67,11 @@ RT_DEV void sphere_frame(const DevScene &sc, unsigned qi, bool flip, const Trav 
         dpdv = mk3(phit.z * cosphi, phit.z * sinphi, -radius * sinf(theta)) * (thetaMax - thetaMin);
     }
     }
-    v.p = xform_point(q.o2w, phit);
+    vp = xform_point(q.o2w, phit);
     const V3 dpduW = xform_vector(q.o2w, dpdu), dpdvW = xform_vector(q.o2w, dpdv);
-    v.nn = normalize3(cross3(dpduW, dpdvW));
-    if (flip) v.nn = v.nn * -1.f;
-    v.sn = normalize3(dpduW);
+    vnn = normalize3(cross3(dpduW, dpdvW));
+    if (flip) vnn = vnn * -1.f;
+    vsn = normalize3(dpduW);
 }
 template <bool EXT>
 RT_DEV void make_vertex(const DevScene &sc, const Trav &tv, Vertex &v) {
@@ -80,7 +80,7 @@ RT_DEV void make_vertex(const DevScene &sc, const Trav &tv, Vertex &v) {
     const unsigned bits = __float_as_uint(a.w);
     if (EXT && (bits & RT_PRIM_QUADRIC)) {
         const unsigned qi = __float_as_uint(RT_GPTR(const DevTri, sc.tris)[unsigned(tv.hit_prim)].q0.x);
-        sphere_frame(sc, qi, (bits & 0x10000u) != 0, tv, v);
+        quadric_frame(sc, qi, (bits & 0x10000u) != 0, tv.o, tv.d, tv.maxt, v.p, v.nn, v.sn);
     } else {
         v.p = tv.o + tv.d * tv.maxt;                     // ray(t), geometry.h:210
         v.nn = mk3(a.x, a.y, a.z);                       // tri_frame(), precomputed per triangle on the host
@@ -92,11 +92,17 @@ RT_DEV void make_vertex(const DevScene &sc, const Trav &tv, Vertex &v) {
     v.light = __float_as_int(b.w);
 }
 // geometric normal (orientation flip applied) and area-light index of a primitive
-RT_DEV void prim_normal_light(const DevScene &sc, unsigned prim, V3 &nn, int &light) {
+template <bool EXT>
+RT_DEV void prim_normal_light(const DevScene &sc, const Trav &tv, V3 &nn, int &light) {
+    const unsigned prim = unsigned(tv.hit_prim);
     const float4 RT_G *q = RT_GPTR(const float4, sc.tri_shade) + size_t(2) * prim;
     const float4 a = q[0];
     nn = mk3(a.x, a.y, a.z);
     light = __float_as_int(q[1].w);
+    if (EXT && (__float_as_uint(a.w) & RT_PRIM_QUADRIC) && light >= 0) {       // an emitting quadric: its normal at this hit
+        V3 hp, sn;
+        quadric_frame(sc, __float_as_uint(RT_GPTR(const DevTri, sc.tris)[prim].q0.x), (__float_as_uint(a.w) & 0x10000u) != 0, tv.o, tv.d, tv.maxt, hp, nn, sn);
+    }
 }
 
 RT_DEV V3 to_local(const Vertex &v, V3 w) { return mk3(dot3(w, v.sn), dot3(w, v.tn), dot3(w, v.nn)); }
@@ -370,9 +376,80 @@ RT_DEV V3 delta_light_sample(LightRef Lt, V3 p, V3 &wi, V3 &sd, float &smax) {
     return div_s(mat_color(Lt.color) * fall, d2);
 }
 
+// ---- area lights on quadrics: {Sphere,Disk,Cylinder}::Sample / ::Pdf / ::Area (sphere.cpp:36-86,:251-253, disk.cpp:37-46,:124-127,
+// cylinder.cpp:38-45,:180-182) and the Shape defaults (shape.h:89-107).  EXT kernels only.
+RT_DEV V3 xform_normal(const float *minv, V3 n) {                               // Transform::operator()(Normal) transform.h:106-112
+    return mk3(minv[0] * n.x + minv[4] * n.y + minv[8] * n.z, minv[1] * n.x + minv[5] * n.y + minv[9] * n.z, minv[2] * n.x + minv[6] * n.y + minv[10] * n.z);
+}
+RT_DEV float dist_sq(V3 a, V3 b) { const V3 d = a - b; return d.x * d.x + d.y * d.y + d.z * d.z; }
+RT_DEV V3 quadric_sample_uniform(const DevQuadric RT_G &q, bool ro, float u1, float u2, V3 &ns) {   // Shape::Sample(u1, u2, Ns)
+    V3 p, n;
+    if (q.type == RT_QUADRIC_DISK) {
+        float dx, dy; concentric_disk(u1, u2, dx, dy);
+        p = mk3(dx * q.radius, dy * q.radius, q.zmin);
+        n = mk3(0.f, 0.f, 1.f);
+    } else if (q.type == RT_QUADRIC_CYLINDER) {
+        const float z = (1.f - u1) * q.zmin + u1 * q.zmax;                         // Lerp
+        const float t = u2 * q.phi_max;
+        p = mk3(q.radius * cosf(t), q.radius * sinf(t), z);
+        n = mk3(p.x, p.y, 0.f);
+    } else {
+        const float z = 1.f - 2.f * u1;                                             // UniformSampleSphere mc.cpp:74-81
+        const float r = sqrtf(fmaxf(0.f, 1.f - z * z));
+        const float phi = 2.f * RT_PI * u2;
+        p = mk3(0.f) + mk3(r * cosf(phi), r * sinf(phi), z) * q.radius;
+        n = p;
+    }
+    ns = normalize3(xform_normal(q.w2o, n));
+    if (ro) ns = ns * -1.f;
+    return xform_point(q.o2w, p);
+}
+RT_DEV V3 quadric_sample(const DevScene &sc, unsigned qi, bool ro, V3 p, float u1, float u2, V3 &ns) {   // Shape::Sample(p, u1, u2, Ns)
+    const DevQuadric RT_G &q = RT_GPTR(const DevQuadric, sc.quadrics)[qi];
+    if (q.type != RT_QUADRIC_SPHERE) return quadric_sample_uniform(q, ro, u1, u2, ns);
+    const V3 Pcenter = xform_point(q.o2w, mk3(0.f));                                 // sphere.cpp:46-72
+    const V3 wc = normalize3(Pcenter - p);
+    V3 wcX, wcY;
+    if (fabsf(wc.x) > fabsf(wc.y)) { const float il = 1.f / sqrtf(wc.x * wc.x + wc.z * wc.z); wcX = mk3(-wc.z * il, 0.f, wc.x * il); }   // CoordinateSystem
+    else { const float il = 1.f / sqrtf(wc.y * wc.y + wc.z * wc.z); wcX = mk3(0.f, wc.z * il, -wc.y * il); }
+    wcY = cross3(wc, wcX);
+    if (dist_sq(p, Pcenter) - q.radius * q.radius < 1e-4f) return quadric_sample_uniform(q, ro, u1, u2, ns);
+    const float cosThetaMax = sqrtf(fmaxf(0.f, 1.f - q.radius * q.radius / dist_sq(p, Pcenter)));
+    const float costheta = (1.f - u1) * cosThetaMax + u1 * 1.f;                     // UniformSampleCone mc.cpp:154-161
+    const float sintheta = sqrtf(1.f - costheta * costheta);
+    const float phi = u2 * 2.f * RT_PI;
+    const V3 rd = wcX * (cosf(phi) * sintheta) + wcY * (sinf(phi) * sintheta) + wc * costheta;
+    float thit;
+    if (!quadric_test(sc, qi, p, rd, RT_RAY_EPSILON, RT_INF, thit)) thit = dot3(Pcenter - p, normalize3(rd));
+    const V3 ps = p + rd * thit;
+    ns = normalize3(ps - Pcenter);
+    if (ro) ns = ns * -1.f;
+    return ps;
+}
+RT_DEV float quadric_light_pdf(const DevScene &sc, unsigned qi, V3 p, V3 wi) {   // Shape::Pdf(p, wi) shape.h:96-107; Sphere::Pdf sphere.cpp:73-86
+    const DevQuadric RT_G &q = RT_GPTR(const DevQuadric, sc.quadrics)[qi];
+    if (q.type == RT_QUADRIC_SPHERE) {
+        const V3 Pcenter = xform_point(q.o2w, mk3(0.f));
+        if (!(dist_sq(p, Pcenter) - q.radius * q.radius < 1e-4f)) {
+            const float cosThetaMax = sqrtf(fmaxf(0.f, 1.f - q.radius * q.radius / dist_sq(p, Pcenter)));
+            return 1.f / (2.f * RT_PI * (1.f - cosThetaMax));                      // UniformConePdf mc.cpp:142-144
+        }
+    }
+    float thit;
+    if (!quadric_test(sc, qi, p, wi, RT_RAY_EPSILON, RT_INF, thit)) return 0.f;
+    V3 hp, nn, sn; quadric_frame(sc, qi, false, p, wi, thit, hp, nn, sn);
+    const float area = q.type == RT_QUADRIC_DISK ? q.phi_max * 0.5f * (q.radius * q.radius - q.zmax * q.zmax)
+                     : (q.type == RT_QUADRIC_CYLINDER ? (q.zmax - q.zmin) * q.phi_max * q.radius : q.phi_max * q.radius * (q.zmax - q.zmin));
+    float pdf = dist_sq(p, p + wi * thit) / (absdot3(nn, -wi) * area);
+    if (absdot3(nn, -wi) == 0.f) pdf = 0.f;
+    return pdf;
+}
+
 // Shape::Pdf(p, wi) shape.h:96-107 evaluated on the emitter's own triangles:
 // ShapeSet::Intersect (shape.h:150-156) keeps the LAST triangle hit, the ray's maxt is never shortened.
+template <bool EXT>
 RT_DEV float area_light_pdf(const DevScene &sc, LightRef L, V3 p, V3 wi) {
+    if (EXT && L.quadric >= 0) return quadric_light_pdf(sc, unsigned(L.quadric), p, wi);
     bool any = false; float thit = 0.f; V3 nl = mk3(0.f);
     for (unsigned k = 0; k < L.n_tris; ++k) {
         V3 p1, p2, p3; light_tri(sc, L.first_tri + k, p1, p2, p3);
@@ -397,8 +474,9 @@ RT_DEV V3 area_L(LightRef L, V3 n, V3 w) { return dot3(n, w) > 0 ? mat_color(L.c
 
 // shape->Sample(p,u1,u2,&ns): ShapeSet::Sample shape.h:115-121 (one extra RandomFloat when the emitter has
 // more than one triangle) + Triangle::Sample trianglemesh.cpp:336-349 + UniformSampleTriangle mc.cpp:136-141
-template <class RNG>
-RT_DEV V3 area_sample_point(const DevScene &sc, LightRef L, float u1, float u2, RNG &rng, V3 &ns) {
+template <bool EXT, class RNG>
+RT_DEV V3 area_sample_point(const DevScene &sc, LightRef L, V3 pref, float u1, float u2, RNG &rng, V3 &ns) {
+    if (EXT && L.quadric >= 0) return quadric_sample(sc, unsigned(L.quadric), L.reverse_orientation != 0, pref, u1, u2, ns);
     unsigned k = 0;
     if (L.n_tris > 1) {
         float ls = rng.next_float();

@@ -521,7 +521,19 @@ void PbrtApi::quadricShape(const std::string &name, const ParamSet &ps) {
     mesh.flags = uint8_t(((gs.reverseOrientation ^ ctm.swaps_handedness()) ? 1 : 0) | 2);
     mesh.verts = {bmin[0], bmin[1], bmin[2], bmax[0], bmax[1], bmax[2], bmin[0], bmin[1], bmin[2]};
     mesh.light = -1;
-    if (!gs.areaLight.empty()) Error("Area lights on quadrics are not on the accelerated path; the shape is rendered as a non-emitting surface");
+    if (!gs.areaLight.empty()) {                                                    // api.cpp:362-366: AreaLight keeps a CanIntersect shape as is (area.cpp:38-39)
+        if (gs.areaLight != "area") Error("Unable to load plugin \"%s\" (area light)", gs.areaLight.c_str());
+        else {
+            Float3 Le = gs.areaLightParams.FindOneSpectrum("L", Float3{1.f, 1.f, 1.f});
+            int ns = gs.areaLightParams.FindOneInt("nsamples", 1);
+            RtLight L; std::memset(&L, 0, sizeof L);
+            L.type = RT_LIGHT_AREA; L.color[0] = Le.x; L.color[1] = Le.y; L.color[2] = Le.z; L.n_samples = std::max(1, ns);
+            L.first_tri = 0; L.n_tris = 0; L.quadric_plus1 = int32_t(quadrics.size()) + 1;
+            L.reverse_orientation = gs.reverseOrientation ? 1 : 0; L.flip_normal = mesh.flags & 1;
+            mesh.light = int(lights.size());
+            lights.push_back(L);
+        }
+    }
     mesh.material = makeMaterial(ps);
     quadrics.push_back(q);
     meshes.push_back(std::move(mesh));

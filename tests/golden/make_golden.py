@@ -39,6 +39,10 @@ QUADRICS = ('AttributeBegin\nMaterial "matte" "color Kd" [.7 .6 .2]\nTranslate 1
             'AttributeBegin\nMaterial "glass" "float index" [1.4]\nTranslate 380 90 180\nRotate 20 0 0 1\nScale 1 .8 1\nShape "cylinder" "float radius" [60] "float zmin" [-50] "float zmax" [70] "float phimax" [270]\nAttributeEnd\n'
             'AttributeBegin\nMaterial "plastic" "color Kd" [.2 .3 .7]\nReverseOrientation\nTranslate 100 400 250\nRotate 45 1 1 0\nShape "cylinder" "float radius" [40] "float zmin" [-60] "float zmax" [60]\nAttributeEnd\n')
 
+QLIGHTS = ('AttributeBegin\nAreaLightSource "area" "color L" [12 10 6]\nMaterial "matte" "color Kd" [0 0 0]\nTranslate 150 300 300\nShape "sphere" "float radius" [40]\nAttributeEnd\n'
+           'AttributeBegin\nAreaLightSource "area" "color L" [6 9 14]\nMaterial "matte" "color Kd" [.2 .2 .2]\nTranslate 420 400 250\nRotate 70 1 0 0.3\nShape "disk" "float radius" [60]\nAttributeEnd\n'
+           'AttributeBegin\nAreaLightSource "area" "color L" [9 4 4]\nMaterial "matte" "color Kd" [.1 .1 .1]\nReverseOrientation\nTranslate 300 60 150\nRotate 90 0 1 0\nScale 1 1.2 1\nShape "cylinder" "float radius" [25] "float zmin" [-80] "float zmax" [80]\nAttributeEnd\n')
+
 CONFIGS = {
     # name: cornell_scene kwargs  (all keyed RNG + counted rays)
     "whitted_point": dict(xres=48, yres=48, integrator="whitted", world_kwargs=dict(point_light=True, area_light=False)),
@@ -92,6 +96,10 @@ CONFIGS = {
     "quadrics_whitted": dict(xres=48, yres=48, integrator="whitted", world_kwargs=dict(point_light=True, extra=QUADRICS)),
     "quadrics_direct_grid": dict(xres=40, yres=40, integrator="directlighting", xsamples=2, ysamples=1, jitter=True, accelerator="grid", world_kwargs=dict(extra=QUADRICS)),
     "quadrics_path": dict(xres=32, yres=32, integrator="path", xsamples=2, ysamples=2, world_kwargs=dict(extra=QUADRICS)),
+    # quadric emitters (sphere / disk / cylinder area lights), with and without the Cornell ceiling light
+    "qlight_whitted": dict(xres=40, yres=40, integrator="whitted", world_kwargs=dict(area_light=False, extra=QLIGHTS)),
+    "qlight_direct_ns2": dict(xres=32, yres=32, integrator="directlighting", xsamples=2, ysamples=1, jitter=True, world_kwargs=dict(extra=QLIGHTS.replace('"color L"', '"integer nsamples" [2] "color L"'))),
+    "qlight_path": dict(xres=32, yres=32, integrator="path", xsamples=2, ysamples=2, world_kwargs=dict(area_light=False, extra=QLIGHTS, mirror_quad=True)),
     # plastic (Lambertian + Blinn microfacet lobes): text substitution of two Material lines below
     "plastic_whitted": dict(xres=40, yres=40, integrator="whitted", world_kwargs=dict(point_light=True)),
     "plastic_direct_ns2": dict(xres=32, yres=32, integrator="directlighting", xsamples=2, ysamples=1, jitter=True, world_kwargs=dict(light_nsamples=2)),
