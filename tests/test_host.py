@@ -97,11 +97,11 @@ def test_f4_plugins_are_accepted(pkg):
         ps = pkg.ParsedScene(text=BASE % (cam, world))
         assert ps.valid and ps.errors == 0
         assert ps.n_tris == 4 and ps.n_lights == 2            # every quadric is one primitive slot
+        v = ps.tri_verts()[0]                                 # its slot = world bound {pMin, pMax, pMin}
+        assert np.allclose(v[0], [-1, 0, 1]) and np.allclose(v[1], [3, 4, 4]) and np.array_equal(v[0], v[2])
     # a quadric under AreaLightSource becomes an area light whose shape is the quadric itself (area.cpp:38-39)
     ps = pkg.ParsedScene(text=BASE % ("", 'AreaLightSource "area" "color L" [3 3 3]\nShape "sphere" "float radius" [1]\n' + TRI))
     assert ps.valid and ps.errors == 0 and ps.n_lights == 2 and ps.n_light_tris == 1
-        v = ps.tri_verts()[0]                                 # its slot = world bound {pMin, pMax, pMin}
-        assert np.allclose(v[0], [-1, 0, 1]) and np.allclose(v[1], [3, 4, 4]) and np.array_equal(v[0], v[2])
 
 
 def test_include_and_comments(pkg, tmp_path):
