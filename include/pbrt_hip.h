@@ -94,16 +94,20 @@ typedef struct RtAccelParams {
     int32_t build_threads;                                /* 0 = auto                  */
 } RtAccelParams;
 
-/* ---- quadrics: shapes/sphere.cpp:89-215, disk.cpp:51-130, cylinder.cpp:52-180.  A quadric is ONE primitive of the accelerator
+/* ---- quadrics: shapes/sphere.cpp:89-215, disk.cpp:51-130, cylinder.cpp:52-180, cone.cpp:41-186, paraboloid.cpp:44-190,
+ * hyperboloid.cpp:46-240.  A quadric is ONE primitive of the accelerator
  * (Shape::CanIntersect, primitive.cpp:40-53).  In the primitive arrays below it occupies one slot whose tri_verts
  * hold its world bound as a degenerate triangle {pMin, pMax, pMin} (Shape::WorldBound shape.h:57-59) and whose
  * tri_flags has bit1 set; the k-th such slot is quadrics[k]. ---- */
-enum { RT_QUADRIC_SPHERE = 0, RT_QUADRIC_DISK = 1, RT_QUADRIC_CYLINDER = 2 };
+enum { RT_QUADRIC_SPHERE = 0, RT_QUADRIC_DISK = 1, RT_QUADRIC_CYLINDER = 2, RT_QUADRIC_CONE = 3, RT_QUADRIC_PARABOLOID = 4, RT_QUADRIC_HYPERBOLOID = 5 };
 typedef struct RtQuadric {
     int32_t type;
     float object_to_world[16], world_to_object[16]; /* Transform::m / ::mInv, row-major                      */
     float radius, zmin, zmax, theta_min, theta_max, phi_max; /* as the ctors store them (sphere.cpp:89-99, cylinder.cpp:52-59);
-                                                              * disk (disk.cpp:51-59): zmin = height, zmax = innerRadius          */
+                                                              * disk (disk.cpp:51-59): zmin = height, zmax = innerRadius;
+                                                              * cone (cone.cpp:41-48): zmin = 0, zmax = height; paraboloid (paraboloid.cpp:44-52);
+                                                              * hyperboloid (hyperboloid.cpp:46-70): radius = rmax + the fields below */
+    float p1[3], p2[3], a, c;                                /* hyperboloid: end points (after the ctor's swap) and the implicit form's a, c */
 } RtQuadric;
 
 /* Scene description = what MakeScene hands to Scene::Scene (core/scene.cpp:100-119),

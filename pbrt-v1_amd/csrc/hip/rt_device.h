@@ -15,6 +15,7 @@ struct DevQuadric {          // Sphere (shapes/sphere.cpp:89-99): transforms as 
     float w2o[16], o2w[16];
     float radius, zmin, zmax, theta_min, theta_max, phi_max;
     int type, pad;
+    float p1[3], p2[3], a, c;   // hyperboloid (hyperboloid.cpp:46-70)
 };
 
 struct DevMaterial {

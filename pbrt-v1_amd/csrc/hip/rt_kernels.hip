@@ -510,10 +510,12 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
         std::vector<DevQuadric> dq(d->n_quadrics);
         for (uint32_t i = 0; i < d->n_quadrics; ++i) {
             const RtQuadric &q = d->quadrics[i]; DevQuadric &o = dq[i];
-            if (q.type < RT_QUADRIC_SPHERE || q.type > RT_QUADRIC_CYLINDER) return fail(RT_EINVAL, "rt_scene_create: unknown quadric type");
+            if (q.type < RT_QUADRIC_SPHERE || q.type > RT_QUADRIC_HYPERBOLOID) return fail(RT_EINVAL, "rt_scene_create: unknown quadric type");
             std::memcpy(o.w2o, q.world_to_object, sizeof o.w2o); std::memcpy(o.o2w, q.object_to_world, sizeof o.o2w);
             o.radius = q.radius; o.zmin = q.zmin; o.zmax = q.zmax; o.theta_min = q.theta_min; o.theta_max = q.theta_max; o.phi_max = q.phi_max;
             o.type = q.type; o.pad = 0;
+            for (int c = 0; c < 3; ++c) { o.p1[c] = q.p1[c]; o.p2[c] = q.p2[c]; }
+            o.a = q.a; o.c = q.c;
         }
         if ((rc = upload(s, dq.data(), dq.size(), &s->dev.quadrics))) return rc;
     }

@@ -53,6 +53,18 @@ RT_DEV void quadric_frame(const DevScene &sc, unsigned qi, bool flip, V3 ow, V3 
     } else if (q.type == RT_QUADRIC_CYLINDER) {                                 // cylinder.cpp:112-115
         dpdu = mk3(-phiMax * phit.y, phiMax * phit.x, 0.f);
         dpdv = mk3(0.f, 0.f, q.zmax - q.zmin);
+    } else if (q.type == RT_QUADRIC_CONE) {                                     // cone.cpp:95-100 (zmax = height)
+        const float vv = phit.z / q.zmax;
+        dpdu = mk3(-phiMax * phit.y, phiMax * phit.x, 0.f);
+        dpdv = mk3(-phit.x / (1.f - vv), -phit.y / (1.f - vv), q.zmax);
+    } else if (q.type == RT_QUADRIC_PARABOLOID) {                               // paraboloid.cpp:97-102
+        dpdu = mk3(-phiMax * phit.y, phiMax * phit.x, 0.f);
+        dpdv = mk3(phit.x / (2.f * phit.z), phit.y / (2.f * phit.z), 1.f) * (q.zmax - q.zmin);
+    } else if (q.type == RT_QUADRIC_HYPERBOLOID) {                              // hyperboloid.cpp:122-130
+        const float phi = quadric_phi(q, phit);
+        cosphi = cosf(phi); sinphi = sinf(phi);
+        dpdu = mk3(-phiMax * phit.y, phiMax * phit.x, 0.f);
+        dpdv = mk3((q.p2[0] - q.p1[0]) * cosphi - (q.p2[1] - q.p1[1]) * sinphi, (q.p2[0] - q.p1[0]) * sinphi + (q.p2[1] - q.p1[1]) * cosphi, q.p2[2] - q.p1[2]);
     } else {
     const float theta = acosf(clampf(phit.z / radius, -1.f, 1.f));
     const float zradius = sqrtf(phit.x * phit.x + phit.y * phit.y);

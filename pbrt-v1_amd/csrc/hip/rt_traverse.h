@@ -105,6 +105,18 @@ RT_DEV bool quadratic(float A, float B, float C, float &t0, float &t1) {   // pb
     if (t0 > t1) { const float tmp = t0; t0 = t1; t1 = tmp; }
     return true;
 }
+// phi of an object-space hit point: atan2f(y, x) folded to [0, 2 pi); the hyperboloid measures it against the generating
+// segment's point at the hit's height (hyperboloid.cpp:105-111)
+RT_DEV float quadric_phi(const DevQuadric RT_G &q, V3 phit) {
+    float phi;
+    if (q.type == RT_QUADRIC_HYPERBOLOID) {
+        const float v = (phit.z - q.p1[2]) / (q.p2[2] - q.p1[2]);
+        const V3 pr = mk3(q.p1[0], q.p1[1], q.p1[2]) * (1.f - v) + mk3(q.p2[0], q.p2[1], q.p2[2]) * v;
+        phi = atan2f(pr.x * phit.y - phit.x * pr.y, phit.x * pr.x + phit.y * pr.y);
+    } else phi = atan2f(phit.y, phit.x);
+    if (phi < 0.f) phi += 2.f * RT_PI;
+    return phi;
+}
 RT_DEV bool quadric_test(const DevScene &sc, unsigned qi, V3 ow, V3 dw, float mint, float maxt, float &t_out) {
     const DevQuadric RT_G &q = RT_GPTR(const DevQuadric, sc.quadrics)[qi];
     const V3 o = xform_point(q.w2o, ow), d = xform_vector(q.w2o, dw);           // WorldToObject(r, &ray) transform.h:128-135
@@ -122,27 +134,50 @@ RT_DEV bool quadric_test(const DevScene &sc, unsigned qi, V3 ow, V3 dw, float mi
         t_out = thit;
         return true;
     }
-    const bool cyl = q.type == RT_QUADRIC_CYLINDER;                             // Cylinder::Intersect(P) cylinder.cpp:65-107
-    const float A = cyl ? d.x * d.x + d.y * d.y : d.x * d.x + d.y * d.y + d.z * d.z;
-    const float B = cyl ? 2 * (d.x * o.x + d.y * o.y) : 2 * (d.x * o.x + d.y * o.y + d.z * o.z);
-    const float C = cyl ? o.x * o.x + o.y * o.y - radius * radius : o.x * o.x + o.y * o.y + o.z * o.z - radius * radius;
+    // the quadratic forms: sphere.cpp:111-116, cylinder.cpp:72-75, cone.cpp:61-68 (zmax = height), paraboloid.cpp:65-70,
+    // hyperboloid.cpp:83-91; then one control flow (the sphere's clip test differs, sphere.cpp:128-130)
+    float A, B, C;
+    if (q.type == RT_QUADRIC_CONE) {
+        float k = radius / zmax;
+        k = k * k;
+        A = d.x * d.x + d.y * d.y - k * d.z * d.z;
+        B = 2 * (d.x * o.x + d.y * o.y - k * d.z * (o.z - zmax));
+        C = o.x * o.x + o.y * o.y - k * (o.z - zmax) * (o.z - zmax);
+    } else if (q.type == RT_QUADRIC_PARABOLOID) {
+        const float k = zmax / (radius * radius);
+        A = k * (d.x * d.x + d.y * d.y);
+        B = 2 * k * (d.x * o.x + d.y * o.y) - d.z;
+        C = k * (o.x * o.x + o.y * o.y) - o.z;
+    } else if (q.type == RT_QUADRIC_HYPERBOLOID) {
+        const float a = q.a, c = q.c;
+        A = a * d.x * d.x + a * d.y * d.y - c * d.z * d.z;
+        B = 2.f * (a * d.x * o.x + a * d.y * o.y - c * d.z * o.z);
+        C = a * o.x * o.x + a * o.y * o.y - c * o.z * o.z - 1;
+    } else if (q.type == RT_QUADRIC_CYLINDER) {
+        A = d.x * d.x + d.y * d.y;
+        B = 2 * (d.x * o.x + d.y * o.y);
+        C = o.x * o.x + o.y * o.y - radius * radius;
+    } else {
+        A = d.x * d.x + d.y * d.y + d.z * d.z;
+        B = 2 * (d.x * o.x + d.y * o.y + d.z * o.z);
+        C = o.x * o.x + o.y * o.y + o.z * o.z - radius * radius;
+    }
     float t0, t1;
     if (!quadratic(A, B, C, t0, t1)) return false;
     if (t0 > maxt || t1 < mint) return false;
     float thit = t0;
     if (t0 < mint) { thit = t1; if (thit > maxt) return false; }
+    const bool sph = q.type == RT_QUADRIC_SPHERE;
     V3 phit = o + d * thit;
-    float phi = atan2f(phit.y, phit.x);
-    if (phi < 0.f) phi += 2.f * RT_PI;
-    const bool clipped = cyl ? (phit.z < zmin || phit.z > zmax || phi > phiMax)
-                             : ((zmin > -radius && phit.z < zmin) || (zmax < radius && phit.z > zmax) || phi > phiMax);
+    float phi = quadric_phi(q, phit);
+    const bool clipped = sph ? ((zmin > -radius && phit.z < zmin) || (zmax < radius && phit.z > zmax) || phi > phiMax)
+                             : (phit.z < zmin || phit.z > zmax || phi > phiMax);
     if (clipped) {
         if (thit == t1) return false;
-        if (t1 > maxt) return false;                  // (the cylinder assigns thit = t1 before this test: same outcome)
+        if (t1 > maxt) return false;                  // (the others assign thit = t1 before this test: same outcome)
         thit = t1;
         phit = o + d * thit;
-        phi = atan2f(phit.y, phit.x);
-        if (phi < 0.f) phi += 2.f * RT_PI;
+        phi = quadric_phi(q, phit);
         if (phit.z < zmin || phit.z > zmax || phi > phiMax) return false;
     }
     t_out = thit;

@@ -426,9 +426,9 @@ int PbrtApi::makeMaterial(const ParamSet &shapeParams) {
 void PbrtApi::Shape(const std::string &n, const ParamList &p) {                     // api.cpp:354-396
     if (!verifyWorld("Shape")) return;
     ParamSet ps(p);
-    if (n == "sphere" || n == "disk" || n == "cylinder") { quadricShape(n, ps); return; }
+    if (n == "sphere" || n == "disk" || n == "cylinder" || n == "cone" || n == "paraboloid" || n == "hyperboloid") { quadricShape(n, ps); return; }
     if (n != "trianglemesh") {
-        Error("Unable to load plugin \"%s\" (shape): \"trianglemesh\", \"sphere\", \"disk\" and \"cylinder\" are on the accelerated path (SURVEY.md rows 12-13)", n.c_str());
+        Error("Unable to load plugin \"%s\" (shape): \"trianglemesh\" and the quadrics are on the accelerated path (SURVEY.md rows 12-13)", n.c_str());
         return;
     }
     // CreateShape shapes/trianglemesh.cpp:350-406
@@ -501,6 +501,38 @@ void PbrtApi::quadricShape(const std::string &name, const ParamSet &ps) {
         q.radius = radius; q.zmin = height; q.zmax = inner;
         q.phi_max = pbrthip::radians(clampf(pm, 0.0f, 360.0f));
         lo[0] = -radius; lo[1] = -radius; lo[2] = height; hi[0] = radius; hi[1] = radius; hi[2] = height;
+    } else if (name == "cone") {                                                    // cone.cpp:187-194, :41-48
+        const float radius = ps.FindOneFloat("radius", 1.f), height = ps.FindOneFloat("height", 1.f), pm = ps.FindOneFloat("phimax", 360.f);
+        q.type = RT_QUADRIC_CONE;
+        q.radius = radius; q.zmin = 0.f; q.zmax = height;
+        q.phi_max = pbrthip::radians(clampf(pm, 0.0f, 360.0f));
+        lo[0] = -radius; lo[1] = -radius; lo[2] = 0.f; hi[0] = radius; hi[1] = radius; hi[2] = height;
+    } else if (name == "paraboloid") {                                              // paraboloid.cpp:191-199, :44-52
+        const float radius = ps.FindOneFloat("radius", 1.f);
+        const float z0 = ps.FindOneFloat("zmin", 0.f), z1 = ps.FindOneFloat("zmax", 1.f), pm = ps.FindOneFloat("phimax", 360.f);
+        q.type = RT_QUADRIC_PARABOLOID;
+        q.radius = radius; q.zmin = std::fmin(z0, z1); q.zmax = std::fmax(z0, z1);
+        q.phi_max = pbrthip::radians(clampf(pm, 0.0f, 360.0f));
+        lo[0] = -radius; lo[1] = -radius; lo[2] = q.zmin; hi[0] = radius; hi[1] = radius; hi[2] = q.zmax;
+    } else if (name == "hyperboloid") {                                             // hyperboloid.cpp:240-246, :46-70
+        Float3 p1 = ps.FindOnePoint("p1", Float3{0, 0, 0}), p2 = ps.FindOnePoint("p2", Float3{1, 1, 1});
+        const float pm = ps.FindOneFloat("phimax", 360.f);
+        q.type = RT_QUADRIC_HYPERBOLOID;
+        q.phi_max = pbrthip::radians(clampf(pm, 0.0f, 360.0f));
+        const float rad1 = std::sqrt(p1.x * p1.x + p1.y * p1.y), rad2 = std::sqrt(p2.x * p2.x + p2.y * p2.y);
+        q.radius = std::fmax(rad1, rad2);
+        q.zmin = std::fmin(p1.z, p2.z); q.zmax = std::fmax(p1.z, p2.z);
+        if (p2.z == 0.) std::swap(p1, p2);
+        Float3 pp = p1; float xy1, xy2, a, c;
+        do {
+            pp.x += 2.f * (p2.x - p1.x); pp.y += 2.f * (p2.y - p1.y); pp.z += 2.f * (p2.z - p1.z);
+            xy1 = pp.x * pp.x + pp.y * pp.y;
+            xy2 = p2.x * p2.x + p2.y * p2.y;
+            a = (1.f / xy1 - (pp.z * pp.z) / (xy1 * p2.z * p2.z)) / (1 - (xy2 * pp.z * pp.z) / (xy1 * p2.z * p2.z));
+            c = (a * xy2 - 1) / (p2.z * p2.z);
+        } while (std::isinf(a) || std::isnan(a));
+        q.p1[0] = p1.x; q.p1[1] = p1.y; q.p1[2] = p1.z; q.p2[0] = p2.x; q.p2[1] = p2.y; q.p2[2] = p2.z; q.a = a; q.c = c;
+        lo[0] = -q.radius; lo[1] = -q.radius; lo[2] = q.zmin; hi[0] = q.radius; hi[1] = q.radius; hi[2] = q.zmax;
     } else {
         const float radius = ps.FindOneFloat("radius", 1.f);
         const float z0 = ps.FindOneFloat("zmin", -1.f), z1 = ps.FindOneFloat("zmax", 1.f), pm = ps.FindOneFloat("phimax", 360.f);
@@ -521,7 +553,9 @@ void PbrtApi::quadricShape(const std::string &name, const ParamSet &ps) {
     mesh.flags = uint8_t(((gs.reverseOrientation ^ ctm.swaps_handedness()) ? 1 : 0) | 2);
     mesh.verts = {bmin[0], bmin[1], bmin[2], bmax[0], bmax[1], bmax[2], bmin[0], bmin[1], bmin[2]};
     mesh.light = -1;
-    if (!gs.areaLight.empty()) {                                                    // api.cpp:362-366: AreaLight keeps a CanIntersect shape as is (area.cpp:38-39)
+    if (!gs.areaLight.empty() && q.type > RT_QUADRIC_CYLINDER)
+        Error("Area lights on cone / paraboloid / hyperboloid: the reference's Shape::Sample is unimplemented for them (shape.h:84-88); rendered as a non-emitting surface");
+    else if (!gs.areaLight.empty()) {                                               // api.cpp:362-366: AreaLight keeps a CanIntersect shape as is (area.cpp:38-39)
         if (gs.areaLight != "area") Error("Unable to load plugin \"%s\" (area light)", gs.areaLight.c_str());
         else {
             Float3 Le = gs.areaLightParams.FindOneSpectrum("L", Float3{1.f, 1.f, 1.f});

@@ -43,6 +43,11 @@ QLIGHTS = ('AttributeBegin\nAreaLightSource "area" "color L" [12 10 6]\nMaterial
            'AttributeBegin\nAreaLightSource "area" "color L" [6 9 14]\nMaterial "matte" "color Kd" [.2 .2 .2]\nTranslate 420 400 250\nRotate 70 1 0 0.3\nShape "disk" "float radius" [60]\nAttributeEnd\n'
            'AttributeBegin\nAreaLightSource "area" "color L" [9 4 4]\nMaterial "matte" "color Kd" [.1 .1 .1]\nReverseOrientation\nTranslate 300 60 150\nRotate 90 0 1 0\nScale 1 1.2 1\nShape "cylinder" "float radius" [25] "float zmin" [-80] "float zmax" [80]\nAttributeEnd\n')
 
+QUADRICS2 = ('AttributeBegin\nMaterial "matte" "color Kd" [.7 .6 .2]\nTranslate 140 0 330\nRotate -90 1 0 0\nShape "cone" "float radius" [80] "float height" [200]\nAttributeEnd\n'
+             'AttributeBegin\nMaterial "mirror"\nTranslate 400 60 380\nRotate -70 1 0 0.2\nShape "paraboloid" "float radius" [90] "float zmin" [20] "float zmax" [150] "float phimax" [300]\nAttributeEnd\n'
+             'AttributeBegin\nMaterial "plastic" "color Kd" [.2 .3 .7]\nTranslate 300 330 200\nRotate 40 1 0 1\nScale 60 60 60\nShape "hyperboloid" "point p1" [1 0 -1.2] "point p2" [.8 .9 1.1]\nAttributeEnd\n'
+             'AttributeBegin\nMaterial "glass" "float index" [1.3]\nReverseOrientation\nTranslate 120 300 160\nRotate 100 0 1 0\nShape "hyperboloid" "point p1" [40 0 0] "point p2" [20 30 70] "float phimax" [270]\nAttributeEnd\n')
+
 CONFIGS = {
     # name: cornell_scene kwargs  (all keyed RNG + counted rays)
     "whitted_point": dict(xres=48, yres=48, integrator="whitted", world_kwargs=dict(point_light=True, area_light=False)),
@@ -100,6 +105,10 @@ CONFIGS = {
     "qlight_whitted": dict(xres=40, yres=40, integrator="whitted", world_kwargs=dict(area_light=False, extra=QLIGHTS)),
     "qlight_direct_ns2": dict(xres=32, yres=32, integrator="directlighting", xsamples=2, ysamples=1, jitter=True, world_kwargs=dict(extra=QLIGHTS.replace('"color L"', '"integer nsamples" [2] "color L"'))),
     "qlight_path": dict(xres=32, yres=32, integrator="path", xsamples=2, ysamples=2, world_kwargs=dict(area_light=False, extra=QLIGHTS, mirror_quad=True)),
+    # cones, paraboloids, hyperboloids
+    "quadrics2_whitted": dict(xres=48, yres=48, integrator="whitted", world_kwargs=dict(point_light=True, extra=QUADRICS2)),
+    "quadrics2_direct": dict(xres=40, yres=40, integrator="directlighting", xsamples=2, ysamples=1, jitter=True, world_kwargs=dict(extra=QUADRICS2)),
+    "quadrics2_path_grid": dict(xres=32, yres=32, integrator="path", xsamples=2, ysamples=2, accelerator="grid", world_kwargs=dict(extra=QUADRICS2)),
     # plastic (Lambertian + Blinn microfacet lobes): text substitution of two Material lines below
     "plastic_whitted": dict(xres=40, yres=40, integrator="whitted", world_kwargs=dict(point_light=True)),
     "plastic_direct_ns2": dict(xres=32, yres=32, integrator="directlighting", xsamples=2, ysamples=1, jitter=True, world_kwargs=dict(light_nsamples=2)),

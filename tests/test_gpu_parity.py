@@ -28,7 +28,7 @@ def libm_bound(name, integrator):
     """Scenes whose geometry goes through device libm (sinf/cosf/acosf/atan2f: cosine-sampled bounces of the path
     integrator, quadric hits) can flip a hit/miss at a silhouette by a last-bit difference from glibc: the bar there is the
     north-star's per-pixel L2 < 1e-4 on >= 99.5 % of pixels and on average, instead of every pixel."""
-    return integrator == 2 or name.startswith("sphere_") or name.startswith("quadrics_")
+    return integrator == 2 or name.startswith("sphere_") or name.startswith("quadrics")
 
 
 def oracle_one_ulp_sensitivity(pkg, oracle, ps):

@@ -78,7 +78,7 @@ def test_primitive_order_is_kdtree_refinement_order(pkg):
 
 
 def test_unsupported_plugins_are_errors_not_silent(pkg):
-    ps = pkg.ParsedScene(text=BASE % ("", 'LightSource "point"\nShape "cone" "float radius" [1]\n' + TRI))
+    ps = pkg.ParsedScene(text=BASE % ("", 'LightSource "point"\nShape "heightfield" "integer nu" [2]\n' + TRI))
     assert ps.errors >= 1 and ps.n_tris == 1
     ps = pkg.ParsedScene(text=BASE % ('Camera "fisheye"', 'LightSource "point"\n' + TRI))
     assert not ps.valid
