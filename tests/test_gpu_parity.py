@@ -246,3 +246,24 @@ def test_errors_are_loud(pkg, scenes):
     assert "film size" in str(e.value)
     assert pkg.hip_lib().rt_render(ds._s, None) < 0 and pkg.hip_lib().rt_render(None, ps.render_desc) < 0
     ds.close()
+
+
+@pytest.mark.parametrize("name", ["path_soup2k", "direct_soup5k_seed7", "whitted_glass_mirror", "grid_path_soup3k_eager", "vol_single_path_grid",
+                                  "plastic_path", "sphere_whitted", "qlight_path", "path_jitter_mitchell_4spp"])
+def test_timed_kernels_produce_the_same_film_as_the_counting_twins(pkg, name, monkeypatch):
+    """bench.py times the COUNT=false kernels (and, on large scenes, the register-capped high-occupancy flavour); the parity
+    tests above render with the counting twins.  Scheduling never changes a sample's arithmetic and the film gather is
+    deterministic, so every flavour must give the bit-identical film."""
+    need_gpu(pkg)
+    g = load_golden(name)
+    ps = pkg.ParsedScene(text=g["scene"])
+    ds = pkg.DeviceScene(ps)
+    ds.render()
+    ref = ds.film_accum()
+    for occ in ("0", "1"):
+        monkeypatch.setenv("PBRT_HIP_HIGH_OCC", occ)
+        ds.set_counting(False)
+        ds.clear_film(); ds.render()
+        got = ds.film_accum()
+        assert np.array_equal(got, ref), (name, occ, float(np.abs(got - ref).max()))
+    ds.close()
