@@ -205,6 +205,17 @@ RT_DEV Ray camera_ray(const RtCamera &cam, float ix, float iy, float lensU, floa
 // map a work index of this shard to (pixel, sample-in-pixel); false if it falls off the image
 RT_DEV bool work_to_sample(const DevFrame &fr, unsigned long long w, unsigned long long &pixel, int &s) {
     const unsigned long long per_tile = (unsigned long long)fr.tile_pixels * fr.spp;
+    // every frame of practical size has fewer than 2^32 samples: 32-bit divisions (a 64-bit division is ~150 VALU instructions
+    // on gfx950, and this runs in the sparsely populated fetch path)
+    if (fr.total_work <= 0xffffffffull && per_tile <= 0xffffffffull) {
+        const unsigned w32 = unsigned(w), pt = unsigned(per_tile);
+        const unsigned lt = w32 / pt, rem = w32 - lt * pt;
+        const unsigned long long tile = (unsigned long long)lt * unsigned(fr.shard_count) + unsigned(fr.shard_index);
+        const unsigned q = rem / unsigned(fr.spp);
+        pixel = tile * unsigned(fr.tile_pixels) + q;
+        s = int(rem - q * unsigned(fr.spp));
+        return pixel < fr.total_pixels;
+    }
     const unsigned long long lt = w / per_tile, rem = w % per_tile;
     const unsigned long long tile = lt * fr.shard_count + fr.shard_index;
     pixel = tile * fr.tile_pixels + rem / fr.spp;
@@ -214,7 +225,9 @@ RT_DEV bool work_to_sample(const DevFrame &fr, unsigned long long w, unsigned lo
 
 RT_DEV void setup_sample(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigned long long pixel, int s, Ray &ray) {
     const int w = fr.x_end - fr.x_start;
-    const int px = fr.x_start + int(pixel % w), py = fr.y_start + int(pixel / w);
+    int px, py;
+    if (fr.total_pixels <= 0xffffffffull) { const unsigned row = unsigned(pixel) / unsigned(w); px = fr.x_start + int(unsigned(pixel) - row * unsigned(w)); py = fr.y_start + int(row); }
+    else { px = fr.x_start + int(pixel % w); py = fr.y_start + int(pixel / w); }
     const uint32_t n0 = uint32_t(pixel * fr.spp);
     ln.sample_index = n0 + uint32_t(s);
     ln.rng.base = rng_base(ln.sample_index, fr.seed);

@@ -780,8 +780,9 @@ static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool nee
         const bool tiny = nn <= 4096 && per_leaf >= 1.5;       // few fat leaves: triangle tests dominate -> lock-step rounds
         fr.trav_mode = tiny ? 3 : 2;                           // lock-step rounds with pooled leaf tests (C2: 83.0 vs 87.1 ms for plain
                                                                // lock-step); else batched rounds (measured best on 100k-1M triangle soups)
-        fr.exit_thresh = tiny ? 8 : 32;                        // long divergent rays: let finished lanes refill early (tiny + phase
-                                                               // gating: 8 measured +1.5 %, 16 -13 %)
+        // long divergent rays: let finished lanes refill early.  Tiny scenes: only with phase gating (path integrator), where 8
+        // measured +1.5 % (16: -13 %); Whitted / DirectLighting on Cornell lose 10 % with any early exit
+        fr.exit_thresh = tiny ? (rd->integrator == RT_INTEGRATOR_PATH ? 8 : 0) : 32;
         fr.high_occupancy = tiny ? 0 : 1;
         if (const char *e = std::getenv("PBRT_HIP_HIGH_OCC")) fr.high_occupancy = std::atoi(e);
         if (const char *e = std::getenv("PBRT_HIP_TRAV_MODE")) fr.trav_mode = std::atoi(e);
