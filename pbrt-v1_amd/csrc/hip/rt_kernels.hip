@@ -377,6 +377,7 @@ struct RtScene {
     KdTree tree;
     GridAccelData gridacc;
     int accel_kind = RT_ACCEL_KDTREE;
+    double per_leaf = -1.0;             // average primitives per non-empty kd leaf (traversal heuristics), computed on first use
     bool has_ext = false;               // plastic materials or quadrics present: use the kernels that carry that code (EXT)
     DevScene dev{};
     std::vector<void *> allocs;
@@ -774,9 +775,12 @@ static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool nee
     // traversal scheduling knobs (performance only; results and counters do not depend on them)
     {
         const size_t nn = s->tree.nodes.size();
-        size_t leaves = 0, refs = 0;
-        if (s->accel_kind == RT_ACCEL_KDTREE) for (const Node &n : s->tree.nodes) if ((n.x & 3u) == 3u && (n.x >> 2)) { ++leaves; refs += n.x >> 2; }
-        const double per_leaf = leaves ? double(refs) / double(leaves) : 1.0;
+        if (s->per_leaf < 0.0) {                              // once per scene: a pass over 36 M nodes costs 12 ms, not something to pay per frame
+            size_t leaves = 0, refs = 0;
+            if (s->accel_kind == RT_ACCEL_KDTREE) for (const Node &n : s->tree.nodes) if ((n.x & 3u) == 3u && (n.x >> 2)) { ++leaves; refs += n.x >> 2; }
+            s->per_leaf = leaves ? double(refs) / double(leaves) : 1.0;
+        }
+        const double per_leaf = s->per_leaf;
         const bool tiny = nn <= 4096 && per_leaf >= 1.5;       // few fat leaves: triangle tests dominate -> lock-step rounds
         fr.trav_mode = tiny ? 3 : 2;                           // lock-step rounds with pooled leaf tests (C2: 83.0 vs 87.1 ms for plain
                                                                // lock-step); else batched rounds (measured best on 100k-1M triangle soups)
