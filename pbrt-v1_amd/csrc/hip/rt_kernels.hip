@@ -191,9 +191,18 @@ __global__ __launch_bounds__(256) void film_gather_kernel(const DevFrame *__rest
             bool mine_col = false;
             if (int(threadIdx.x) < ncols) {
                 const unsigned long long pixel = (unsigned long long)(sy - fr.y_start) * ew + (cx + int(threadIdx.x) - fr.x_start);
-                const unsigned long long tile = pixel / fr.tile_pixels;
-                const bool mine = int(tile % fr.shard_count) == fr.shard_index;
-                colbase[threadIdx.x] = mine ? ((tile / fr.shard_count) * per_tile + (pixel % fr.tile_pixels) * fr.spp) * 2 : ~0ull;
+                bool mine; unsigned long long base;
+                if (fr.total_pixels <= 0xffffffffull) {             // 32-bit divisions (a 64-bit one is ~150 VALU instructions)
+                    const unsigned p32 = unsigned(pixel), tile = p32 / unsigned(fr.tile_pixels), in_tile = p32 - tile * unsigned(fr.tile_pixels);
+                    const unsigned lt = tile / unsigned(fr.shard_count);
+                    mine = int(tile - lt * unsigned(fr.shard_count)) == fr.shard_index;
+                    base = ((unsigned long long)lt * per_tile + (unsigned long long)in_tile * fr.spp) * 2;
+                } else {
+                    const unsigned long long tile = pixel / fr.tile_pixels;
+                    mine = int(tile % fr.shard_count) == fr.shard_index;
+                    base = ((tile / fr.shard_count) * per_tile + (pixel % fr.tile_pixels) * fr.spp) * 2;
+                }
+                colbase[threadIdx.x] = mine ? base : ~0ull;
                 mine_col = mine;
             }
             if (!__syncthreads_or(mine_col)) continue;        // this shard owns no sample pixel of this row chunk (7 of 8 chunks at 8 ranks)
