@@ -48,68 +48,8 @@ def main():
             run("profile_" + wl, ["-DRT_PROFILE"], workload=wl)
             run("profile_stages_" + wl, ["-DRT_PROFILE", "-DRT_PROFILE_STAGES"], workload=wl)
         return
-    if which == "h":
-        run("auto_c2"); run("c2_highocc", env={"PBRT_HIP_HIGH_OCC": "1"})
-        run("auto_p100000", workload="p100000"); run("p100000_lowocc", env={"PBRT_HIP_HIGH_OCC": "0"}, workload="p100000")
-        run("auto_c3_100000", workload="c3_100000"); run("c3_100000_lowocc", env={"PBRT_HIP_HIGH_OCC": "0"}, workload="c3_100000")
-        return
-    if which == "g":
-        for wl in ("c2", "p100000"):
-            run("mailbox_" + wl, workload=wl)
-            run("nomailbox_" + wl, ["-DRT_MAILBOX=0"], workload=wl)
-            run("w4_lds16_" + wl, ["-DRT_MIN_WAVES=4", "-DRT_STACK_LDS=16"], workload=wl)
-            run("w3_lds16_" + wl, ["-DRT_STACK_LDS=16"], workload=wl)
-            run("w5_lds12_" + wl, ["-DRT_MIN_WAVES=5", "-DRT_STACK_LDS=12"], workload=wl)
-        return
-    if which == "f":
-        run("auto_c2")
-        run("auto_c3_100k", workload="c3_100000")
-        for mode in (0, 2):
-            for ex in (16, 32, 40, 48, 56):
-                run("c3_100k_mode%d_exit%d" % (mode, ex), env={"PBRT_HIP_TRAV_MODE": str(mode), "PBRT_HIP_EXIT_THRESH": str(ex)}, workload="c3_100000")
-        run("c2_mode1_exit8", env={"PBRT_HIP_TRAV_MODE": "1", "PBRT_HIP_EXIT_THRESH": "8"})
-        run("c2_mode1_exit16", env={"PBRT_HIP_TRAV_MODE": "1", "PBRT_HIP_EXIT_THRESH": "16"})
-        return
-    if which == "e":
-        for k in (8, 16, 32, 48):
-            run("batched_k%d" % k, ["-DRT_LOCKSTEP=2", "-DRT_BATCH_K=%d" % k])
-            run("batched_k%d_c3_100k" % k, ["-DRT_LOCKSTEP=2", "-DRT_BATCH_K=%d" % k], workload="c3_100000")
-        run("batched_k16_c3_100k_exit24", ["-DRT_LOCKSTEP=2", "-DRT_BATCH_K=16", "-DRT_EXIT_THRESH=24"], workload="c3_100000")
-    if which == "d":
-        run("lockstep")
-        run("stepwise", ["-DRT_LOCKSTEP=0"])
-        run("lockstep_c3_100k", workload="c3_100000")
-        run("stepwise_c3_100k", ["-DRT_LOCKSTEP=0"], workload="c3_100000")
-        run("lockstep_c3_100k_exit24", ["-DRT_EXIT_THRESH=24"], workload="c3_100000")
-        run("lockstep_lds16", ["-DRT_STACK_LDS=16"])
-    if which == "c":
-        run("base")
-        run("nofilm", env={"PBRT_HIP_DEBUG_NOFILM": "1"})
-        run("c3_100k_base", workload="c3_100000")
-        run("c3_100k_exit24", ["-DRT_EXIT_THRESH=24"], workload="c3_100000")
-        run("c1", workload="c1", steps=5)
-    if which == "b":
-        run("base")
-        run("nofilm", env={"PBRT_HIP_DEBUG_NOFILM": "1"})
-        run("waves4_lds12", ["-DRT_MIN_WAVES=4", "-DRT_STACK_LDS=12"])
-        run("waves4_lds16", ["-DRT_MIN_WAVES=4", "-DRT_STACK_LDS=16"])
-        run("waves5_lds12", ["-DRT_MIN_WAVES=5", "-DRT_STACK_LDS=12"])
-        run("waves4_lds12_exit16", ["-DRT_MIN_WAVES=4", "-DRT_STACK_LDS=12", "-DRT_EXIT_THRESH=16"])
-        run("waves4_lds12_exit32", ["-DRT_MIN_WAVES=4", "-DRT_STACK_LDS=12", "-DRT_EXIT_THRESH=32"])
-        run("c3_100k_base", workload="c3_100000")
-        run("c3_100k_w4", ["-DRT_MIN_WAVES=4", "-DRT_STACK_LDS=16"], workload="c3_100000")
-        run("c3_100k_w4_exit24", ["-DRT_MIN_WAVES=4", "-DRT_STACK_LDS=16", "-DRT_EXIT_THRESH=24"], workload="c3_100000")
-    if which == "a":
-        run("base")
-        run("nofilm", env={"PBRT_HIP_DEBUG_NOFILM": "1"})
-        run("waves2", ["-DRT_MIN_WAVES=2"])
-        run("waves3_lds16", ["-DRT_MIN_WAVES=3", "-DRT_STACK_LDS=16"])
-        run("waves4_lds12", ["-DRT_MIN_WAVES=4", "-DRT_STACK_LDS=12"])
-        run("exit16", ["-DRT_EXIT_THRESH=16"])
-        run("exit32", ["-DRT_EXIT_THRESH=32"])
-        run("c3_100k_base", workload="c3_100000")
-        run("c3_100k_exit24", ["-DRT_EXIT_THRESH=24"], workload="c3_100000")
-    run("base_restore")
+    raise SystemExit("usage: perf_sweep.py p|q|r|s  (p: RT_PROFILE cycle split, q: film-gather ablation, r/s: occupancy flavours on the soups)")
+
 
 if __name__ == "__main__":
     main()
