@@ -26,6 +26,11 @@ def run(tag, defs=(), env=None, workload="c2", steps=2, extra=()):
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "a"
+    if which == "t":
+        for k in (8, 32):
+            run("batch_k%d_p1m" % k, ["-DRT_BATCH_K=%d" % k], workload="p1000000")
+            run("batch_k%d_c3" % k, ["-DRT_BATCH_K=%d" % k], workload="c3")
+        return
     if which == "s":
         for w in (4, 5):
             run("highocc%d_p1m" % w, ["-DRT_HIGH_OCC_WAVES=%d" % w], workload="p1000000")
@@ -48,7 +53,7 @@ def main():
             run("profile_" + wl, ["-DRT_PROFILE"], workload=wl)
             run("profile_stages_" + wl, ["-DRT_PROFILE", "-DRT_PROFILE_STAGES"], workload=wl)
         return
-    raise SystemExit("usage: perf_sweep.py p|q|r|s  (p: RT_PROFILE cycle split, q: film-gather ablation, r/s: occupancy flavours on the soups)")
+    raise SystemExit("usage: perf_sweep.py p|q|r|s|t  (p: RT_PROFILE cycle split, q: film-gather ablation, r/s: occupancy flavours on the soups)")
 
 
 if __name__ == "__main__":
