@@ -138,6 +138,8 @@ def main():
 
     text, label, crop = workload(args.workload)
     ps = pkg.ParsedScene(text=text)
+    if not ps.valid or ps.errors:
+        raise SystemExit("bench.py: the workload's scene description did not parse cleanly (%d errors): refusing to time a different scene" % ps.errors)
     emu = int(os.environ.get("PBRT_BENCH_EMULATE_WORLD", "0"))      # debugging aid: time rank 0's share of an N-rank job on one GPU
     ps.set_shard(rank, emu if (emu > 1 and world == 1) else world, args.tile_pixels)
     ds = pkg.DeviceScene(ps, device=local_rank)

@@ -56,16 +56,26 @@ def lcg_soup(n_tris: int, seed: int = 12345) -> np.ndarray:
     return (centre[:, None, :] + off).astype(np.float32)
 
 
+MAX_MESH_TRIS = 1_000_000
+
+
 def soup_shape_text(tris: np.ndarray) -> str:
-    n = tris.shape[0]
+    """One `trianglemesh` per MAX_MESH_TRIS triangles: the pbrt-v1 file format reads every number as a float
+    (pbrtlex.l: atof into a float), so vertex indices above 2^24 = 16.7 M cannot be written exactly -- a single mesh holds at
+    most 5.59 M independent triangles in the reference too."""
     import io
-    buf = io.StringIO()
-    np.savetxt(buf, tris.reshape(-1, 9), fmt="%.9g")
-    pts = buf.getvalue()
-    buf = io.StringIO()
-    np.savetxt(buf, np.arange(3 * n, dtype=np.int64).reshape(-1, 3), fmt="%d")
-    idx = buf.getvalue()
-    return 'Shape "trianglemesh" "integer indices" [%s] "point P" [%s]\n' % (idx, pts)
+    out = []
+    for lo in range(0, tris.shape[0], MAX_MESH_TRIS):
+        part = tris[lo:lo + MAX_MESH_TRIS]
+        n = part.shape[0]
+        buf = io.StringIO()
+        np.savetxt(buf, part.reshape(-1, 9), fmt="%.9g")
+        pts = buf.getvalue()
+        buf = io.StringIO()
+        np.savetxt(buf, np.arange(3 * n, dtype=np.int64).reshape(-1, 3), fmt="%d")
+        idx = buf.getvalue()
+        out.append('Shape "trianglemesh" "integer indices" [%s] "point P" [%s]\n' % (idx, pts))
+    return "".join(out)
 
 
 def cornell_world(soup: np.ndarray | None = None, soup_materials: bool = False,
