@@ -35,7 +35,7 @@ def workload(name: str):
         text = scenes.cornell_scene(xres=1024, yres=1024, integrator="path", maxdepth=5, xsamples=8, ysamples=8,
                                     jitter=True, pixel_filter="mitchell", accelerator="kdtree")
         label = "Cornell box (12 tris + 2-tri area light), PathIntegrator maxdepth=5, 1024x1024 @ 64 spp (stratified 8x8 jittered), mitchell 2x2 filter, kd-tree"
-        crop = (0.4375, 0.5625, 0.4375, 0.5625)
+        crop = (0.34, 0.66, 0.34, 0.66)                       # ~10 % of the frame: ~14 s of reference CPU time
     elif name in ("c2w", "c2d"):        # same frame as c2 with the cheaper integrators (where does the time go?)
         integ = "whitted" if name == "c2w" else "directlighting"
         text = scenes.cornell_scene(xres=1024, yres=1024, integrator=integ, xsamples=8, ysamples=8, jitter=True, pixel_filter="mitchell")
@@ -51,25 +51,25 @@ def workload(name: str):
         text = scenes.cornell_scene(xres=1920, yres=1080, integrator="directlighting", xsamples=4, ysamples=4,
                                     jitter=True, pixel_filter="mitchell", soup_tris=ntri)
         label = "Cornell + %d-triangle LCG soup, DirectLighting(all), 1920x1080 @ 16 spp, mitchell, kd-tree" % ntri
-        crop = (0.47, 0.53, 0.47, 0.53)
+        crop = (0.2, 0.8, 0.2, 0.8)
     elif name.startswith("c4"):             # c4_1000000: BASELINE config 4 at single-GPU size (material mix, path depth 8)
         ntri = 1_000_000 if name == "c4" else int(name.split("_")[1])
         text = scenes.cornell_scene(xres=1024, yres=1024, integrator="path", maxdepth=8, xsamples=4, ysamples=4, jitter=True,
                                     pixel_filter="mitchell", soup_tris=ntri, soup_materials=True)
         label = "Cornell + %d-triangle LCG soup, matte/glass/mirror mix, PathIntegrator maxdepth=8, 1024x1024 @ 16 spp, mitchell, kd-tree" % ntri
-        crop = (0.48, 0.52, 0.48, 0.52)
+        crop = (0.39, 0.61, 0.39, 0.61)
     elif name.startswith("c5"):             # c5_1000000: BASELINE config 5 at single-GPU size (homogeneous medium, single scattering)
         ntri = 1_000_000 if name == "c5" else int(name.split("_")[1])
         text = scenes.cornell_scene(xres=1024, yres=1024, integrator="directlighting", xsamples=4, ysamples=4, jitter=True, pixel_filter="mitchell",
                                     soup_tris=ntri, volume_integrator='"single" "float stepsize" [40]', world_kwargs=dict(volume='"float g" [.2]'))
         label = "Cornell + %d-triangle LCG soup in a homogeneous medium, single-scattering volume integrator (stepsize 40) + DirectLighting, 1024x1024 @ 16 spp" % ntri
-        crop = (0.48, 0.52, 0.48, 0.52)
+        crop = (0.39, 0.61, 0.39, 0.61)
     elif name.startswith("p"):              # p1000000: Cornell + N-triangle soup, path tracing (the north-star's 1M-triangle case)
         ntri = int(name[1:])
         text = scenes.cornell_scene(xres=1024, yres=1024, integrator="path", maxdepth=5, xsamples=4, ysamples=4,
                                     jitter=True, pixel_filter="mitchell", soup_tris=ntri)
         label = "Cornell + %d-triangle LCG soup, PathIntegrator maxdepth=5, 1024x1024 @ 16 spp, mitchell, kd-tree" % ntri
-        crop = (0.48, 0.52, 0.48, 0.52)
+        crop = (0.39, 0.61, 0.39, 0.61)
     else:
         raise SystemExit("unknown workload " + name)
     return text, label, crop
