@@ -530,7 +530,12 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
         if ((rc = upload(s, dq.data(), dq.size(), &s->dev.quadrics))) return rc;
     }
     const uint2 *nodes_dev = nullptr;
-    if ((rc = upload(s, reinterpret_cast<const uint2 *>(s->tree.nodes.data()), s->tree.nodes.size(), &nodes_dev))) return rc;
+    {   // one node of padding: the traversal may fetch node i+1 together with node i
+        std::vector<uint2> padded(s->tree.nodes.size() + 1);
+        std::memcpy(padded.data(), s->tree.nodes.data(), s->tree.nodes.size() * sizeof(uint2));
+        padded.back() = make_uint2(3u, 0u);
+        if ((rc = upload(s, padded.data(), padded.size(), &nodes_dev))) return rc;
+    }
     s->dev.nodes = nodes_dev;
     if ((rc = upload(s, s->tree.leaf_refs.data(), s->tree.leaf_refs.size(), &s->dev.leaf_refs))) return rc;
 

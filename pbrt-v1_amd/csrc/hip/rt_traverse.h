@@ -34,6 +34,11 @@
 namespace rt {
 
 struct Ray { V3 o, d; float mint, maxt; };
+#ifdef RT_PAIR_FETCH
+#define RT_PAIR_INIT(tv) tv.nxt_node = 0xffffffffu;
+#else
+#define RT_PAIR_INIT(tv)
+#endif
 
 struct Trav {
     // ray being traced
@@ -43,6 +48,9 @@ struct Trav {
     unsigned node;
     float tmin, tmax;
     int sp, sbase;                 // todo stack: entries [sbase, sp) live in the LDS ring, [0, sbase) in HBM
+#ifdef RT_PAIR_FETCH
+    uint2 nxt; unsigned nxt_node;  // contents of node nxt_node (the below child of the node fetched last), fetched with its parent
+#endif
     // leaf / voxel primitive-list cursor for the lock-step ("while-while") traversal: at_leaf => test prims [li, ln)
     unsigned li, ln_, ly;
     bool at_leaf;
@@ -222,7 +230,7 @@ RT_DEV uint2 stack_pop(Trav &tv, const uint2 RT_L *lds_stack, const uint2 RT_G *
 // start a traversal: slab-clip against the tree bounds (geometry.cpp:51-68, NaN-preserving ternaries)
 RT_DEV void trav_begin(Trav &tv, const DevScene &sc, const Ray &r, bool any) {
     tv.o = r.o; tv.d = r.d; tv.mint = r.mint; tv.maxt = r.maxt; tv.any = any;
-    tv.hit_prim = -1; tv.b1 = 0.f; tv.b2 = 0.f; tv.sp = 0; tv.sbase = 0; tv.node = 0; tv.at_leaf = false; tv.li = tv.ln_ = tv.ly = 0;
+    tv.hit_prim = -1; tv.b1 = 0.f; tv.b2 = 0.f; tv.sp = 0; tv.sbase = 0; RT_PAIR_INIT(tv) tv.node = 0; tv.at_leaf = false; tv.li = tv.ln_ = tv.ly = 0;
 #if RT_MAILBOX
     tv.mb0 = tv.mb1 = tv.mb2 = tv.mb3 = 0xffffffffu;
 #endif
@@ -297,7 +305,7 @@ RT_DEV float arr3(const float *a, int i) { return i == 0 ? a[0] : (i == 1 ? a[1]
 RT_DEV int arr3i(const int *a, int i) { return i == 0 ? a[0] : (i == 1 ? a[1] : a[2]); }
 RT_DEV void grid_begin(Trav &tv, const DevScene &sc, const Ray &r, bool any) {
     tv.o = r.o; tv.d = r.d; tv.mint = r.mint; tv.maxt = r.maxt; tv.any = any;
-    tv.hit_prim = -1; tv.b1 = 0.f; tv.b2 = 0.f; tv.sp = 0; tv.sbase = 0; tv.node = 0; tv.at_leaf = false; tv.li = tv.ln_ = tv.ly = 0;
+    tv.hit_prim = -1; tv.b1 = 0.f; tv.b2 = 0.f; tv.sp = 0; tv.sbase = 0; RT_PAIR_INIT(tv) tv.node = 0; tv.at_leaf = false; tv.li = tv.ln_ = tv.ly = 0;
 #if RT_MAILBOX
     tv.mb0 = tv.mb1 = tv.mb2 = tv.mb3 = 0xffffffffu;
 #endif
@@ -377,7 +385,19 @@ RT_DEV void grid_step(Trav &tv, const DevScene &sc, TravCounters &cnt) {
 template <bool COUNT>
 RT_DEV void kd_descend(Trav &tv, const DevScene &sc, uint2 RT_L *lds_stack, uint2 RT_G *spill, unsigned n_threads, unsigned gtid, TravCounters &cnt) {
     if (!tv.any && tv.maxt < tv.tmin) { tv.active = false; return; }      // kdtree.cpp:330
+#ifdef RT_PAIR_FETCH
+    // the below child sits right behind its parent (depth-first layout): fetch the pair with one 16-byte request and skip the
+    // next round trip when the traversal continues there (the array is padded by one node)
+    uint2 nd;
+    if (tv.nxt_node == tv.node) { nd = tv.nxt; tv.nxt_node = 0xffffffffu; }
+    else {
+        typedef uint4 __attribute__((aligned(8))) uint4_a8;
+        const uint4_a8 pr = *(const uint4_a8 RT_G *)(RT_GPTR(const uint2, sc.nodes) + tv.node);
+        nd = make_uint2(pr.x, pr.y); tv.nxt = make_uint2(pr.z, pr.w); tv.nxt_node = tv.node + 1u;
+    }
+#else
     const uint2 nd = RT_GPTR(const uint2, sc.nodes)[tv.node];
+#endif
     if (COUNT) ++cnt.nodes;
     if ((nd.x & 3u) == 3u) { tv.at_leaf = true; tv.li = 0; tv.ln_ = nd.x >> 2; tv.ly = nd.y; return; }
     const int axis = int(nd.x & 3u);
