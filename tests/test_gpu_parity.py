@@ -346,3 +346,19 @@ def test_randomized_feature_mixes_against_the_oracle(pkg, scenes, oracle, k):
         assert s["frac"] < 0.995, (k, m, s)
         assert m["frac"] >= 0.75 * s["frac"] - 0.02, (k, m, s)
         assert abs(float(rgb.mean()) - float(orgb.mean())) <= 0.05 * float(orgb.mean()) + 1e-3, (k, float(rgb.mean()), float(orgb.mean()))
+
+
+def test_film_into_caller_buffers(pkg, scenes):
+    """rt_film_resolve into caller-provided (e.g. page-locked, reused) buffers gives the film it allocates itself; wrong shapes
+    are rejected on the host side."""
+    need_gpu(pkg)
+    ps = pkg.ParsedScene(text=scenes.cornell_scene(xres=40, yres=24, integrator="directlighting", keyed=True))
+    ds = pkg.DeviceScene(ps)
+    ds.render()
+    rgb, alpha = ds.film()
+    out = (np.full((24, 40, 3), -1, np.float32), np.full((24, 40), -1, np.float32))
+    r2, a2 = ds.film(out=out)
+    assert r2 is out[0] and a2 is out[1] and np.array_equal(r2, rgb) and np.array_equal(a2, alpha)
+    with pytest.raises(ValueError):
+        ds.film(out=(np.zeros((24, 40, 4), np.float32), out[1]))
+    ds.close()
