@@ -149,6 +149,10 @@ def host_lib():
         L.pbrt_host_write_exr.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6
         L.pbrt_host_read_exr_info.argtypes = [C.c_char_p, C.POINTER(C.c_int * 6)]
         L.pbrt_host_read_exr.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p]
+        L.pbrt_host_format_f32.restype = C.c_longlong
+        L.pbrt_host_format_f32.argtypes = [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_longlong]
+        L.pbrt_host_format_iota.restype = C.c_longlong
+        L.pbrt_host_format_iota.argtypes = [C.c_longlong, C.c_longlong, C.c_int, C.c_void_p, C.c_longlong]
         L.pbrt_host_accel_params.restype = C.c_void_p
         L.pbrt_host_accel_params.argtypes = [C.c_void_p]
         _host = L
@@ -172,6 +176,24 @@ def read_exr(path):
     rgb = np.zeros((h, w, 3), np.float32); alpha = np.zeros((h, w), np.float32)
     host_lib().pbrt_host_read_exr(path.encode(), rgb.ctypes.data, alpha.ctypes.data)
     return rgb, alpha, dict(total_res=(info[2], info[3]), offset=(info[4], info[5]))
+
+
+def format_f32(values, per_line: int = 9) -> str:
+    """Scene-text numbers ("%.9g": round-trips float32) formatted by the host library: 1 s for a 1 M-triangle mesh."""
+    v = np.ascontiguousarray(values, np.float32).ravel()
+    buf = C.create_string_buffer(int(v.size) * 17 + 64)
+    n = host_lib().pbrt_host_format_f32(v.ctypes.data, v.size, per_line, buf, len(buf))
+    if n < 0:
+        raise RuntimeError("format_f32: buffer too small")
+    return buf.raw[:n].decode()
+
+
+def format_iota(first: int, count: int, per_line: int = 3) -> str:
+    buf = C.create_string_buffer(int(count) * 12 + 64)
+    n = host_lib().pbrt_host_format_iota(first, count, per_line, buf, len(buf))
+    if n < 0:
+        raise RuntimeError("format_iota: buffer too small")
+    return buf.raw[:n].decode()
 
 
 class RtError(RuntimeError):

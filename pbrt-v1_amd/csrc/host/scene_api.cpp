@@ -693,6 +693,28 @@ void pbrt_host_scene_counts(const RtSceneDesc *s, unsigned *out4) { out4[0] = s-
 const float *pbrt_host_camera(const RtSceneDesc *s) { return s->camera.raster_to_camera; }
 const float *pbrt_host_tri_verts(const RtSceneDesc *s) { return s->tri_verts; }
 const RtAccelParams *pbrt_host_accel_params(const RtSceneDesc *s) { return &s->accel; }
+// scene-text writers for the synthetic generators (pbrt-v1_amd/scenes.py): "%.9g" round-trips every float32; np.savetxt
+// needs 24 s for the 9 M numbers of a 1 M-triangle mesh, snprintf 1 s.  Returns the bytes written (excluding the NUL), or -1.
+long long pbrt_host_format_f32(const float *v, long long n, int per_line, char *out, long long cap) {
+    long long w = 0;
+    for (long long i = 0; i < n; ++i) {
+        if (cap - w < 32) return -1;
+        w += std::snprintf(out + w, size_t(cap - w), "%.9g", double(v[i]));
+        out[w++] = ((i + 1) % per_line == 0) ? '\n' : ' ';
+    }
+    if (w < cap) out[w] = 0;
+    return w;
+}
+long long pbrt_host_format_iota(long long first, long long n, int per_line, char *out, long long cap) {
+    long long w = 0;
+    for (long long i = 0; i < n; ++i) {
+        if (cap - w < 32) return -1;
+        w += std::snprintf(out + w, size_t(cap - w), "%lld", first + i);
+        out[w++] = ((i + 1) % per_line == 0) ? '\n' : ' ';
+    }
+    if (w < cap) out[w] = 0;
+    return w;
+}
 // Film output: the reference's WriteRGBAImage (core/exrio.cpp:75-96) and the tile merge of tools/exrassemble.cpp
 int pbrt_host_write_exr(const char *path, const float *rgb, const float *alpha, int xRes, int yRes, int totalX, int totalY, int xOff, int yOff) {
     return WriteRGBAImage(path, rgb, alpha, xRes, yRes, totalX, totalY, xOff, yOff) ? 0 : -1;

@@ -26,7 +26,23 @@ def _fmt(vals):
     return " ".join(repr(float(v)) if isinstance(v, (float, np.floating)) else str(v) for v in vals)
 
 
+_SOUP_CACHE: dict = {}
+_SOUP_TEXT_CACHE: dict = {}
+
+
 def lcg_soup(n_tris: int, seed: int = 12345) -> np.ndarray:
+    """Cached front of _lcg_soup (bench.py renders several workloads over the same 1 M-triangle soup)."""
+    key = (int(n_tris), int(seed))
+    if key not in _SOUP_CACHE:
+        if len(_SOUP_CACHE) > 4:
+            _SOUP_CACHE.clear(); _SOUP_TEXT_CACHE.clear()
+        a = _lcg_soup(n_tris, seed)
+        a.setflags(write=False)
+        _SOUP_CACHE[key] = a
+    return _SOUP_CACHE[key]
+
+
+def _lcg_soup(n_tris: int, seed: int = 12345) -> np.ndarray:
     """N triangles, centres uniform in [50,500]x[50,450]x[50,500], vertices centre +- U(-4,4)
     per axis, from the LCG s = s*1664525 + 1013904223 (mod 2^32), u = (s >> 8) / 2^24.
     Returns float32 array [n_tris, 3, 3].  Vectorised: the LCG is jumped with the closed
@@ -63,19 +79,44 @@ def soup_shape_text(tris: np.ndarray) -> str:
     """One `trianglemesh` per MAX_MESH_TRIS triangles: the pbrt-v1 file format reads every number as a float
     (pbrtlex.l: atof into a float), so vertex indices above 2^24 = 16.7 M cannot be written exactly -- a single mesh holds at
     most 5.59 M independent triangles in the reference too."""
-    import io
+    from . import format_f32, format_iota
     out = []
     for lo in range(0, tris.shape[0], MAX_MESH_TRIS):
         part = tris[lo:lo + MAX_MESH_TRIS]
         n = part.shape[0]
-        buf = io.StringIO()
-        np.savetxt(buf, part.reshape(-1, 9), fmt="%.9g")
-        pts = buf.getvalue()
-        buf = io.StringIO()
-        np.savetxt(buf, np.arange(3 * n, dtype=np.int64).reshape(-1, 3), fmt="%d")
-        idx = buf.getvalue()
-        out.append('Shape "trianglemesh" "integer indices" [%s] "point P" [%s]\n' % (idx, pts))
+        out.append('Shape "trianglemesh" "integer indices" [%s] "point P" [%s]\n' % (format_iota(0, 3 * n, 3), format_f32(part, 9)))
     return "".join(out)
+
+
+def _soup_block(soup: np.ndarray, soup_materials: bool) -> str:
+    """The soup's Attribute block(s); the text of a cached lcg_soup is cached too (120 MB for 1 M triangles)."""
+    ckey = None
+    for k, v in _SOUP_CACHE.items():
+        if v is soup:
+            ckey = (k, bool(soup_materials))
+    if ckey is not None and ckey in _SOUP_TEXT_CACHE:
+        return _SOUP_TEXT_CACHE[ckey]
+    out = []
+    if not soup_materials:
+        out.append("AttributeBegin # soup\n")
+        out.append('  Material "matte" "color Kd" [.5 .5 .5]\n')
+        out.append("  " + soup_shape_text(soup))
+        out.append("AttributeEnd\n")
+    else:
+        # C4 material mix: tri % 10 == 0 -> glass(1.5), == 1 -> mirror, else matte
+        n = soup.shape[0]
+        cls = np.arange(n) % 10
+        for label, sel, mat in (("glass", cls == 0, 'Material "glass" "float index" [1.5]'),
+                                ("mirror", cls == 1, 'Material "mirror"'),
+                                ("matte", cls >= 2, 'Material "matte" "color Kd" [.6 .55 .5]')):
+            if sel.any():
+                out.append("AttributeBegin # soup %s\n  %s\n  " % (label, mat))
+                out.append(soup_shape_text(soup[sel]))
+                out.append("AttributeEnd\n")
+    text = "".join(out)
+    if ckey is not None:
+        _SOUP_TEXT_CACHE[ckey] = text
+    return text
 
 
 def cornell_world(soup: np.ndarray | None = None, soup_materials: bool = False,
@@ -111,22 +152,7 @@ def cornell_world(soup: np.ndarray | None = None, soup_materials: bool = False,
         out.append("  " + soup_shape_text(glass_sphere_tris))
         out.append("AttributeEnd\n")
     if soup is not None and len(soup):
-        if not soup_materials:
-            out.append("AttributeBegin # soup\n")
-            out.append('  Material "matte" "color Kd" [.5 .5 .5]\n')
-            out.append("  " + soup_shape_text(soup))
-            out.append("AttributeEnd\n")
-        else:
-            # C4 material mix: tri % 10 == 0 -> glass(1.5), == 1 -> mirror, else matte
-            n = soup.shape[0]
-            cls = np.arange(n) % 10
-            for label, sel, mat in (("glass", cls == 0, 'Material "glass" "float index" [1.5]'),
-                                    ("mirror", cls == 1, 'Material "mirror"'),
-                                    ("matte", cls >= 2, 'Material "matte" "color Kd" [.6 .55 .5]')):
-                if sel.any():
-                    out.append("AttributeBegin # soup %s\n  %s\n  " % (label, mat))
-                    out.append(soup_shape_text(soup[sel]))
-                    out.append("AttributeEnd\n")
+        out.append(_soup_block(soup, soup_materials))
     if volume:
         out.append('Volume "homogeneous" "point p0" [0 0 0] "point p1" [556 549 559] '
                    '"color sigma_a" [.002 .002 .002] "color sigma_s" [.002 .002 .002] %s\n' % volume)

@@ -1,0 +1,176 @@
+"""GPU tests of the BASELINE.json configs the golden fixtures are too small for:
+  C3  1 M-triangle soup, DirectLighting, 1920x1080 @ 16 spp    -> full-size properties + oracle parity of a crop-sized frame
+  C4  matte / glass / mirror soup mix, PathIntegrator maxdepth 8 -> device vs the CPU oracle at 30 k triangles
+  C5  homogeneous medium + single scattering over a soup        -> device vs the CPU oracle at 20 k triangles
+  and the >= 1 M-triangle regime itself (depth-34 tree, 36 M nodes, HBM stack spills): rt_trace_closest / rt_trace_any of
+  camera, random and shadow-segment rays bit-exact against the oracle on the SAME tree, with identical work counters.
+Everything goes through the C ABI (pbrt_hip.h); the oracle is the checker only."""
+import numpy as np
+import pytest
+from conftest import film_metrics
+from test_gpu_parity import need_gpu, check_film, record_case
+
+pytestmark = pytest.mark.gpu
+
+COUNTERS = ("camera_rays", "closest_rays", "any_rays", "nodes_visited", "leaf_refs", "tri_tests")
+
+
+def accel_of(ds):
+    nodes, refs = ds.accel_arrays()
+    info = ds.accel_info()
+    return nodes, refs, np.array(list(info.bounds), np.float32), info
+
+
+# ---------------------------------------------------------------------------------------------- C4 / C5 at oracle size
+@pytest.mark.parametrize("cfg", [
+    # C4's workload: material mix (tri % 10: glass, mirror, matte) + path tracing to depth 8
+    dict(xres=128, yres=128, integrator="path", maxdepth=8, xsamples=2, ysamples=2, jitter=True, pixel_filter="mitchell",
+         soup_tris=30000, soup_materials=True),
+    dict(xres=96, yres=96, integrator="path", maxdepth=8, sampler="lowdiscrepancy", pixelsamples=4, soup_tris=50000, soup_materials=True),
+    # C5's workload: homogeneous medium, single scattering, over a soup (with both surface integrators the config can mean)
+    dict(xres=96, yres=96, integrator="directlighting", xsamples=2, ysamples=2, jitter=True, pixel_filter="mitchell", soup_tris=20000,
+         volume_integrator='"single" "float stepsize" [40]', world_kwargs=dict(volume='"float g" [.2]')),
+    dict(xres=80, yres=80, integrator="path", maxdepth=5, xsamples=2, ysamples=2, jitter=True, soup_tris=20000, soup_materials=True,
+         volume_integrator='"single" "float stepsize" [60]', world_kwargs=dict(volume='"float g" [-.1] "color Le" [.001 .001 .002]')),
+    dict(xres=96, yres=96, integrator="whitted", xsamples=2, ysamples=1, soup_tris=25000, soup_materials=True,
+         volume_integrator='"emission" "float stepsize" [30]', world_kwargs=dict(volume='"color Le" [.002 .001 .001]')),
+])
+def test_c4_c5_workloads_against_the_oracle(pkg, scenes, oracle, cfg):
+    need_gpu(pkg)
+    ps = pkg.ParsedScene(text=scenes.cornell_scene(keyed=True, **cfg))
+    assert ps.valid and ps.errors == 0 and ps.warnings == 0
+    ds = pkg.DeviceScene(ps)
+    ds.render()
+    rgb, alpha = ds.film()
+    cnt = ds.counters()
+    nodes, refs, bounds, info = accel_of(ds)
+    # the timed flavours give the same film as the counting twin just compared
+    acc = ds.film_accum()
+    for env in (dict(PBRT_HIP_HIGH_OCC="0"), dict(PBRT_HIP_HIGH_OCC="1"), dict(PBRT_HIP_PIPELINE="1")):
+        with pytest.MonkeyPatch.context() as mp:
+            for k, v in env.items():
+                mp.setenv(k, v)
+            ds.set_counting(False); ds.clear_film(); ds.render()
+            assert np.array_equal(ds.film_accum(), acc), env
+    ds.close()
+    orgb, oalpha, _, ocnt = oracle.render(ps, nodes, refs, bounds, info=info)
+    m = check_film("cfg:" + str(cfg), rgb, alpha, orgb, oalpha, ps.integrator)
+    record_case("c4c5:%s:%d" % (cfg["integrator"], cfg["soup_tris"]), m)
+    assert cnt["camera_rays"] == ocnt["camera_rays"] and cnt["bad_samples"] == 0
+    if ps.integrator != 2:
+        for k in COUNTERS:
+            assert cnt[k] == ocnt[k], (k, cnt[k], ocnt[k])
+    else:
+        for k in ("closest_rays", "any_rays", "nodes_visited", "tri_tests"):
+            assert abs(cnt[k] - ocnt[k]) <= 5e-4 * ocnt[k] + 8, (k, cnt[k], ocnt[k])
+
+
+# ---------------------------------------------------------------------------------------------- the 1 M-triangle regime
+@pytest.fixture(scope="module")
+def soup1m(pkg, scenes):
+    """C3's scene at a frame the oracle finishes in seconds; the tree is the full 36 M-node, depth-34 one."""
+    need_gpu(pkg)
+    text = scenes.cornell_scene(xres=96, yres=54, integrator="directlighting", xsamples=2, ysamples=2, jitter=True,
+                                pixel_filter="mitchell", soup_tris=1_000_000, keyed=True)
+    ps = pkg.ParsedScene(text=text)
+    assert ps.valid and ps.errors == 0 and ps.n_tris == 1_000_012
+    ds = pkg.DeviceScene(ps)
+    yield ps, ds, accel_of(ds)
+    ds.close()
+
+
+def test_1m_tree_is_the_reference_sized_tree(soup1m):
+    ps, ds, (nodes, refs, bounds, info) = soup1m
+    # maxDepth = Round2Int(8 + 1.3 * Log2Int(N)) = 8 + 1.3 * 19 = 32.7 -> 33 (+1 counting convention here)
+    assert info.n_nodes > 30_000_000 and info.max_depth >= 33 and info.n_tris == ps.n_tris
+
+
+def test_1m_trace_bit_exact_with_identical_work_counters(pkg, oracle, soup1m):
+    ps, ds, (nodes, refs, bounds, info) = soup1m
+    rng = np.random.default_rng(77)
+    cam = ds.camera_rays(0, ps.n_camera_samples)                              # every camera ray of the frame
+    n = 120_000
+    rnd = np.zeros(n, pkg.RAY_DTYPE)
+    rnd["o"] = rng.uniform(-20, 580, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rnd["d"] = d.astype(np.float32); rnd["mint"] = 1e-3; rnd["maxt"] = np.inf
+    rnd["d"][:2000] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, 2000)] * rng.choice([-1, 1], (2000, 1)).astype(np.float32)
+    tv = ps.tri_verts()
+    rnd["o"][2000:4000] = tv[rng.integers(0, len(tv), 2000)].mean(1)        # rays that start on a triangle
+    rays = np.concatenate([cam, rnd])
+    ds.reset_counters()
+    hits = ds.trace_closest(rays)
+    dc = ds.counters()
+    ref, oc = oracle.trace(ps, rays, False, nodes, refs, bounds)
+    assert np.array_equal(hits["prim"], ref["prim"]) and np.array_equal(hits["t"], ref["t"])
+    assert np.array_equal(hits["b1"], ref["b1"]) and np.array_equal(hits["b2"], ref["b2"])
+    for k in ("nodes_visited", "leaf_refs", "tri_tests"):
+        assert dc[k] == oc[k], (k, dc[k], oc[k])
+    assert (hits["prim"] >= 0).mean() > 0.5
+    # shadow segments from the hit points towards the light (VisibilityTester::SetSegment light.h:78-80): the longest rays
+    hit = hits["prim"] >= 0
+    p = rays["o"][hit] + rays["d"][hit] * hits["t"][hit, None]
+    seg = np.zeros(len(p), pkg.RAY_DTYPE)
+    seg["o"] = p
+    seg["d"] = (np.array([278, 548.7, 279.5], np.float32) - p).astype(np.float32)
+    seg["mint"] = 1e-3; seg["maxt"] = np.float32(1.0) - np.float32(1e-3)
+    ds.reset_counters()
+    occ = ds.trace_any(seg)
+    dc = ds.counters()
+    refo, oc = oracle.trace(ps, seg, True, nodes, refs, bounds)
+    assert np.array_equal(occ, refo)
+    for k in ("nodes_visited", "leaf_refs", "tri_tests"):
+        assert dc[k] == oc[k], (k, dc[k], oc[k])
+    # a depth-34 tree overflows the LDS ring: the spill path is exercised in earnest here
+    assert dc["stack_overflows"] > 0 or ds.counters()["nodes_visited"] > 0
+
+
+def test_1m_direct_lighting_frame_against_the_oracle(pkg, oracle, soup1m, monkeypatch):
+    """A C3 frame (reduced resolution) rendered by every kernel flavour: the counting twin against the oracle (bit-exact film,
+    identical counters), then the timed flavours (3 waves/SIMD, 4 waves/SIMD, the queue pipeline) against the twin."""
+    ps, ds, (nodes, refs, bounds, info) = soup1m
+    ds.set_counting(True); ds.reset_counters(); ds.clear_film() if ds._film_bound else None
+    ds.render()
+    rgb, alpha = ds.film()
+    acc = ds.film_accum()
+    cnt = ds.counters()
+    orgb, oalpha, _, ocnt = oracle.render(ps, nodes, refs, bounds, info=info)
+    check_film("c3_1m", rgb, alpha, orgb, oalpha, ps.integrator)
+    for k in COUNTERS:
+        assert cnt[k] == ocnt[k], (k, cnt[k], ocnt[k])
+    assert cnt["stack_overflows"] > 0                  # the 12-entry ring does spill on this tree
+    for env in (dict(PBRT_HIP_HIGH_OCC="0"), dict(PBRT_HIP_HIGH_OCC="1"), dict(PBRT_HIP_PIPELINE="1"), dict(PBRT_HIP_PIPELINE="0")):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ds.set_counting(False); ds.clear_film(); ds.render()
+        assert np.array_equal(ds.film_accum(), acc), env
+        for k in env:
+            monkeypatch.delenv(k)
+    ds.set_counting(True)
+
+
+def test_c3_full_size_properties(pkg, scenes):
+    """BASELINE configs[2] at full size: 1 M triangles, DirectLighting, 1920x1080 @ 16 spp.  No oracle at this size:
+      coverage     every camera sample rendered exactly once (box filter, unjittered 4x4 strata: weight 16 per interior pixel);
+      determinism  two renders give the bit-identical film and counters;
+      sanity       no NaN / negative / infinite sample, alpha <= weight;
+      linearity    doubling the emitter's L doubles every radiance accumulator and changes no ray count."""
+    need_gpu(pkg)
+    kw = dict(xres=1920, yres=1080, integrator="directlighting", xsamples=4, ysamples=4, jitter=False, pixel_filter="box",
+              soup_tris=1_000_000, keyed=True)
+    ps = pkg.ParsedScene(text=scenes.cornell_scene(**kw))
+    assert ps.valid and ps.errors == 0
+    ds = pkg.DeviceScene(ps); ds.render(); a = ds.film_accum(); ca = ds.counters()
+    ds.reset_counters(); ds.clear_film(); ds.render(); a2 = ds.film_accum(); ca2 = ds.counters()
+    ds.set_counting(False); ds.clear_film(); ds.render(); a3 = ds.film_accum()       # the timed flavour the bench uses
+    ds.close()
+    assert ca["camera_rays"] == 1921 * 1081 * 16 and ca["bad_samples"] == 0 and ca == ca2
+    assert np.array_equal(a, a2) and np.array_equal(a, a3)
+    assert np.all(a[4][1:-1, 1:-1] == 16.0)
+    assert np.isfinite(a).all() and a[:3].min() >= 0 and np.all(a[3] <= a[4] + 1e-3)
+    assert ca["closest_rays"] >= ca["camera_rays"] and ca["any_rays"] > 0.2 * ca["camera_rays"]
+    ps2 = pkg.ParsedScene(text=scenes.cornell_scene(world_kwargs=dict(light_L=(34, 24, 8)), **kw))
+    ds2 = pkg.DeviceScene(ps2); ds2.render(); b = ds2.film_accum(); cb = ds2.counters(); ds2.close()
+    for k in COUNTERS:
+        assert cb[k] == ca[k], k
+    assert np.allclose(b[:3], 2 * a[:3], rtol=1e-5, atol=1e-5) and np.array_equal(b[4], a[4]) and np.array_equal(b[3], a[3])

@@ -53,6 +53,30 @@ def oracle_one_ulp_sensitivity(pkg, oracle, ps, accel=None):
     return film_metrics(b, a)
 
 
+# Cases that may take the "no worse than the reference algorithm's own one-ulp sensitivity" bar instead of the per-pixel one
+# (pbrt-v1's fixed RAY_EPSILON makes them ill-conditioned under ANY other libm).  Every case records which bar it
+# met in gpurun_out/parity_cases.json (also printed at the end of the session); a case NOT listed here that needs the
+# fallback fails, so a regression cannot hide behind it.
+FALLBACK_ALLOWED = {"sphere_path_soup", "quadrics_path", "mix:3", "mix:6", "mix:9", "mix:12"}
+_CASES = {}
+
+
+def record_case(name, metrics, fallback=False, sensitivity=None):
+    import json, os
+    _CASES[name] = dict(bar="one-ulp-sensitivity" if fallback else "per-pixel", frac=metrics.get("frac"), mean_l2=metrics.get("mean_l2"),
+                        maxabs=metrics.get("maxabs"), sensitivity=sensitivity)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_cases.json"), "w") as f:
+            json.dump(dict(fallback_allowed=sorted(FALLBACK_ALLOWED), fallback_used=sorted(k for k, v in _CASES.items() if v["bar"] != "per-pixel"),
+                           cases=_CASES), f, indent=1)
+    except OSError:
+        pass
+    if fallback:
+        assert name in FALLBACK_ALLOWED, "case %r needed the one-ulp-sensitivity bar but is not on the allow-list: %r" % (name, _CASES[name])
+
+
 def check_film(name, rgb, alpha, ref_rgb, ref_alpha, integrator, self_sensitivity=None):
     m = film_metrics(rgb, ref_rgb)
     if libm_bound(name, integrator):
@@ -60,10 +84,14 @@ def check_film(name, rgb, alpha, ref_rgb, ref_alpha, integrator, self_sensitivit
             s = self_sensitivity() if self_sensitivity else None
             assert s is not None and s["frac"] < 0.995, (name, m, s)          # only an ill-conditioned scene may miss the bar
             assert m["frac"] >= s["frac"] - 0.02 and m["mean_l2"] <= 2 * s["mean_l2"] + 1e-5, (name, m, s)
+            record_case(name, m, True, s)
+        else:
+            record_case(name, m)
         assert (np.abs(alpha - ref_alpha) > 1e-5).mean() <= 0.005, name
     else:
         assert m["maxabs"] <= 1e-5, (name, m)
         assert np.abs(alpha - ref_alpha).max() <= 1e-5, name
+        record_case(name, m)
     return m
 
 
@@ -338,7 +366,9 @@ def test_randomized_feature_mixes_against_the_oracle(pkg, scenes, oracle, k):
     orgb, oalpha, _, ocnt = oracle.render(ps, nodes, refs, bounds, info=info)
     assert cnt["camera_rays"] == ocnt["camera_rays"] and cnt["bad_samples"] == ocnt["bad_samples"]
     m = film_metrics(rgb, orgb)
-    if not (m["frac"] >= 0.99 and m["mean_l2"] < 2e-4):
+    if m["frac"] >= 0.99 and m["mean_l2"] < 2e-4:
+        record_case("mix:%d" % k, m)
+    else:
         # an ill-conditioned mix (see oracle_one_ulp_sensitivity): pixels cannot be compared one by one under another libm.  The
         # device must then be about as far from the oracle as the oracle is from its one-ulp twin (the device differs in every
         # libm function, the twin only in one cosf) and must carry the same energy.
@@ -346,6 +376,7 @@ def test_randomized_feature_mixes_against_the_oracle(pkg, scenes, oracle, k):
         assert s["frac"] < 0.995, (k, m, s)
         assert m["frac"] >= 0.75 * s["frac"] - 0.02, (k, m, s)
         assert abs(float(rgb.mean()) - float(orgb.mean())) <= 0.05 * float(orgb.mean()) + 1e-3, (k, float(rgb.mean()), float(orgb.mean()))
+        record_case("mix:%d" % k, m, True, s)
 
 
 def test_film_into_caller_buffers(pkg, scenes):
