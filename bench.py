@@ -176,11 +176,11 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    kern_ms = []
+    stats = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        kern_ms.append(ds.last_ms()[1])     # HIP events around the render kernel on its stream
+        stats.append(ds.last_stats())       # HIP events around the kernels on their stream
     fence()
     elapsed = time.perf_counter() - t0
     rays_local = cnt["closest_rays"] + cnt["any_rays"]
@@ -194,7 +194,9 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        k_ms = float(np.mean(kern_ms))
+        # the dominant kernel: rt::render_kernel (megakernel, small scenes) or the rt::pipe_trace_kernel launches of the queue pipeline
+        k_ms = float(np.mean([st["trace_ms"] for st in stats]))
+        pipeline = bool(stats[-1]["pipeline"])
         alg_bytes = 8 * cnt["nodes_visited"] + 4 * cnt["leaf_refs"] + 48 * cnt["tri_tests"] + 48 * rays_local
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         out = {
@@ -216,7 +218,12 @@ def main():
                        "rng": "counter-based keyed RNG, seed 0"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 5), "traffic": None,
-                         "kernel": "rt::render_kernel<COUNT=false,...> (persistent wavefront renderer)", "kernel_ms": round(k_ms, 3),
+                         "kernel": ("rt::pipe_trace_kernel<COUNT=false,...> (persistent trace waves of the queue pipeline; all %d launches of a frame summed)" % stats[-1]["iterations"])
+                                   if pipeline else "rt::render_kernel<COUNT=false,...> (persistent megakernel)",
+                         "kernel_ms": round(k_ms, 3),
+                         "frame_kernels_ms": {"render": round(float(np.mean([st["render_ms"] for st in stats])), 3),
+                                              "film_gather": round(float(np.mean([st["gather_ms"] for st in stats])), 3)},
+                         "pipeline_iterations": int(stats[-1]["iterations"]), "pipeline_slots": int(stats[-1]["slots"]),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "bytes_per_ray": round(alg_bytes / max(rays_local, 1), 1),
                          "nodes_per_ray": round(cnt["nodes_visited"] / max(rays_local, 1), 2),

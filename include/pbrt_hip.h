@@ -243,6 +243,16 @@ int rt_set_counting(RtScene *s, int enabled);
 /* elapsed GPU milliseconds of the last rt_render launch sequence (HIP events on the
  * handle's stream) and of its dominant kernel */
 int rt_last_render_ms(RtScene *s, float *total_ms, float *kernel_ms);
+/* The same by kernel.  Small, cache-resident scenes render with one persistent megakernel (pipeline = 0: trace_ms == render_ms);
+ * large ones with the queue pipeline (pipeline = 1): `iterations` alternations of the shade kernel (SurfaceIntegrator::Li between
+ * two rays, for every path slot) and the trace kernel (KdTreeAccel::Intersect / IntersectP for the queued rays); trace_ms is the
+ * sum over the first `timed_iterations` trace launches (all of them unless a frame needs more than 256). */
+typedef struct RtRenderStats {
+    float total_ms, render_ms, trace_ms, gather_ms;
+    int32_t pipeline, iterations, timed_iterations;
+    uint32_t slots;
+} RtRenderStats;
+int rt_last_render_stats(RtScene *s, RtRenderStats *out);
 
 #ifdef __cplusplus
 }

@@ -26,12 +26,21 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-msse2", "-mfpmath=sse"]
 
 
-def build(force: bool = False, verbose: bool = False) -> None:
-    """Compile both shared libraries in-tree (hipcc cross-compiles gfx950 without a GPU)."""
+HIP_UNITS = ("rt_kernels.hip", "rt_trace.hip", "rt_mega_w.hip", "rt_mega_d.hip", "rt_mega_p.hip", "rt_pipe_w.hip", "rt_pipe_d.hip",
+             "rt_pipe_p.hip", "kd_build.cpp", "grid_build.cpp")
+
+
+def build(force: bool = False, verbose: bool = False, defines=(), jobs: int | None = None) -> None:
+    """Compile both shared libraries in-tree (hipcc cross-compiles gfx950 without a GPU).  The HIP library is ten translation
+    units (the megakernel and the pipeline's shade kernel per integrator, the trace kernel, the C ABI, the two host builders)
+    compiled in parallel and linked; `defines` (-D knobs for tools/perf_sweep.py) force a rebuild into the same place."""
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIB_DIR, exist_ok=True)
-    hip_src = [os.path.join(CSRC, "hip", f) for f in ("rt_kernels.hip", "kd_build.cpp", "grid_build.cpp")]
-    hip_dep = [os.path.join(CSRC, "hip", f) for f in os.listdir(os.path.join(CSRC, "hip"))] + \
-              [os.path.join(_HERE, "..", "include", "pbrt_hip.h")]
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    hip_dir = os.path.join(CSRC, "hip")
+    hip_dep = [os.path.join(hip_dir, f) for f in os.listdir(hip_dir)] + [os.path.join(_HERE, "..", "include", "pbrt_hip.h")]
+    headers = [d for d in hip_dep if d.endswith((".h", ".inc"))]
     host_src = [os.path.join(CSRC, "host", "scene_api.cpp")]
     host_dep = [os.path.join(CSRC, "host", f) for f in os.listdir(os.path.join(CSRC, "host"))] + \
                [os.path.join(_HERE, "..", "include", "pbrt_hip.h")]
@@ -39,8 +48,26 @@ def build(force: bool = False, verbose: bool = False) -> None:
     def stale(out, deps):
         return force or not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
 
-    if stale(HIP_LIB, hip_dep):
-        cmd = ["hipcc"] + HIPCC_FLAGS + hip_src + ["-o", HIP_LIB]
+    stamp = os.path.join(obj_dir, "defines.txt")
+    dtext = " ".join(defines)
+    if (open(stamp).read() if os.path.exists(stamp) else "") != dtext:
+        force = True
+    todo = []
+    for u in HIP_UNITS:
+        obj = os.path.join(obj_dir, u.rsplit(".", 1)[0] + ".o")
+        if stale(obj, [os.path.join(hip_dir, u)] + headers):
+            todo.append(["hipcc"] + [f for f in HIPCC_FLAGS if f != "-shared"] + list(defines) + ["-c", os.path.join(hip_dir, u), "-o", obj])
+    if todo:
+        def run(cmd):
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        with ThreadPoolExecutor(max_workers=jobs or min(len(todo), os.cpu_count() or 4)) as ex:
+            list(ex.map(run, todo))
+        open(stamp, "w").write(dtext)
+    objs = [os.path.join(obj_dir, u.rsplit(".", 1)[0] + ".o") for u in HIP_UNITS]
+    if stale(HIP_LIB, objs):
+        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", HIP_LIB]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
@@ -66,6 +93,14 @@ class RtAccelInfo(C.Structure):
                 ("grid_nvoxels", C.c_int32 * 3), ("grid_width", C.c_float * 3), ("grid_inv_width", C.c_float * 3)]
 
 
+class RtRenderStats(C.Structure):
+    _fields_ = [("total_ms", C.c_float), ("render_ms", C.c_float), ("trace_ms", C.c_float), ("gather_ms", C.c_float),
+                ("pipeline", C.c_int32), ("iterations", C.c_int32), ("timed_iterations", C.c_int32), ("slots", C.c_uint32)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 RAY_DTYPE = np.dtype([("o", np.float32, 3), ("d", np.float32, 3), ("mint", np.float32), ("maxt", np.float32)])
 HIT_DTYPE = np.dtype([("prim", np.int32), ("t", np.float32), ("b1", np.float32), ("b2", np.float32)])
 
@@ -83,7 +118,7 @@ def hip_lib():
         for name in ("rt_scene_create", "rt_scene_destroy", "rt_scene_set_stream", "rt_scene_accel_info",
                      "rt_scene_accel_copy", "rt_camera_rays", "rt_trace_closest", "rt_trace_any", "rt_film_bind",
                      "rt_film_clear", "rt_film_read", "rt_film_resolve", "rt_render", "rt_sync", "rt_counters",
-                     "rt_counters_reset", "rt_last_render_ms", "rt_device_count", "rt_set_counting",
+                     "rt_counters_reset", "rt_last_render_ms", "rt_last_render_stats", "rt_device_count", "rt_set_counting",
                      "rt_kdtree_build", "rt_kdtree_info", "rt_kdtree_copy", "rt_kdtree_destroy",
                      "rt_accel_build", "rt_accel_info", "rt_accel_copy", "rt_accel_destroy"):
             getattr(L, name).restype = C.c_int
@@ -104,6 +139,7 @@ def hip_lib():
         L.rt_counters.argtypes = [C.c_void_p, C.POINTER(RtCounters)]
         L.rt_counters_reset.argtypes = [C.c_void_p]
         L.rt_last_render_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.rt_last_render_stats.argtypes = [C.c_void_p, C.POINTER(RtRenderStats)]
         L.rt_device_count.argtypes = [C.POINTER(C.c_int)]
         L.rt_set_counting.argtypes = [C.c_void_p, C.c_int]
         L.rt_kdtree_build.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p)]
@@ -372,6 +408,11 @@ class DeviceScene:
         a, b = C.c_float(0), C.c_float(0)
         _chk(hip_lib().rt_last_render_ms(self._s, C.byref(a), C.byref(b)))
         return float(a.value), float(b.value)
+
+    def last_stats(self) -> dict:
+        st = RtRenderStats()
+        _chk(hip_lib().rt_last_render_stats(self._s, C.byref(st)))
+        return st.as_dict()
 
     def camera_rays(self, first: int, count: int) -> np.ndarray:
         rays = np.zeros(count, RAY_DTYPE)

@@ -86,6 +86,7 @@ struct DevFrame {
     int phase_sync;             // path integrator: alternate the two halves of the state machine between sweeps (rt_integrate.h)
     int high_occupancy;          // host-side choice of the 5-waves/SIMD kernel flavour (not read by the device)
     int trav_mode;               // 0 = one node per lane per round, 1 = lock-step (descend all, then test), 2 = batched
+    int pipeline;                // host-side choice: the queue pipeline (rt_pipeline.h) instead of the megakernel (not read by the device)
     unsigned long long total_work;     // samples this shard renders
     unsigned long long total_pixels;   // pixels in the sample extent
     // sampler dimension table (Sample::oneD/twoD, sampling.cpp:41-70)

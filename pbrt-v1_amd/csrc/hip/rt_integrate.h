@@ -296,9 +296,12 @@ RT_DEV int frame_pop(const DevFrame &fr, Lane &ln, unsigned gtid, V3 child) {
     return after;
 }
 
+// DEFER (queue pipeline, rt_pipeline.h): the ray is only recorded; the trace kernel starts the traversal
+template <bool DEFER = false>
 RT_DEV void launch_ray(Lane &ln, const DevScene &sc, V3 o, V3 d, float mint, float maxt, bool any, int next_stage) {
     Ray r; r.o = o; r.d = d; r.mint = mint; r.maxt = maxt;
-    if (sc.accel_kind == RT_ACCEL_GRID) grid_begin(ln.tv, sc, r, any); else trav_begin(ln.tv, sc, r, any);
+    if (DEFER) { ln.tv.o = o; ln.tv.d = d; ln.tv.mint = mint; ln.tv.maxt = maxt; ln.tv.any = any; ln.tv.hit_prim = -1; ln.tv.b1 = 0.f; ln.tv.b2 = 0.f; }
+    else if (sc.accel_kind == RT_ACCEL_GRID) grid_begin(ln.tv, sc, r, any); else trav_begin(ln.tv, sc, r, any);
     ln.has_ray = true;
     ln.stage = next_stage;
 }
@@ -354,7 +357,7 @@ RT_DEV V3 scene_transmittance(const DevScene &sc, Lane &ln, V3 o, V3 d, float mi
 
 // ---- EstimateDirect (core/transport.cpp:123-194), split at its two ray casts ------------------------------
 // BSDF-sampling half; returns with either a MIS ray in flight (ST_MIS_DONE) or ST_ED_DONE.
-template <bool EXT>
+template <bool EXT, bool DEFER = false>
 RT_DEV void estimate_direct_bsdf(const DevScene &sc, Lane &ln) {
     LightRef Lt = RT_LIGHT(sc, ln.cur_light);
     ln.stage = ST_ED_DONE;
@@ -369,13 +372,13 @@ RT_DEV void estimate_direct_bsdf(const DevScene &sc, Lane &ln) {
             float weight = (fw * fw) / (fw * fw + gw * gw);
             // Li is Lemit iff the closest hit is this emitter seen from its front side; decided after the trace
             ln.pend = div_s(((f * mat_color(Lt.color)) * absdot3(wi, ln.v.nn)) * weight, bsdfPdf);
-            launch_ray(ln, sc, ln.v.p, wi, RT_RAY_EPSILON, RT_INF, false, ST_MIS_DONE);
+            launch_ray<DEFER>(ln, sc, ln.v.p, wi, RT_RAY_EPSILON, RT_INF, false, ST_MIS_DONE);
         }
     }
 }
 
 // light-sampling half
-template <bool EXT>
+template <bool EXT, bool DEFER = false>
 RT_DEV void estimate_direct_begin(const DevScene &sc, Lane &ln, int light, float ls1, float ls2) {
     ln.cur_light = light;
     ln.Ld = mk3(0.f);
@@ -404,7 +407,7 @@ RT_DEV void estimate_direct_begin(const DevScene &sc, Lane &ln, int light, float
                 ln.pend = div_s(((f * Li) * absdot3(wi, ln.v.nn)) * weight, lightPdf);
             }
             // VisibilityTester::SetSegment / SetRay light.h:78-83
-            launch_ray(ln, sc, ln.v.p, sd, RT_RAY_EPSILON, smax, true, ST_SHADOW_DONE);
+            launch_ray<DEFER>(ln, sc, ln.v.p, sd, RT_RAY_EPSILON, smax, true, ST_SHADOW_DONE);
             return;
         }
     }
@@ -412,7 +415,7 @@ RT_DEV void estimate_direct_begin(const DevScene &sc, Lane &ln, int light, float
 }
 
 // The body of ONE stage.  Returns when the lane has a ray in flight or has changed stage.
-template <bool COUNT, int INTEG, bool VOL, bool EXT, int STAGE>
+template <bool COUNT, int INTEG, bool VOL, bool EXT, int STAGE, bool DEFER = false>
 RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigned gtid,
                        unsigned *c_closest, unsigned *c_any, unsigned *c_bad) {
     if constexpr (STAGE == ST_VERTEX) {
@@ -471,7 +474,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
                 ln.bs1 = ln.rng.next_float(); ln.bs2 = ln.rng.next_float(); ln.bcs = ln.rng.next_float();
             }
             int lightNum = min(int(floorf(un * nLights)), nLights - 1);
-            estimate_direct_begin<EXT>(sc, ln, lightNum, ls1, ls2);
+            estimate_direct_begin<EXT, DEFER>(sc, ln, lightNum, ls1, ls2);
             return;
         }
         if (INTEG == RT_INTEGRATOR_DIRECT) {
@@ -482,7 +485,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
             const float ls1 = dim_value(fr, ln, rl, ln.lj, 0), ls2 = dim_value(fr, ln, rl, ln.lj, 1);
             ln.bs1 = dim_value(fr, ln, rb, ln.lj, 0); ln.bs2 = dim_value(fr, ln, rb, ln.lj, 1);
             ln.bcs = dim_value(fr, ln, rc, ln.lj, 0);
-            estimate_direct_begin<EXT>(sc, ln, ln.li, ls1, ls2);
+            estimate_direct_begin<EXT, DEFER>(sc, ln, ln.li, ls1, ls2);
             return;
         }
         // Whitted: one sample per light, unweighted (whitted.cpp:73-81)
@@ -507,7 +510,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
             V3 f = bsdf_f<EXT>(m, ln.v, ln.v.wo, wi);
             if (is_black(f)) return;
             ln.pend = (f * Li) * absdot3(wi, ln.v.nn);
-            launch_ray(ln, sc, ln.v.p, sd, RT_RAY_EPSILON, smax, true, ST_SHADOW_DONE);
+            launch_ray<DEFER>(ln, sc, ln.v.p, sd, RT_RAY_EPSILON, smax, true, ST_SHADOW_DONE);
         }
         return;
     }
@@ -524,7 +527,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
         return;
     }
     if constexpr (STAGE == ST_ED_BSDF) {
-        estimate_direct_bsdf<EXT>(sc, ln);
+        estimate_direct_bsdf<EXT, DEFER>(sc, ln);
         return;
     }
     if constexpr (STAGE == ST_MIS_DONE) {
@@ -578,7 +581,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
         }
         if (k == fr.max_depth) { ln.stage = ST_RETURN; return; }
         ++ln.depth;
-        launch_ray(ln, sc, ln.v.p, wi, RT_RAY_EPSILON, RT_INF, false, ST_VERTEX);
+        launch_ray<DEFER>(ln, sc, ln.v.p, wi, RT_RAY_EPSILON, RT_INF, false, ST_VERTEX);
         return;
     }
     if constexpr (STAGE == ST_SPECULAR) {                                                         // whitted.cpp:82-109
@@ -592,7 +595,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
         if (!is_black(f) && ad > 0.f) {
             frame_push(fr, ln, gtid, f, ad, ST_SPEC_TRANS);
             ++ln.depth;
-            launch_ray(ln, sc, ln.v.p, wi, RT_RAY_EPSILON, RT_INF, false, ST_VERTEX);
+            launch_ray<DEFER>(ln, sc, ln.v.p, wi, RT_RAY_EPSILON, RT_INF, false, ST_VERTEX);
             if (VOL) { Ray cr; cr.o = ln.v.p; cr.d = wi; cr.mint = RT_RAY_EPSILON; cr.maxt = RT_INF; vol_store_ray(fr, ln.fsp, gtid, cr); }
             return;
         }
@@ -609,7 +612,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
         if (!is_black(f) && ad > 0.f) {
             frame_push(fr, ln, gtid, f, ad, ST_RETURN);
             ++ln.depth;
-            launch_ray(ln, sc, ln.v.p, wi, RT_RAY_EPSILON, RT_INF, false, ST_VERTEX);
+            launch_ray<DEFER>(ln, sc, ln.v.p, wi, RT_RAY_EPSILON, RT_INF, false, ST_VERTEX);
             if (VOL) { Ray cr; cr.o = ln.v.p; cr.d = wi; cr.mint = RT_RAY_EPSILON; cr.maxt = RT_INF; vol_store_ray(fr, ln.fsp, gtid, cr); }
             return;
         }
@@ -690,7 +693,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
                         vs[0] = __int_as_float(i); vs[st] = __int_as_float(N); vs[2 * st] = t0; vs[3 * st] = step;
                         vs[4 * st] = Tr.x; vs[5 * st] = Tr.y; vs[6 * st] = Tr.z; vs[7 * st] = p.x; vs[8 * st] = p.y; vs[9 * st] = p.z;
                         vs[10 * st] = Lv.x; vs[11 * st] = Lv.y; vs[12 * st] = Lv.z;
-                        launch_ray(ln, sc, p, sd, RT_RAY_EPSILON, smax, true, ST_VOL_STEP);
+                        launch_ray<DEFER>(ln, sc, p, sd, RT_RAY_EPSILON, smax, true, ST_VOL_STEP);
                         return;
                     }
                 }
@@ -736,15 +739,15 @@ RT_DEV bool stage_in_phase(int stage, int phase) {
     const bool first = stage == ST_VERTEX || stage == ST_DIRECT_NEXT;
     return phase == 0 ? first : !first;
 }
-template <bool COUNT, int INTEG, bool VOL, bool EXT>
+template <bool COUNT, int INTEG, bool VOL, bool EXT, bool DEFER = false>
 RT_DEV void advance_pass(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigned gtid,
                          unsigned *c_closest, unsigned *c_any, unsigned *c_bad, int phase) {
 #ifdef RT_PROFILE_STAGES
 #define RT_RUN(S) { const unsigned long long m_ = __ballot(!ln.has_ray && ln.stage == S); if (m_) { const unsigned long long t_ = __builtin_readcyclecounter(); \
-        if (!ln.has_ray && ln.stage == S) stage_body<COUNT, INTEG, VOL, EXT, S>(sc, fr, ln, gtid, c_closest, c_any, c_bad); \
+        if (!ln.has_ray && ln.stage == S) stage_body<COUNT, INTEG, VOL, EXT, S, DEFER>(sc, fr, ln, gtid, c_closest, c_any, c_bad); \
         if (__lane_id() == 0) { atomicAdd(&g_pf_stage[2 * S], __builtin_readcyclecounter() - t_); atomicAdd(&g_pf_stage[2 * S + 1], (unsigned long long)__popcll(m_) | (1ull << 40)); } } }
 #else
-#define RT_RUN(S) if (!ln.has_ray && ln.stage == S) stage_body<COUNT, INTEG, VOL, EXT, S>(sc, fr, ln, gtid, c_closest, c_any, c_bad)
+#define RT_RUN(S) if (!ln.has_ray && ln.stage == S) stage_body<COUNT, INTEG, VOL, EXT, S, DEFER>(sc, fr, ln, gtid, c_closest, c_any, c_bad)
 #endif
     if (phase != 0) {
         RT_RUN(ST_MIS_DONE);

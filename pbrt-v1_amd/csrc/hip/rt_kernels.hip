@@ -7,10 +7,12 @@
 //                   bounce, MIS closest-hit, shadow any-hit); finished lanes refill from a global work
 //                   counter with one wave-aggregated atomic.  No MFMA: the work is pointer chasing and
 //                   3-vector arithmetic, bounded by HBM/L2 latency and bandwidth, not by dense math.
-//   trace_kernel    Scene::Intersect / IntersectP for caller-supplied rays (unit parity entry points).
+//   (rt_pipeline.h) pipe_shade_kernel / pipe_trace_kernel: the queue pipeline used for large scenes; rt_trace_closest / rt_trace_any
+//                   (unit parity entry points) run caller-supplied rays through the same pipe_trace_kernel.
 //   camera_kernel   Sampler + Camera::GenerateRay only.
 // Compile: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (parity with the reference's non-FMA build).
-#include "rt_integrate.h"
+#include "rt_render_kernel.h"
+#include "rt_pipeline.h"
 #include "rt_internal.h"
 #include <cstdio>
 #include <cstdlib>
@@ -20,132 +22,6 @@
 #include <cmath>
 
 namespace rt {
-
-// ------------------------------------------------------------------------------------------ kernels
-#ifndef RT_MIN_WAVES
-#define RT_MIN_WAVES 1
-#endif
-// waves per SIMD of the high-occupancy flavour: 4 = 128 VGPRs.  5 (96 VGPRs) was marginally faster at one point but its
-// spill placement swings with every code change (measured 108 -> 153 ms on the 1 M-triangle path frame for the same
-// algorithm); 4 is stable: 101 ms there, 138 ms on the 100 k soup.
-#ifndef RT_HIGH_OCC_WAVES
-#define RT_HIGH_OCC_WAVES 4
-#endif
-#ifndef RT_EXIT_THRESH
-#define RT_EXIT_THRESH 0
-#endif
-#ifndef RT_LOCKSTEP
-#define RT_LOCKSTEP 1
-#endif
-// Scene and frame descriptors are read through pointers (uniform addresses -> scalar loads on demand) instead of
-// being passed by value: the by-value form pinned >100 SGPRs and spilled them.
-// MINW = minimum waves per SIMD the register allocator must make room for: 1 = natural allocation (~160 VGPRs, 3 waves/SIMD,
-// best when VALU-bound: tiny cache-resident scenes); RT_HIGH_OCC_WAVES = 4 caps at 128 VGPRs (some spills to scratch) for
-// 4 waves/SIMD: +20 % on the memory-latency-bound 100k..1M-triangle scenes, -15 % on Cornell.
-template <bool COUNT, int INTEG, int ACCEL, bool VOL, int MINW, bool EXT>
-__global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *__restrict__ scp,
-                                                                       const DevFrame *__restrict__ frp) {
-    __shared__ uint2 lds_stack[RT_STACK_LDS * RT_BLOCK];
-    constexpr bool POOL = MINW < RT_HIGH_OCC_WAVES;                       // the pooled-leaf scratch (19 KB) is only carried by the kernels that use it
-    constexpr int PN = POOL ? RT_BLOCK : 64;
-    __shared__ unsigned long long pool_key[PN];
-    __shared__ float4 pool_res[PN];
-    __shared__ unsigned pool_head[PN];
-    __shared__ float4 pool_ray[3 * PN];
-    const DevScene &sc = *scp;
-    const DevFrame &fr = *frp;
-    const unsigned wave0 = POOL ? (threadIdx.x & ~63u) : 0u;
-    const PoolLds pool = {(unsigned long long RT_L *)pool_key + wave0, (float4 RT_L *)pool_res + wave0, (unsigned RT_L *)pool_head + wave0,
-                          (float4 RT_L *)pool_ray + 3 * wave0};
-    const unsigned gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    Lane ln;
-    ln.stage = ST_FETCH; ln.has_ray = false; ln.fsp = 0; ln.tv.active = false; ln.tv.hit_prim = -1;
-    ln.L = mk3(0.f); ln.thr = mk3(1.f); ln.alpha = 0.f; ln.depth = 0; ln.specular = false;
-    TravCounters tc; tc.nodes = tc.leaf_refs = tc.tris = tc.spills = 0;
-    RT_PFT(tc.c_desc = tc.c_leaf = tc.n_chunks = tc.n_pooled = tc.n_iter = 0;)
-    unsigned c_cam = 0, c_closest = 0, c_any = 0, c_bad = 0;
-
-#ifdef RT_PROFILE
-    unsigned long long pf_shade = 0, pf_trav = 0, pf_outer = 0, pf_inner = 0, pf_rounds = 0, pf_act = 0, pf_rays = 0, pf_t0 = 0;
-#define RT_PF(x) x
-#else
-#define RT_PF(x)
-#endif
-    // phase gating (rt_integrate.h, stage_in_phase): sweeps alternate between the two halves of the path state machine;
-    // the first sweep is of the second kind (it contains the work fetch)
-    int phase = (INTEG == RT_INTEGRATOR_PATH && fr.phase_sync) ? 1 : -1;
-    for (;;) {
-        RT_PF(pf_t0 = __builtin_readcyclecounter(); ++pf_outer;)
-        // ---- shade / regenerate: run every lane that is not waiting on a ray until it is (or is out of work)
-        do {
-            RT_PF(++pf_inner;)
-            advance_pass<COUNT, INTEG, VOL, EXT>(sc, fr, ln, gtid, &c_closest, &c_any, &c_bad, phase);
-            const unsigned long long want = phase == 0 ? 0ull : __ballot(!ln.has_ray && ln.stage == ST_FETCH);
-            if (want) {                                                   // wave-aggregated work fetch
-                const int leader = __ffsll((long long)want) - 1;
-                unsigned long long base = 0;
-                if (lane == leader) base = atomicAdd(fr.work_counter, (unsigned long long)__popcll(want));
-                base = __shfl(base, leader);
-                if (!ln.has_ray && ln.stage == ST_FETCH) {
-                    const unsigned long long w = base + __popcll(want & ((1ull << lane) - 1ull));
-                    if (w >= fr.total_work) ln.stage = ST_EXIT;
-                    else {
-                        unsigned long long pixel; int s;
-                        if (work_to_sample(fr, w, pixel, s)) {
-                            Ray ray;
-                            setup_sample(sc, fr, ln, pixel, s, ray);
-                            ln.work = uint32_t(w);
-                            ln.L = mk3(0.f); ln.thr = mk3(1.f); ln.alpha = 0.f; ln.depth = 0; ln.fsp = 0;
-                            ln.specular = false;
-                            if (COUNT) ++c_cam;
-                            accel_begin<ACCEL>(ln.tv, sc, ray, false);
-                            if (VOL) vol_store_ray(fr, 0, gtid, ray);
-                            ln.has_ray = true; ln.stage = ST_VERTEX;
-                        }
-                    }
-                }
-            }
-        } while (__any(!ln.has_ray && stage_in_phase(ln.stage, phase)));
-        if (phase >= 0) phase ^= 1;
-        RT_PF({ unsigned long long t1 = __builtin_readcyclecounter(); pf_shade += t1 - pf_t0; pf_t0 = t1; pf_rays += __popcll(__ballot(ln.has_ray && ln.tv.active)); })
-        if (!__any(ln.has_ray)) {
-            if (!__any(ln.stage != ST_EXIT)) break;
-            continue;                                                     // everybody waits for the other kind of sweep
-        }
-        // ---- extend: one shared traversal loop.  Leave it early when only a few lanes are still traversing AND some
-        // lane could meanwhile shade / fetch (its traversal state stays in registers + LDS and resumes next round).
-        for (;;) {
-            const bool act = ln.has_ray && ln.tv.active;
-            const unsigned long long am = __ballot(act);
-            if (!am) break;
-            RT_PF(++pf_rounds; pf_act += __popcll(am);)
-            if (fr.exit_thresh > 0 && __popcll(am) <= fr.exit_thresh && __any(!act && ln.stage != ST_EXIT)) break;
-            if (fr.trav_mode == 1) accel_round<COUNT, ACCEL, EXT>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc);
-            else if (fr.trav_mode == 2) accel_round_batched<COUNT, ACCEL, EXT>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc);
-            else if (POOL && fr.trav_mode == 3) accel_round_pooled<COUNT, ACCEL, EXT>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc, pool);
-            else if (act) accel_step<COUNT, ACCEL, EXT>(ln.tv, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc);
-        }
-        if (ln.has_ray && !ln.tv.active) ln.has_ray = false;
-        RT_PF(pf_trav += __builtin_readcyclecounter() - pf_t0;)
-    }
-#ifdef RT_PROFILE
-    if (lane == 0) {
-        unsigned long long v[12] = {pf_shade, pf_trav, pf_outer, pf_inner, pf_rounds, pf_act, pf_rays, tc.c_desc, tc.c_leaf, tc.n_chunks, tc.n_pooled, tc.n_iter};
-        for (int k = 0; k < 12; ++k) atomicAdd(fr.counters + 8 + k, v[k]);
-    }
-#endif
-
-    if (COUNT) {
-        unsigned long long v[8] = {c_cam, c_closest, c_any, tc.nodes, tc.leaf_refs, tc.tris, c_bad, tc.spills};
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            unsigned long long x = v[k];
-            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
-            if (lane == 0 && x) atomicAdd(fr.counters + k, x);
-        }
-    }
-}
 
 // ImageFilm::AddSample (film/image.cpp:103-142) as a gather: one thread per film pixel visits, in the reference's
 // sample order (sample-pixel rows, then columns, then sample-in-pixel), every sample of this shard whose filter
@@ -309,29 +185,6 @@ __global__ void film_resolve_kernel(const float *__restrict__ accum, size_t n, i
     rgb[3 * i] = r; rgb[3 * i + 1] = g; rgb[3 * i + 2] = b; alpha[i] = a;
 }
 
-__global__ __launch_bounds__(RT_BLOCK) void trace_kernel(DevScene sc, const RtRay *rays, unsigned n, int any,
-                                                         RtHit *hits, unsigned char *occ, uint2 *spill,
-                                                         unsigned n_threads, unsigned long long *counters) {
-    __shared__ uint2 lds_stack[RT_STACK_LDS * RT_BLOCK];
-    const unsigned gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
-    TravCounters tc; tc.nodes = tc.leaf_refs = tc.tris = tc.spills = 0;
-    for (unsigned i = gtid; i < n; i += n_threads) {
-        Ray r; r.o = mk3(rays[i].o[0], rays[i].o[1], rays[i].o[2]); r.d = mk3(rays[i].d[0], rays[i].d[1], rays[i].d[2]);
-        r.mint = rays[i].mint; r.maxt = rays[i].maxt;
-        Trav tv;
-        if (sc.accel_kind == RT_ACCEL_GRID) { grid_begin(tv, sc, r, any != 0); while (tv.active) grid_step<true, true>(tv, sc, tc); }
-        else { trav_begin(tv, sc, r, any != 0); while (tv.active) trav_step<true, true>(tv, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, spill), n_threads, gtid, tc); }
-        if (any) occ[i] = tv.hit_prim >= 0 ? 1 : 0;
-        else { hits[i].prim = tv.hit_prim; hits[i].t = tv.hit_prim >= 0 ? tv.maxt : 0.f; hits[i].b1 = tv.b1; hits[i].b2 = tv.b2; }
-    }
-    if (counters) {
-        atomicAdd(counters + 3, (unsigned long long)tc.nodes);
-        atomicAdd(counters + 4, (unsigned long long)tc.leaf_refs);
-        atomicAdd(counters + 5, (unsigned long long)tc.tris);
-        atomicAdd(counters + 7, (unsigned long long)tc.spills);
-    }
-}
-
 __global__ void camera_kernel(DevScene sc, DevFrame fr, unsigned long long first, unsigned count, RtRay *out) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -348,22 +201,17 @@ __global__ void camera_kernel(DevScene sc, DevFrame fr, unsigned long long first
 // ------------------------------------------------------------------------------------------ host side
 using namespace rt;
 
-// render_kernel instantiations, index = ((VOL*2 + ACCEL)*2 + COUNT)*3 + INTEG; +24..35: the high-occupancy flavour
-// (COUNT = false only), index = 24 + (VOL*2 + ACCEL)*3 + INTEG; +36..47: timed kernels with the glossy (plastic) lobes compiled
-// in, index = 36 + (VOL*2 + ACCEL)*3 + INTEG.  The counting twins always carry the glossy code (they are not timed); the
-// common timed kernels do not: powf and the second lobe cost ~17 VGPRs (path 150 -> 167, direct 176: one wave per SIMD less).
-typedef void (*RenderKernelFn)(const DevScene *, const DevFrame *);
-#define RT_K3(C, A, V, W, G) render_kernel<C, 0, A, V, W, G>, render_kernel<C, 1, A, V, W, G>, render_kernel<C, 2, A, V, W, G>
-static const RenderKernelFn g_render_kernels[48] = {
-    RT_K3(false, 0, false, RT_MIN_WAVES, false), RT_K3(true, 0, false, RT_MIN_WAVES, true), RT_K3(false, 1, false, RT_MIN_WAVES, false),
-    RT_K3(true, 1, false, RT_MIN_WAVES, true),
-    RT_K3(false, 0, true, RT_MIN_WAVES, false),  RT_K3(true, 0, true, RT_MIN_WAVES, true),  RT_K3(false, 1, true, RT_MIN_WAVES, false),
-    RT_K3(true, 1, true, RT_MIN_WAVES, true),
-    RT_K3(false, 0, false, RT_HIGH_OCC_WAVES, false), RT_K3(false, 1, false, RT_HIGH_OCC_WAVES, false), RT_K3(false, 0, true, RT_HIGH_OCC_WAVES, false),
-    RT_K3(false, 1, true, RT_HIGH_OCC_WAVES, false),
-    RT_K3(false, 0, false, RT_MIN_WAVES, true), RT_K3(false, 1, false, RT_MIN_WAVES, true), RT_K3(false, 0, true, RT_MIN_WAVES, true),
-    RT_K3(false, 1, true, RT_MIN_WAVES, true)};
-#undef RT_K3
+// render_kernel instantiations live in rt_mega_{w,d,p}.hip, 16 per integrator: k = (VOL*2 + ACCEL)*2 + COUNT for the natural-allocation
+// kernels (0..7; the counting twins always carry the glossy / quadric code, they are not timed), 8 + VOL*2 + ACCEL for the
+// high-occupancy flavour, 12 + VOL*2 + ACCEL for the timed kernels with the glossy (plastic) lobes and quadric slots compiled in
+// (EXT: powf and the second lobe cost ~17 VGPRs, one wave per SIMD less for DirectLighting).  `variant` keeps round 1's numbering:
+// ((VOL*2 + ACCEL)*2 + COUNT)*3 + INTEG | 24 + (VOL*2 + ACCEL)*3 + INTEG | 36 + (VOL*2 + ACCEL)*3 + INTEG.
+namespace rt { extern const RenderKernelFn g_render_kernels_whitted[16], g_render_kernels_direct[16], g_render_kernels_path[16]; }
+namespace rt { extern const PipeShadeFn g_pipe_shade_whitted[6], g_pipe_shade_direct[6], g_pipe_shade_path[6]; extern const PipeTraceFn g_pipe_trace[6]; }
+static RenderKernelFn render_kernel_of(int variant) {
+    const RenderKernelFn *t = (variant % 3 == 0) ? g_render_kernels_whitted : (variant % 3 == 1) ? g_render_kernels_direct : g_render_kernels_path;
+    return t[variant < 24 ? variant / 3 : variant < 36 ? 8 + (variant - 24) / 3 : 12 + (variant - 36) / 3];
+}
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -410,7 +258,19 @@ struct RtScene {
     bool have_timing = false;
     bool counting = true;
     uint32_t n_tris = 0;
+    // queue pipeline (rt_pipeline.h)
+    PipePool pool{}; unsigned pool_cap = 0; int pool_vec = 0; PipePool *dev_pool = nullptr;
+    unsigned *h_qcount = nullptr;                       // page-locked mirror of pool.q_count (termination test)
+    unsigned trace_grids[6] = {0};
+    std::vector<hipEvent_t> pipe_ev;                    // [2 * RT_PIPE_TIMED] around the trace launches, [.. + RT_PIPE_QN / 4] batch fences
+    std::vector<hipEvent_t> pipe_fence;
+    bool last_pipeline = false; int pipe_iters = 0, pipe_timed = 0; unsigned pipe_slots = 0;
+    float4 *trace_buf = nullptr; size_t trace_cap = 0;   // rt_trace_*: rays (2 x float4) and hits, reused across calls
+    unsigned *trace_qc = nullptr;
 };
+#define RT_PIPE_QN 4096          // ring of per-iteration queue counters
+#define RT_PIPE_TIMED 256        // iterations whose trace launch is bracketed by events
+#define RT_PIPE_BATCH 4          // iterations launched between two termination checks
 
 // tri_frame() of rt_shade.h on the host: same operations in the same order (trianglemesh.cpp:248-274, shape.cpp:43-50,
 // reflection.cpp:475-476)
@@ -442,6 +302,101 @@ static int upload(RtScene *s, const T *host, size_t n, const T **dev) {
     return RT_OK;
 }
 
+// (re)allocate a scratch buffer that is only ever used inside one rt_render call
+template <class T>
+static int ensure(RtScene *s, T **buf, size_t *cap, size_t need) {
+    if (need <= *cap) return RT_OK;
+    if (*buf) { HIPCHK(hipStreamSynchronize(s->stream)); HIPWARN(hipFree(*buf)); *buf = nullptr; *cap = 0; }
+    HIPCHK(hipMalloc((void **)buf, need * sizeof(T)));
+    *cap = need;
+    return RT_OK;
+}
+
+// The queue pipeline: alternate pipe_shade_kernel / pipe_trace_kernel until a shade pass enqueues no ray.  The host learns the
+// queue sizes RT_PIPE_BATCH iterations late (page-locked copy + fence event per batch), so the GPU never waits for it; the
+// iterations launched after the last productive one find every slot in ST_EXIT and return at once.
+static int render_pipeline(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, int vol_levels, int vol_nmax, size_t vol_samp_words) {
+    const int integ = rd->integrator;
+    unsigned want = 1u << 22;
+    if (const char *e = std::getenv("PBRT_HIP_PIPE_SLOTS")) want = unsigned(std::max(256, std::atoi(e)));
+    unsigned long long tw = fr.total_work ? fr.total_work : 1;
+    unsigned n_slots = unsigned(std::min<unsigned long long>(want, tw));
+    n_slots = (n_slots + RT_BLOCK - 1) / RT_BLOCK * RT_BLOCK;
+    const int vec = RT_PIPE_VEC;
+    if (n_slots > s->pool_cap) {
+        HIPCHK(hipStreamSynchronize(s->stream));
+        HIPWARN(hipFree(s->pool.state)); HIPWARN(hipFree(s->pool.ray_o)); HIPWARN(hipFree(s->pool.hit)); HIPWARN(hipFree(s->pool.q_o)); HIPWARN(hipFree(s->pool.q_slot));
+        s->pool = PipePool{}; s->pool_cap = 0;
+        HIPCHK(hipMalloc((void **)&s->pool.state, size_t(vec) * n_slots * sizeof(float4)));
+        HIPCHK(hipMalloc((void **)&s->pool.ray_o, size_t(2) * n_slots * sizeof(float4)));
+        HIPCHK(hipMalloc((void **)&s->pool.hit, size_t(n_slots) * sizeof(float4)));
+        HIPCHK(hipMalloc((void **)&s->pool.q_o, size_t(4) * n_slots * sizeof(float4)));
+        HIPCHK(hipMalloc((void **)&s->pool.q_slot, size_t(2) * n_slots * sizeof(unsigned)));
+        s->pool_cap = n_slots;
+    }
+    if (!s->pool.q_count) HIPCHK(hipMalloc((void **)&s->pool.q_count, RT_PIPE_QN * 4 * sizeof(unsigned)));
+    PipePool pl = s->pool;
+    pl.n_slots = n_slots; pl.ray_d = pl.ray_o + n_slots; pl.q_d = pl.q_o + size_t(2) * n_slots;
+    // per-slot scratch of the state machine: recursion frames (whitted / directlighting), volume march state
+    if (integ != RT_INTEGRATOR_PATH) {
+        int rc = ensure(s, &s->frames, &s->frames_floats, size_t(rd->max_depth + 2) * RT_FRAME_WORDS * n_slots); if (rc) return rc;
+    }
+    if (s->volume.present) {
+        int rc = ensure(s, &s->vol_buf, &s->vol_cap, (size_t(vol_levels) * 8 + 13 + vol_samp_words) * n_slots); if (rc) return rc;
+        fr.vol_rays = s->vol_buf; fr.vol_state = s->vol_buf + size_t(vol_levels) * 8 * n_slots;
+        fr.vol_samp = fr.vol_state + size_t(13) * n_slots; fr.vol_nmax = vol_nmax;
+    }
+    fr.frames = s->frames; fr.n_threads = n_slots;
+    if (s->pipe_ev.empty()) {
+        s->pipe_ev.resize(2 * RT_PIPE_TIMED); s->pipe_fence.resize(RT_PIPE_QN / RT_PIPE_BATCH);
+        for (auto &e : s->pipe_ev) HIPCHK(hipEventCreate(&e));
+        for (auto &e : s->pipe_fence) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    const int f = s->counting ? 1 : (s->has_ext ? 2 : 0);
+    const PipeShadeFn *st = integ == RT_INTEGRATOR_WHITTED ? g_pipe_shade_whitted : integ == RT_INTEGRATOR_DIRECT ? g_pipe_shade_direct : g_pipe_shade_path;
+    const PipeShadeFn shade = st[(s->volume.present ? 3 : 0) + f];
+    const int tk = (s->accel_kind == RT_ACCEL_GRID ? 3 : 0) + f;
+    const PipeTraceFn trace = g_pipe_trace[tk];
+    HIPCHK(hipMemcpyAsync(s->dev_frame, &fr, sizeof(DevFrame), hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(s->dev_pool, &pl, sizeof(PipePool), hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemsetAsync(s->work_counter, 0, sizeof(unsigned long long), s->stream));
+    HIPCHK(hipMemsetAsync(pl.state + n_slots, 0, size_t(n_slots) * sizeof(float4), s->stream));      // control words: every slot in ST_FETCH
+    HIPCHK(hipEventRecord(s->ev0, s->stream));
+    int iter = 0, checked = 0, batch = 0;
+    bool done = false;
+    const int max_iters = 1 << 20;
+    while (!done) {
+        for (int k = 0; k < RT_PIPE_BATCH; ++k, ++iter) {
+            const unsigned qi = unsigned(iter % RT_PIPE_QN);
+            HIPCHK(hipMemsetAsync(pl.q_count + 4 * qi, 0, 4 * sizeof(unsigned), s->stream));
+            hipLaunchKernelGGL(shade, dim3(n_slots / RT_BLOCK), dim3(RT_BLOCK), 0, s->stream, (const DevScene *)s->dev_scene,
+                               (const DevFrame *)s->dev_frame, (const PipePool *)s->dev_pool, qi);
+            TraceJob job{};
+            job.q_o = pl.q_o; job.q_d = pl.q_d; job.q_slot = pl.q_slot; job.q_count = pl.q_count + 4 * qi; job.hit = pl.hit;
+            job.n_slots = n_slots; job.spill = s->spill; job.n_threads = s->n_threads; job.counters = s->counters;
+            if (iter < RT_PIPE_TIMED) HIPCHK(hipEventRecord(s->pipe_ev[2 * iter], s->stream));
+            hipLaunchKernelGGL(trace, dim3(s->trace_grids[tk]), dim3(RT_BLOCK), 0, s->stream, (const DevScene *)s->dev_scene, job);
+            if (iter < RT_PIPE_TIMED) HIPCHK(hipEventRecord(s->pipe_ev[2 * iter + 1], s->stream));
+            HIPCHK(hipMemcpyAsync(s->h_qcount + 4 * qi, pl.q_count + 4 * qi, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(s->pipe_fence[batch % (RT_PIPE_QN / RT_PIPE_BATCH)], s->stream));
+        if (batch >= 1) {                                                   // look at the batch before the one just launched
+            HIPCHK(hipEventSynchronize(s->pipe_fence[(batch - 1) % (RT_PIPE_QN / RT_PIPE_BATCH)]));
+            for (int k = 0; k < RT_PIPE_BATCH; ++k, ++checked) {
+                const unsigned *q = s->h_qcount + 4 * (checked % RT_PIPE_QN);
+                if (q[0] + q[1] == 0) { done = true; break; }
+            }
+        }
+        ++batch;
+        if (iter > max_iters) return fail(RT_ESTATE, "rt_render: the queue pipeline did not terminate");
+    }
+    s->pipe_slots = n_slots; s->pipe_iters = checked + 1; s->pipe_timed = std::min(s->pipe_iters, RT_PIPE_TIMED);
+    HIPCHK(hipEventRecord(s->ev1, s->stream));
+    s->last_pipeline = true;
+    return RT_OK;
+}
+
 static void fill_info(const KdTree &tree, const GridAccelData &g, int kind, uint32_t n_tris, RtAccelInfo *info);
 
 extern "C" {
@@ -461,13 +416,20 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
     if (d->n_tris && (!d->tri_verts || !d->tri_material || !d->tri_light || !d->tri_flags))
         return fail(RT_EINVAL, "rt_scene_create: missing triangle arrays");
     if (d->accel.kind != RT_ACCEL_KDTREE && d->accel.kind != RT_ACCEL_GRID) return fail(RT_EINVAL, "rt_scene_create: unknown accelerator kind");
-    for (uint32_t i = 0; i < d->n_tris; ++i)
+    for (uint32_t i = 0; i < d->n_tris; ++i) {
         if (d->tri_material[i] >= d->n_materials) return fail(RT_EINVAL, "rt_scene_create: material index out of range");
+        const int32_t tl = d->tri_light[i];               // the device indexes `lights` with it (make_vertex, prim_normal_light)
+        if (tl < -1 || tl >= int32_t(d->n_lights) || (tl >= 0 && d->lights[tl].type != RT_LIGHT_AREA))
+            return fail(RT_EINVAL, "rt_scene_create: triangle refers to a light that is out of range or not an area light");
+    }
+    if (d->n_lights > 65534u) return fail(RT_EINVAL, "rt_scene_create: more than 65534 lights");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(RT_EDEVICE, "rt_scene_create: no HIP device visible (the product path has no CPU fallback)");
-    RtScene *s = new RtScene();
-    if (device >= 0) { hipError_t e = hipSetDevice(device); if (e != hipSuccess) { delete s; return fail(RT_EDEVICE, "hipSetDevice failed"); } }
+    // every error exit below goes through the guard: rt_scene_destroy frees whatever has been created so far
+    struct Guard { RtScene *p; ~Guard() { if (p) rt_scene_destroy(p); } } guard{new RtScene()};
+    RtScene *s = guard.p;
+    if (device >= 0) { hipError_t e = hipSetDevice(device); if (e != hipSuccess) return fail(RT_EDEVICE, "hipSetDevice failed"); }
     HIPCHK(hipGetDevice(&s->device));
     HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)); s->own_stream = true;
     HIPCHK(hipEventCreate(&s->ev0)); HIPCHK(hipEventCreate(&s->ev1));
@@ -615,7 +577,7 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
         unsigned mx = 0;
         for (int k = 0; k < 48; ++k) {
             int per_cu = 0;
-            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)g_render_kernels[k], RT_BLOCK, 0));
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)render_kernel_of(k), RT_BLOCK, 0));
             if (per_cu < 1) per_cu = 1;
             s->grids[k] = unsigned(prop.multiProcessorCount) * unsigned(per_cu);
             mx = s->grids[k] > mx ? s->grids[k] : mx;
@@ -623,16 +585,28 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
         s->grid = mx;
     }
     s->n_threads = s->grid * RT_BLOCK;
-    s->spill_depth = s->tree.max_depth > RT_STACK_LDS ? s->tree.max_depth - RT_STACK_LDS + 1 : 1;
-    HIPCHK(hipMalloc((void **)&s->spill, size_t(s->spill_depth) * s->n_threads * sizeof(uint2)));
+    s->spill_depth = s->tree.max_depth > RT_TRACE_STACK ? s->tree.max_depth - RT_TRACE_STACK + 1 : 1;     // RT_TRACE_STACK <= RT_STACK_LDS
     HIPCHK(hipMalloc((void **)&s->work_counter, sizeof(unsigned long long)));
     HIPCHK(hipMalloc((void **)&s->counters, 24 * sizeof(unsigned long long)));
-    HIPCHK(hipMemset(s->counters, 0, 24 * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(s->counters, 0, 24 * sizeof(unsigned long long), s->stream));
     HIPCHK(hipMalloc((void **)&s->filter_dev, 256 * sizeof(float)));
     HIPCHK(hipMalloc((void **)&s->dev_scene, sizeof(DevScene)));
     HIPCHK(hipMalloc((void **)&s->dev_frame, sizeof(DevFrame)));
     HIPCHK(hipMemcpy(s->dev_scene, &s->dev, sizeof(DevScene), hipMemcpyHostToDevice));
     HIPCHK(hipEventCreate(&s->ev2));
+    for (int k = 0; k < 6; ++k) {
+        int per_cu = 0;
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)g_pipe_trace[k], RT_BLOCK, 0));
+        if (const char *e = std::getenv("PBRT_HIP_TRACE_BLOCKS_PER_CU")) per_cu = std::min(per_cu, std::max(1, std::atoi(e)));   // occupancy experiments
+        s->trace_grids[k] = unsigned(prop.multiProcessorCount) * unsigned(per_cu < 1 ? 1 : per_cu);
+        if (s->trace_grids[k] * RT_BLOCK > s->n_threads) s->n_threads = s->trace_grids[k] * RT_BLOCK;      // the spill area is shared
+    }
+    HIPCHK(hipMalloc((void **)&s->spill, size_t(s->spill_depth) * s->n_threads * sizeof(uint2)));
+    HIPCHK(hipMalloc((void **)&s->dev_pool, sizeof(PipePool)));
+    HIPCHK(hipMalloc((void **)&s->trace_qc, 4 * sizeof(unsigned)));
+    HIPCHK(hipHostMalloc((void **)&s->h_qcount, RT_PIPE_QN * 4 * sizeof(unsigned), hipHostMallocDefault));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    guard.p = nullptr;
     *out = s;
     return RT_OK;
 }
@@ -640,7 +614,7 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
 int rt_scene_destroy(RtScene *s) {
     if (!s) return RT_OK;
     HIPWARN(hipSetDevice(s->device));
-    hipStreamSynchronize(s->stream);
+    if (s->stream) hipStreamSynchronize(s->stream);
     for (void *p : s->allocs) HIPWARN(hipFree(p));
     if (s->own_accum && s->accum) HIPWARN(hipFree(s->accum));
     HIPWARN(hipFree(s->spill)); HIPWARN(hipFree(s->work_counter)); HIPWARN(hipFree(s->counters)); HIPWARN(hipFree(s->filter_dev));
@@ -649,6 +623,12 @@ int rt_scene_destroy(RtScene *s) {
     if (s->resolve_buf) HIPWARN(hipFree(s->resolve_buf));
     if (s->vol_buf) HIPWARN(hipFree(s->vol_buf));
     HIPWARN(hipFree(s->dev_scene)); HIPWARN(hipFree(s->dev_frame));
+    HIPWARN(hipFree(s->pool.state)); HIPWARN(hipFree(s->pool.ray_o)); HIPWARN(hipFree(s->pool.hit)); HIPWARN(hipFree(s->pool.q_o));
+    HIPWARN(hipFree(s->pool.q_slot)); HIPWARN(hipFree(s->pool.q_count)); HIPWARN(hipFree(s->dev_pool));
+    HIPWARN(hipFree(s->trace_buf)); HIPWARN(hipFree(s->trace_qc));
+    if (s->h_qcount) HIPWARN(hipHostFree(s->h_qcount));
+    for (hipEvent_t e : s->pipe_ev) HIPWARN(hipEventDestroy(e));
+    for (hipEvent_t e : s->pipe_fence) HIPWARN(hipEventDestroy(e));
     if (s->ev2) HIPWARN(hipEventDestroy(s->ev2));
     if (s->ev0) HIPWARN(hipEventDestroy(s->ev0));
     if (s->ev1) HIPWARN(hipEventDestroy(s->ev1));
@@ -809,6 +789,10 @@ static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool nee
         if (const char *e = std::getenv("PBRT_HIP_DEBUG_PIXEL")) std::sscanf(e, "%d,%d", &fr.dbg_x, &fr.dbg_y);
         fr.phase_sync = tiny ? 1 : 0;                          // C2: 63.6 vs 82.4 ms; 100k/1M soups (early-exit rounds): 8 % slower
         if (const char *e = std::getenv("PBRT_HIP_PHASE_SYNC")) fr.phase_sync = std::atoi(e);
+        // large trees (traversal bound by memory latency): the queue pipeline of rt_pipeline.h; tiny cache-resident ones: the megakernel
+        fr.pipeline = tiny ? 0 : 1;
+        if (const char *e = std::getenv("PBRT_HIP_PIPELINE")) fr.pipeline = std::atoi(e) != 0;
+        if (fr.max_depth > 250 || fr.max_depth < 0) fr.pipeline = 0;     // the slot's control word holds depth in 8 bits
         if (fr.trav_mode == 3 && fr.high_occupancy) fr.trav_mode = 1;   // the high-occupancy kernels carry no pooled-leaf scratch
         if (fr.trav_mode < 0 || fr.trav_mode > 3) fr.trav_mode = 1;
     }
@@ -835,22 +819,39 @@ int rt_camera_rays(RtScene *s, const RtRenderDesc *rd, uint64_t first, uint32_t 
     return RT_OK;
 }
 
+// Scene::Intersect / IntersectP for caller-supplied rays: the rays form one queue of the pipeline's trace kernel (counting
+// twin with the quadric code), so the unit parity tests exercise the very kernel the large-scene renders spend their time in.
 static int trace_common(RtScene *s, const RtRay *rays, uint32_t n, int any, RtHit *hits, uint8_t *occ) {
     if (!s || !rays || (!hits && !occ)) return fail(RT_EINVAL, "null argument");
     HIPCHK(hipSetDevice(s->device));
-    RtRay *drays = nullptr; void *dout = nullptr;
-    const size_t out_bytes = any ? size_t(n) : size_t(n) * sizeof(RtHit);
-    HIPCHK(hipMalloc((void **)&drays, size_t(n ? n : 1) * sizeof(RtRay)));
-    HIPCHK(hipMalloc(&dout, out_bytes ? out_bytes : 1));
-    HIPCHK(hipMemcpy(drays, rays, size_t(n) * sizeof(RtRay), hipMemcpyHostToDevice));
+    if (n == 0) return RT_OK;
+    if (size_t(n) > s->trace_cap) {
+        if (s->trace_buf) { HIPCHK(hipStreamSynchronize(s->stream)); HIPWARN(hipFree(s->trace_buf)); s->trace_buf = nullptr; s->trace_cap = 0; }
+        HIPCHK(hipMalloc((void **)&s->trace_buf, size_t(n) * 3 * sizeof(float4))); s->trace_cap = n;
+    }
+    std::vector<float4> host(size_t(n) * 2);
+    for (uint32_t i = 0; i < n; ++i) {
+        host[i] = make_float4(rays[i].o[0], rays[i].o[1], rays[i].o[2], rays[i].mint);
+        host[size_t(n) + i] = make_float4(rays[i].d[0], rays[i].d[1], rays[i].d[2], rays[i].maxt);
+    }
+    const unsigned qc[4] = {any ? 0u : n, any ? n : 0u, 0u, 0u};
+    HIPCHK(hipMemcpyAsync(s->trace_buf, host.data(), host.size() * sizeof(float4), hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(s->trace_qc, qc, sizeof qc, hipMemcpyHostToDevice, s->stream));
+    TraceJob job{};
+    job.q_o = s->trace_buf; job.q_d = s->trace_buf + n; job.q_slot = nullptr; job.q_count = s->trace_qc; job.hit = s->trace_buf + 2 * size_t(n);
+    job.n_slots = 0; job.spill = s->spill; job.n_threads = s->n_threads; job.counters = s->counters;
+    const int k = (s->accel_kind == RT_ACCEL_GRID ? 3 : 0) + 1;
     HIPWARN(hipEventRecord(s->ev0, s->stream));
-    hipLaunchKernelGGL(trace_kernel, dim3(s->grid), dim3(RT_BLOCK), 0, s->stream, s->dev, drays, n, any,
-                       (RtHit *)(any ? nullptr : dout), (unsigned char *)(any ? dout : nullptr), s->spill, s->n_threads, s->counters);
-    HIPWARN(hipEventRecord(s->ev1, s->stream)); HIPWARN(hipEventRecord(s->ev2, s->stream)); s->have_timing = true;
+    hipLaunchKernelGGL(g_pipe_trace[k], dim3(s->trace_grids[k]), dim3(RT_BLOCK), 0, s->stream, (const DevScene *)s->dev_scene, job);
+    HIPWARN(hipEventRecord(s->ev1, s->stream)); HIPWARN(hipEventRecord(s->ev2, s->stream)); s->have_timing = true; s->last_pipeline = false;
     HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(host.data(), s->trace_buf + 2 * size_t(n), size_t(n) * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
-    HIPCHK(hipMemcpy(any ? (void *)occ : (void *)hits, dout, out_bytes, hipMemcpyDeviceToHost));
-    HIPWARN(hipFree(drays)); HIPWARN(hipFree(dout));
+    for (uint32_t i = 0; i < n; ++i) {
+        int prim; std::memcpy(&prim, &host[i].x, 4);
+        if (any) occ[i] = prim >= 0 ? 1 : 0;
+        else { hits[i].prim = prim; hits[i].t = host[i].y; hits[i].b1 = host[i].z; hits[i].b2 = host[i].w; }
+    }
     return RT_OK;
 }
 int rt_trace_closest(RtScene *s, const RtRay *rays, uint32_t n, RtHit *hits_out) { return trace_common(s, rays, n, 0, hits_out, nullptr); }
@@ -904,15 +905,24 @@ int rt_film_resolve(RtScene *s, int premultiply, float *rgb_out, float *alpha_ou
 int rt_render(RtScene *s, const RtRenderDesc *rd) {
     if (!s || !rd) return fail(RT_EINVAL, "null argument");
     HIPCHK(hipSetDevice(s->device));
-    // recursion frames for whitted / directlighting
-    if (rd->integrator != RT_INTEGRATOR_PATH) {
-        const size_t need = size_t(rd->max_depth + 2) * RT_FRAME_WORDS * s->n_threads;
-        if (need > s->frames_floats) {
-            if (s->frames) { HIPCHK(hipStreamSynchronize(s->stream)); HIPWARN(hipFree(s->frames)); s->frames = nullptr; }
-            HIPCHK(hipMalloc((void **)&s->frames, need * sizeof(float))); s->frames_floats = need;
-        }
-    }
+    // ---- validation first: a failing call launches nothing and leaves the film and the sample buffer untouched
+    if (rd->integrator < RT_INTEGRATOR_WHITTED || rd->integrator > RT_INTEGRATOR_PATH) return fail(RT_EINVAL, "unknown integrator");
+    if (rd->max_depth < 0) return fail(RT_EINVAL, "rt_render: negative maxdepth");
+    if (!rd->filter_table) return fail(RT_EINVAL, "rt_render: no filter table");
     DevFrame fr; int rc = make_frame(s, rd, fr, true); if (rc) return rc;
+    const bool skip_film = std::getenv("PBRT_HIP_DEBUG_NOFILM") != nullptr;   // perf experiments only
+    const int grx = int(std::floor(fr.fxw + 0.5f)), gry = int(std::floor(fr.fyw + 0.5f));   // reach of a sample pixel: |x - sx| <= w + .5
+    const size_t col_bytes = size_t(fr.spp * 2 + 1) * sizeof(float4);
+    size_t lds_kb = 40;                                       // 3 workgroups per CU (measured 60 KB: 5.6 ms, 40 KB: 5.3 ms on C2)
+    if (const char *e = std::getenv("PBRT_HIP_GATHER_LDS_KB")) lds_kb = size_t(std::max(4, std::atoi(e)));
+    int cols = int((lds_kb << 10) / col_bytes);
+    if (fr.x_pixel_start + fr.x_pixel_count > 32767 || fr.y_pixel_start + fr.y_pixel_count > 32767 || fr.x_pixel_start < -32768 || fr.y_pixel_start < -32768)
+        return fail(RT_EINVAL, "rt_render: film coordinates beyond 32767 (the gather packs sample footprints as int16)");
+    if (cols < 1) return fail(RT_EINVAL, "rt_render: more samples per pixel than the film gather stages in LDS (max ~1900)");
+    if (cols > 16 + 2 * grx) cols = 16 + 2 * grx;
+    if (cols > 256) cols = 256;                               // one thread per column resolves the record addresses of a chunk
+    if (!(fr.fxw > 0.f) || !(fr.fyw > 0.f)) return fail(RT_EINVAL, "rt_render: filter widths must be positive");
+    int vol_levels = 0, vol_nmax = 0; size_t vol_samp_words = 0;
     if (s->volume.present) {
         if (!(rd->step_size > 0.f)) return fail(RT_EINVAL, "rt_render: volume integrator stepsize must be positive");
         if (rd->volume_integrator != RT_VOLUME_EMISSION && rd->volume_integrator != RT_VOLUME_SINGLE) return fail(RT_EINVAL, "rt_render: unknown volume integrator");
@@ -920,48 +930,46 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
         const double diag = std::sqrt(double(ex) * ex + double(ey) * ey + double(ez) * ez);
         const double nsteps = std::ceil(diag / rd->step_size) + 2;
         if (nsteps > 65536) return fail(RT_EINVAL, "rt_render: stepsize too small for the medium (more than 65536 march steps)");
-        const int nmax = int(nsteps);
-        const int levels = (rd->integrator == RT_INTEGRATOR_PATH) ? 1 : rd->max_depth + 2;
-        const size_t samp_words = rd->volume_integrator == RT_VOLUME_SINGLE ? size_t(3) * nmax : 0;
-        const size_t need = (size_t(levels) * 8 + 13 + samp_words) * s->n_threads;
-        if (need > s->vol_cap) {
-            if (s->vol_buf) { HIPCHK(hipStreamSynchronize(s->stream)); HIPWARN(hipFree(s->vol_buf)); s->vol_buf = nullptr; }
-            HIPCHK(hipMalloc((void **)&s->vol_buf, need * sizeof(float))); s->vol_cap = need;
-        }
-        fr.vol_rays = s->vol_buf; fr.vol_state = s->vol_buf + size_t(levels) * 8 * s->n_threads;
-        fr.vol_samp = fr.vol_state + size_t(13) * s->n_threads; fr.vol_nmax = nmax;
+        vol_nmax = int(nsteps);
+        vol_levels = (rd->integrator == RT_INTEGRATOR_PATH) ? 1 : rd->max_depth + 2;
+        vol_samp_words = rd->volume_integrator == RT_VOLUME_SINGLE ? size_t(3) * vol_nmax : 0;
     }
-    const bool skip_film = std::getenv("PBRT_HIP_DEBUG_NOFILM") != nullptr;   // perf experiments only
-    if (fr.total_work > s->samples_cap) {
-        if (s->samples) { HIPCHK(hipStreamSynchronize(s->stream)); HIPWARN(hipFree(s->samples)); s->samples = nullptr; }
-        HIPCHK(hipMalloc((void **)&s->samples, size_t(fr.total_work) * 2 * sizeof(float4)));
-        s->samples_cap = fr.total_work;
+    // ---- scratch
+    {
+        size_t cap = s->samples_cap;
+        rc = ensure(s, &s->samples, &cap, size_t(fr.total_work ? fr.total_work : 1) * 2); if (rc) return rc;
+        s->samples_cap = cap;
     }
     fr.samples = s->samples;
-    int variant = (((s->volume.present ? 1 : 0) * 2 + (s->accel_kind == RT_ACCEL_GRID ? 1 : 0)) * 2 + (s->counting ? 1 : 0)) * 3 + rd->integrator;
-    if (fr.high_occupancy && !s->counting) variant = 24 + ((s->volume.present ? 1 : 0) * 2 + (s->accel_kind == RT_ACCEL_GRID ? 1 : 0)) * 3 + rd->integrator;
-    if (s->has_ext && !s->counting) variant = 36 + ((s->volume.present ? 1 : 0) * 2 + (s->accel_kind == RT_ACCEL_GRID ? 1 : 0)) * 3 + rd->integrator;
     HIPCHK(hipMemcpyAsync(s->filter_dev, rd->filter_table, 256 * sizeof(float), hipMemcpyHostToDevice, s->stream));
-    HIPCHK(hipMemcpyAsync(s->dev_frame, &fr, sizeof(DevFrame), hipMemcpyHostToDevice, s->stream));
-    HIPCHK(hipMemsetAsync(s->work_counter, 0, sizeof(unsigned long long), s->stream));
-    HIPCHK(hipEventRecord(s->ev0, s->stream));
     { hipError_t pre = hipGetLastError(); if (pre != hipSuccess) return fail(RT_EDEVICE, std::string("pending HIP error before launch: ") + hipGetErrorString(pre)); }
-    if (s->grids[variant] == 0) return fail(RT_ESTATE, "render kernel variant has no resident grid");
-    hipLaunchKernelGGL(g_render_kernels[variant], dim3(s->grids[variant]), dim3(RT_BLOCK), 0, s->stream,
-                       (const DevScene *)s->dev_scene, (const DevFrame *)s->dev_frame);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(s->ev1, s->stream));
+    if (fr.pipeline) {
+        rc = render_pipeline(s, rd, fr, vol_levels, vol_nmax, vol_samp_words); if (rc) return rc;
+    } else {
+        if (rd->integrator != RT_INTEGRATOR_PATH) {           // recursion frames for whitted / directlighting
+            rc = ensure(s, &s->frames, &s->frames_floats, size_t(rd->max_depth + 2) * RT_FRAME_WORDS * s->n_threads); if (rc) return rc;
+            fr.frames = s->frames;
+        }
+        if (s->volume.present) {
+            rc = ensure(s, &s->vol_buf, &s->vol_cap, (size_t(vol_levels) * 8 + 13 + vol_samp_words) * s->n_threads); if (rc) return rc;
+            fr.vol_rays = s->vol_buf; fr.vol_state = s->vol_buf + size_t(vol_levels) * 8 * s->n_threads;
+            fr.vol_samp = fr.vol_state + size_t(13) * s->n_threads; fr.vol_nmax = vol_nmax;
+        }
+        int variant = (((s->volume.present ? 1 : 0) * 2 + (s->accel_kind == RT_ACCEL_GRID ? 1 : 0)) * 2 + (s->counting ? 1 : 0)) * 3 + rd->integrator;
+        if (fr.high_occupancy && !s->counting) variant = 24 + ((s->volume.present ? 1 : 0) * 2 + (s->accel_kind == RT_ACCEL_GRID ? 1 : 0)) * 3 + rd->integrator;
+        if (s->has_ext && !s->counting) variant = 36 + ((s->volume.present ? 1 : 0) * 2 + (s->accel_kind == RT_ACCEL_GRID ? 1 : 0)) * 3 + rd->integrator;
+        if (s->grids[variant] == 0) return fail(RT_ESTATE, "render kernel variant has no resident grid");
+        HIPCHK(hipMemcpyAsync(s->dev_frame, &fr, sizeof(DevFrame), hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemsetAsync(s->work_counter, 0, sizeof(unsigned long long), s->stream));
+        HIPCHK(hipEventRecord(s->ev0, s->stream));
+        hipLaunchKernelGGL(render_kernel_of(variant), dim3(s->grids[variant]), dim3(RT_BLOCK), 0, s->stream,
+                           (const DevScene *)s->dev_scene, (const DevFrame *)s->dev_frame);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(s->ev1, s->stream));
+        s->last_pipeline = false;
+    }
     if (!skip_film) {
         const unsigned gb = unsigned((fr.x_pixel_count + 15) / 16) * unsigned((fr.y_pixel_count + 15) / 16);
-        const int grx = int(std::floor(fr.fxw + 0.5f)), gry = int(std::floor(fr.fyw + 0.5f));   // reach of a sample pixel: |x - sx| <= w + .5
-        const size_t col_bytes = size_t(fr.spp * 2 + 1) * sizeof(float4);
-        if (fr.x_pixel_start + fr.x_pixel_count > 32767 || fr.y_pixel_start + fr.y_pixel_count > 32767)
-            return fail(RT_EINVAL, "rt_render: film coordinates beyond 32767 (the gather packs sample footprints as int16)");
-        size_t lds_kb = 40;                                   // 3 workgroups per CU (measured 60 KB: 5.6 ms, 40 KB: 5.3 ms on C2)
-        if (const char *e = std::getenv("PBRT_HIP_GATHER_LDS_KB")) lds_kb = size_t(std::max(4, std::atoi(e)));
-        int cols = int((lds_kb << 10) / col_bytes);
-        if (cols < 1) return fail(RT_EINVAL, "rt_render: more samples per pixel than the film gather stages in LDS (max ~1900)");
-        if (cols > 16 + 2 * grx) cols = 16 + 2 * grx;
         const size_t lds_bytes = size_t(cols) * col_bytes + size_t(cols) * sizeof(unsigned long long) + 16;
         hipLaunchKernelGGL(film_gather_kernel, dim3(gb), dim3(256), lds_bytes, s->stream, s->dev_frame, grx, gry, cols);
         HIPCHK(hipGetLastError());
@@ -976,14 +984,6 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
         std::fprintf(stderr, "RT_PROFILE shade_cyc=%llu trav_cyc=%llu outer=%llu inner=%llu rounds=%llu act_lane_rounds=%llu rays_at_trav_start=%llu desc_cyc=%llu leaf_cyc=%llu chunks=%llu pooled_rounds=%llu leaf_iters=%llu\n",
                      v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15], v[16], v[17], v[18], v[19]);
         HIPCHK(hipMemsetAsync(s->counters + 8, 0, 16 * sizeof(unsigned long long), s->stream));
-#ifdef RT_PROFILE_STAGES
-        unsigned long long st[64];
-        HIPCHK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_pf_stage), sizeof st));
-        for (int k = 0; k < 32; ++k) if (st[2 * k + 1])
-            std::fprintf(stderr, "RT_PROFILE_STAGE %d cyc=%llu passes=%llu lanes=%llu\n", k, st[2 * k], st[2 * k + 1] >> 40, st[2 * k + 1] & ((1ull << 40) - 1));
-        std::memset(st, 0, sizeof st);
-        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_pf_stage), st, sizeof st));
-#endif
     }
 #endif
     return RT_OK;
@@ -1024,8 +1024,29 @@ int rt_last_render_ms(RtScene *s, float *total_ms, float *kernel_ms) {
     float k = 0.f, t = 0.f;
     HIPCHK(hipEventElapsedTime(&k, s->ev0, s->ev1));
     HIPCHK(hipEventElapsedTime(&t, s->ev0, s->ev2));
-    if (total_ms) *total_ms = t;        // render kernel + film gather
-    if (kernel_ms) *kernel_ms = k;      // rt::render_kernel alone (the dominant kernel)
+    if (total_ms) *total_ms = t;        // render kernel(s) + film gather
+    if (kernel_ms) *kernel_ms = k;      // rt::render_kernel alone, or the whole shade / trace loop of the queue pipeline
+    return RT_OK;
+}
+// Timing of the last rt_render by kernel: {whole frame, render part (megakernel or shade+trace loop), trace kernel launches summed,
+// film gather} in ms, the number of pipeline iterations (0: megakernel) and how many of them were timed.
+int rt_last_render_stats(RtScene *s, RtRenderStats *out) {
+    if (!s || !out) return fail(RT_EINVAL, "null argument");
+    if (!s->have_timing) return fail(RT_ESTATE, "no timed launch yet");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipEventSynchronize(s->ev2));
+    std::memset(out, 0, sizeof *out);
+    HIPCHK(hipEventElapsedTime(&out->render_ms, s->ev0, s->ev1));
+    HIPCHK(hipEventElapsedTime(&out->total_ms, s->ev0, s->ev2));
+    out->gather_ms = out->total_ms - out->render_ms;
+    out->pipeline = s->last_pipeline ? 1 : 0;
+    if (s->last_pipeline) {
+        out->iterations = s->pipe_iters; out->timed_iterations = s->pipe_timed;
+        float sum = 0.f;
+        for (int i = 0; i < s->pipe_timed; ++i) { float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, s->pipe_ev[2 * i], s->pipe_ev[2 * i + 1])); sum += ms; }
+        out->trace_ms = sum;
+        out->slots = s->pipe_slots;
+    } else out->trace_ms = out->render_ms;
     return RT_OK;
 }
 

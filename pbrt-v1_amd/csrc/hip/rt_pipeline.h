@@ -1,0 +1,414 @@
+// rt_pipeline.h -- the queue ("wavefront") form of Scene::Render for scenes whose traversal is bound by memory latency.
+//
+// The megakernel (rt_render_kernel.h) keeps a lane's whole path state in registers while its ray is traced: ~128-160 VGPRs,
+// 3-4 waves per SIMD, and at 1 M triangles only ~43 % of the lanes of a wave are traversing at any time.  Every one of the
+// ~135 node visits of a ray is a dependent HBM / L2 round trip, so throughput is (rays in flight) / latency.  Here the same
+// per-sample state machine (rt_integrate.h, unchanged arithmetic and draw order) is cut at its only blocking operation:
+//
+//   pipe_shade_kernel   one thread per path SLOT: load the slot's state (coalesced float4 planes), take the result of the ray
+//                       it was waiting for, run advance_pass until the slot has set up its next ray (or fetched a new camera
+//                       sample, or run out of work), append that ray to the closest-hit or the any-hit queue with one
+//                       wave-aggregated atomic (ballot + popcount compaction: the queues hold live rays only, sorted by kind),
+//                       store the state back.
+//   pipe_trace_kernel   persistent waves that hold nothing but traversal state (<= 64 VGPRs -> 8 waves per SIMD): each lane
+//                       pulls a ray from the queue, walks KdTreeAccel::Intersect / IntersectP (rt_traverse.h: same visit
+//                       order, same counters), writes {prim, t, b1, b2} for its slot and immediately pulls the next ray, so
+//                       all 64 lanes traverse all the time and twice as many waves hide the latency.
+//
+// The host alternates the two kernels until a shade pass enqueues nothing.  Cost: ~400 B of state traffic per ray (coalesced,
+// 100 M rays -> 40 GB = ~7 ms at HBM rate) against ~1.5 KB of scattered traversal traffic per ray.  Whitted / DirectLighting
+// recursion frames and the volume scratch are indexed by slot instead of by resident thread.
+#pragma once
+#include "rt_integrate.h"
+
+#ifndef RT_TRACE_WAVES
+#define RT_TRACE_WAVES 8          // waves per SIMD the trace kernel is register-capped for (8 = 64 VGPRs)
+#endif
+#ifndef RT_TRACE_STACK
+#define RT_TRACE_STACK 8          // LDS ring entries per lane in the trace kernel: 8 x 8 B x 256 = 16 KB per workgroup, 8 workgroups per CU
+#endif
+#ifndef RT_TRACE_REFILL
+#define RT_TRACE_REFILL 16        // a wave refills its idle lanes from the queue when at least this many are idle
+#endif
+
+namespace rt {
+
+#define RT_PIPE_VEC 11            // float4 planes of slot state (the 11th only for DirectLighting "all")
+
+struct PipePool {
+    unsigned n_slots;
+    float4 *state;                // [RT_PIPE_VEC][n_slots]
+    float4 *ray_o, *ray_d;        // [n_slots] {o, mint} {d, maxt}: the slot's ray, kept for the shading that follows the trace
+    float4 *hit;                  // [n_slots] {prim, t, b1, b2} written by the trace kernel
+    float4 *q_o, *q_d;            // [2][n_slots] compacted queues: closest-hit rays in [0, n), any-hit rays in [n_slots, n_slots + m)
+    unsigned *q_slot;             // [2][n_slots] slot of each queued ray
+    unsigned *q_count;            // [iterations][4] {n closest, n any, consumer head, -}
+};
+
+// ---- slot state <-> Lane ----------------------------------------------------------------------------------------
+// ctl word: stage (4 bits) | has_ray << 4 | specular << 5 | any << 6 | depth << 8 | fsp << 16
+template <int INTEG>
+RT_DEV void pipe_load(const PipePool &pl, const DevFrame &fr, unsigned slot, Lane &ln) {
+    const float4 RT_G *st = RT_GPTR(const float4, pl.state) + slot;
+    const size_t n = pl.n_slots;
+    const float4 a0 = st[0], a1 = st[n];
+    const unsigned ctl = __float_as_uint(a1.z);
+    ln.stage = int(ctl & 15u); ln.has_ray = (ctl >> 4) & 1u; ln.specular = (ctl >> 5) & 1u; ln.tv.any = (ctl >> 6) & 1u;
+    ln.depth = int((ctl >> 8) & 255u); ln.fsp = int(ctl >> 16);
+    ln.sample_index = __float_as_uint(a0.x); ln.work = __float_as_uint(a0.y); ln.image_x = a0.z; ln.image_y = a0.w;
+    ln.dim_base = __float_as_uint(a1.x); ln.rng.ctr = __float_as_uint(a1.y); ln.alpha = a1.w;
+    ln.rng.base = rng_base(ln.sample_index, fr.seed);
+    ln.tv.active = false; ln.tv.hit_prim = -1;
+    if (ln.stage == ST_EXIT || ln.stage == ST_FETCH) {        // nothing else is live
+        ln.L = mk3(0.f); ln.thr = mk3(1.f);
+        return;
+    }
+    const float4 a2 = st[2 * n], a3 = st[3 * n], a4 = st[4 * n], a5 = st[5 * n], a6 = st[6 * n], a7 = st[7 * n], a8 = st[8 * n], a9 = st[9 * n];
+    ln.L = mk3(a2.x, a2.y, a2.z);
+    { const unsigned ml = __float_as_uint(a2.w); ln.v.mat = int(ml & 0xffffu); ln.v.light = int(ml >> 16) - 1; }
+    ln.thr = mk3(a3.x, a3.y, a3.z);
+    { const unsigned lj = __float_as_uint(a3.w); ln.li = int(lj & 0xffffu); ln.lj = int(lj >> 16); }
+    ln.v.p = mk3(a4.x, a4.y, a4.z); ln.cur_light = __float_as_int(a4.w);
+    ln.v.nn = mk3(a5.x, a5.y, a5.z); ln.bs1 = a5.w;
+    ln.v.sn = mk3(a6.x, a6.y, a6.z); ln.bs2 = a6.w;
+    ln.v.tn = cross3(ln.v.nn, ln.v.sn);                        // make_vertex's own expression (rt_shade.h)
+    ln.v.wo = mk3(a7.x, a7.y, a7.z); ln.bcs = a7.w;
+    ln.Ld = mk3(a8.x, a8.y, a8.z);
+    ln.pend = mk3(a8.w, a9.x, a9.y);
+    if (INTEG == RT_INTEGRATOR_DIRECT) {
+        const float4 a10 = st[10 * n];
+        ln.Ld_light = mk3(a9.z, a9.w, a10.x); ln.L_all = mk3(a10.y, a10.z, a10.w);
+    }
+}
+template <int INTEG>
+RT_DEV void pipe_store(const PipePool &pl, unsigned slot, const Lane &ln) {
+    float4 RT_G *st = RT_GPTR(float4, pl.state) + slot;
+    const size_t n = pl.n_slots;
+    const unsigned ctl = unsigned(ln.stage) | (ln.has_ray ? 16u : 0u) | (ln.specular ? 32u : 0u) | (ln.tv.any ? 64u : 0u) |
+                         (unsigned(ln.depth) << 8) | (unsigned(ln.fsp) << 16);
+    st[0] = make_float4(__uint_as_float(ln.sample_index), __uint_as_float(ln.work), ln.image_x, ln.image_y);
+    st[n] = make_float4(__uint_as_float(ln.dim_base), __uint_as_float(ln.rng.ctr), __uint_as_float(ctl), ln.alpha);
+    if (ln.stage == ST_EXIT) return;
+    st[2 * n] = make_float4(ln.L.x, ln.L.y, ln.L.z, __uint_as_float(unsigned(ln.v.mat) | (unsigned(ln.v.light + 1) << 16)));
+    st[3 * n] = make_float4(ln.thr.x, ln.thr.y, ln.thr.z, __uint_as_float(unsigned(ln.li) | (unsigned(ln.lj) << 16)));
+    st[4 * n] = make_float4(ln.v.p.x, ln.v.p.y, ln.v.p.z, __int_as_float(ln.cur_light));
+    st[5 * n] = make_float4(ln.v.nn.x, ln.v.nn.y, ln.v.nn.z, ln.bs1);
+    st[6 * n] = make_float4(ln.v.sn.x, ln.v.sn.y, ln.v.sn.z, ln.bs2);
+    st[7 * n] = make_float4(ln.v.wo.x, ln.v.wo.y, ln.v.wo.z, ln.bcs);
+    st[8 * n] = make_float4(ln.Ld.x, ln.Ld.y, ln.Ld.z, ln.pend.x);
+    if (INTEG == RT_INTEGRATOR_DIRECT) {
+        st[9 * n] = make_float4(ln.pend.y, ln.pend.z, ln.Ld_light.x, ln.Ld_light.y);
+        st[10 * n] = make_float4(ln.Ld_light.z, ln.L_all.x, ln.L_all.y, ln.L_all.z);
+    } else st[9 * n] = make_float4(ln.pend.y, ln.pend.z, 0.f, 0.f);
+}
+
+// ---- shade: everything between two rays of a path, for every slot ---------------------------------------------------
+template <bool COUNT, int INTEG, bool VOL, bool EXT>
+__global__ __launch_bounds__(RT_BLOCK) void pipe_shade_kernel(const DevScene *__restrict__ scp, const DevFrame *__restrict__ frp,
+                                                               const PipePool *__restrict__ plp, unsigned iter) {
+    const DevScene &sc = *scp;
+    const DevFrame &fr = *frp;
+    const PipePool &pl = *plp;
+    const unsigned slot = blockIdx.x * RT_BLOCK + threadIdx.x;          // n_slots is a multiple of RT_BLOCK
+    const int lane = threadIdx.x & 63;
+    Lane ln;
+    ln.v.p = ln.v.nn = ln.v.sn = ln.v.tn = ln.v.wo = mk3(0.f); ln.v.mat = 0; ln.v.light = -1;
+    ln.li = ln.lj = 0; ln.cur_light = 0; ln.Ld = ln.Ld_light = ln.L_all = ln.pend = mk3(0.f); ln.bs1 = ln.bs2 = ln.bcs = 0.f;
+    pipe_load<INTEG>(pl, fr, slot, ln);
+    if (!__any(ln.stage != ST_EXIT)) return;
+    if (ln.has_ray) {                                                   // the ray this slot was waiting for has been traced
+        const float4 ro = RT_GPTR(const float4, pl.ray_o)[slot], rd = RT_GPTR(const float4, pl.ray_d)[slot];
+        const float4 h = RT_GPTR(const float4, pl.hit)[slot];
+        ln.tv.o = mk3(ro.x, ro.y, ro.z); ln.tv.mint = ro.w; ln.tv.d = mk3(rd.x, rd.y, rd.z); ln.tv.maxt = rd.w;
+        ln.tv.hit_prim = __float_as_int(h.x);
+        if (ln.tv.hit_prim >= 0 && !ln.tv.any) ln.tv.maxt = h.y;        // primitive.cpp:120: the accepted hit shortens the ray
+        ln.tv.b1 = h.z; ln.tv.b2 = h.w;
+        ln.has_ray = false;
+    }
+    unsigned c_cam = 0, c_closest = 0, c_any = 0, c_bad = 0;
+    do {
+        advance_pass<COUNT, INTEG, VOL, EXT, true>(sc, fr, ln, slot, &c_closest, &c_any, &c_bad, -1);
+        const unsigned long long want = __ballot(!ln.has_ray && ln.stage == ST_FETCH);
+        if (want) {                                                     // wave-aggregated work fetch (as in render_kernel)
+            const int leader = __ffsll((long long)want) - 1;
+            unsigned long long base = 0;
+            if (lane == leader) base = atomicAdd(fr.work_counter, (unsigned long long)__popcll(want));
+            base = __shfl(base, leader);
+            if (!ln.has_ray && ln.stage == ST_FETCH) {
+                const unsigned long long w = base + __popcll(want & ((1ull << lane) - 1ull));
+                if (w >= fr.total_work) ln.stage = ST_EXIT;
+                else {
+                    unsigned long long pixel; int s;
+                    if (work_to_sample(fr, w, pixel, s)) {
+                        Ray ray;
+                        setup_sample(sc, fr, ln, pixel, s, ray);
+                        ln.work = uint32_t(w);
+                        ln.L = mk3(0.f); ln.thr = mk3(1.f); ln.alpha = 0.f; ln.depth = 0; ln.fsp = 0;
+                        ln.specular = false;
+                        if (COUNT) ++c_cam;
+                        if (VOL) vol_store_ray(fr, 0, slot, ray);
+                        launch_ray<true>(ln, sc, ray.o, ray.d, ray.mint, ray.maxt, false, ST_VERTEX);
+                    }
+                }
+            }
+        }
+    } while (__any(!ln.has_ray && ln.stage != ST_EXIT));
+    // ---- enqueue: ballot compaction per ray kind, one atomic per wave and kind
+    {
+        unsigned RT_G *qc = RT_GPTR(unsigned, pl.q_count) + size_t(iter) * 4;
+        const unsigned long long mc = __ballot(ln.has_ray && !ln.tv.any), ma = __ballot(ln.has_ray && ln.tv.any);
+        unsigned bc = 0, ba = 0;
+        if (mc && lane == __ffsll((long long)mc) - 1) bc = atomicAdd((unsigned *)qc, unsigned(__popcll(mc)));
+        if (ma && lane == __ffsll((long long)ma) - 1) ba = atomicAdd((unsigned *)(qc + 1), unsigned(__popcll(ma)));
+        if (mc) bc = __shfl(bc, __ffsll((long long)mc) - 1);
+        if (ma) ba = __shfl(ba, __ffsll((long long)ma) - 1);
+        if (ln.has_ray) {
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const size_t q = ln.tv.any ? size_t(pl.n_slots) + ba + __popcll(ma & below) : size_t(bc) + __popcll(mc & below);
+            const float4 ro = make_float4(ln.tv.o.x, ln.tv.o.y, ln.tv.o.z, ln.tv.mint), rd = make_float4(ln.tv.d.x, ln.tv.d.y, ln.tv.d.z, ln.tv.maxt);
+            RT_GPTR(float4, pl.q_o)[q] = ro; RT_GPTR(float4, pl.q_d)[q] = rd; RT_GPTR(unsigned, pl.q_slot)[q] = slot;
+            RT_GPTR(float4, pl.ray_o)[slot] = ro; RT_GPTR(float4, pl.ray_d)[slot] = rd;
+        }
+    }
+    pipe_store<INTEG>(pl, slot, ln);
+    if (COUNT) {
+        unsigned long long v[4] = {c_cam, c_closest, c_any, c_bad};
+        const int idx[4] = {0, 1, 2, 6};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned long long x = v[k];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+            if (lane == 0 && x) atomicAdd(fr.counters + idx[k], x);
+        }
+    }
+}
+
+// ---- trace: persistent waves, ray replacement -------------------------------------------------------------------------
+struct TraceJob {
+    const float4 *q_o, *q_d;       // queue rays: closest in [0, n_slots), any in [n_slots, 2 n_slots)
+    const unsigned *q_slot;
+    unsigned *q_count;             // {n closest, n any, head, -} of this iteration
+    float4 *hit;                   // [slot]; for rt_trace_* (q_slot == nullptr) indexed by queue position
+    unsigned n_slots;
+    uint2 *spill; unsigned n_threads;
+    unsigned long long *counters;
+};
+
+#ifndef RT_TRACE_LOOP
+#define RT_TRACE_LOOP 2
+#endif
+#ifndef RT_TRACE_DSTEPS
+#define RT_TRACE_DSTEPS 4         // interior steps a descending lane may take per round before the leaf phase gets its turn
+#endif
+#ifndef RT_TRACE_LEAF_MIN
+#define RT_TRACE_LEAF_MIN 12      // keep testing primitives while at least this many lanes have one left
+#endif
+
+// ---- the trace kernel's own traversal steps ------------------------------------------------------------------------------
+// Same semantics as kd_descend / leaf_test_one / kd_leaf_done of rt_traverse.h (KdTreeAccel::Intersect / IntersectP,
+// kdtree.cpp:313-488; Triangle::Intersect, trianglemesh.cpp:213-246), written as straight-line code with selects: every
+// state variable is updated by ONE predicated assignment at the end of a step instead of inside nested divergent branches
+// with early returns.  The branchy form costs ~30 register copies per step (the structurizer's phi moves); at 135 node
+// visits per ray the trace kernel was bound by VALU issue, not by memory.
+template <bool COUNT, int NS>
+RT_DEV void kd_step_flat(Trav &tv, bool desc, const DevScene &sc, uint2 RT_L *lds_stack, uint2 RT_G *spill, unsigned n_threads, unsigned gtid, TravCounters &cnt) {
+    const bool dead = desc && !tv.any && tv.maxt < tv.tmin;                    // kdtree.cpp:330
+    const bool go = desc && !dead;
+    uint2 nd = make_uint2(3u, 0u);
+    if (go) nd = RT_GPTR(const uint2, sc.nodes)[tv.node];
+    if (COUNT) cnt.nodes += go ? 1u : 0u;
+    const unsigned axis = nd.x & 3u;
+    const bool leaf = axis == 3u;
+    const float split = __uint_as_float(nd.x);                                 // perturbed split, B10
+    const float oa = comp(tv.o, int(axis)), da = comp(tv.d, int(axis)), ia = comp(tv.inv, int(axis));   // by value: stays in registers
+    const float tplane = (split - oa) * ia;
+    const bool belowFirst = (oa < split) || (oa == split && da >= 0.f);
+    const unsigned below = tv.node + 1u, above = nd.y;
+    const unsigned first = belowFirst ? below : above, second = belowFirst ? above : below;
+    const bool only_first = tplane > tv.tmax || tplane <= 0.f;
+    const bool only_second = !only_first && tplane < tv.tmin;
+    const bool interior = go && !leaf;
+    const bool both = interior && !only_first && !only_second;
+    if (both) stack_push<COUNT, NS>(tv, make_uint2(second, __float_as_uint(tv.tmax)), lds_stack, spill, n_threads, gtid, cnt);
+    tv.node = interior ? (only_second ? second : first) : tv.node;
+    tv.tmax = both ? tplane : tv.tmax;
+    const bool enter = go && leaf;
+    tv.at_leaf = enter ? true : tv.at_leaf;
+    tv.li = enter ? 0u : tv.li;
+    tv.ln_ = enter ? (nd.x >> 2) : tv.ln_;
+    tv.ly = enter ? nd.y : tv.ly;
+    tv.active = dead ? false : tv.active;
+}
+template <bool COUNT>
+RT_DEV void leaf_test_flat(Trav &tv, bool leafw, const DevScene &sc, TravCounters &cnt) {
+    const bool single = tv.ln_ == 1u;
+    unsigned prim = tv.ly;
+    if (leafw && !single) prim = RT_GPTR(const unsigned, sc.leaf_refs)[tv.ly + tv.li];
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
+    if (leafw) { const DevTri RT_G *gt = RT_GPTR(const DevTri, sc.tris) + prim; q0 = gt->q0; q1 = gt->q1; q2 = gt->q2; }
+    if (COUNT) { cnt.tris += leafw ? 1u : 0u; cnt.leaf_refs += (leafw && !single) ? 1u : 0u; }
+    tv.li += leafw ? 1u : 0u;
+    const V3 p1 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
+    const V3 s1 = cross3(tv.d, e2);
+    const float divisor = dot3(s1, e1);
+    const float invDivisor = 1.f / divisor;
+    const V3 dd = tv.o - p1;
+    const float b1 = dot3(dd, s1) * invDivisor;
+    const V3 s2 = cross3(dd, e1);
+    const float b2 = dot3(tv.d, s2) * invDivisor;
+    const float t = dot3(e2, s2) * invDivisor;
+    const bool miss = (divisor == 0.f) || (b1 < 0.f || b1 > 1.f) || (b2 < 0.f || b1 + b2 > 1.f) || (t < tv.mint || t > tv.maxt);
+    const bool hit = leafw && !miss;
+    const bool stop = hit && tv.any;                                           // kdtree.cpp:432-434
+    const bool keep = hit && !tv.any;                                          // primitive.cpp:120
+    tv.hit_prim = stop ? 0 : (keep ? int(prim) : tv.hit_prim);
+    tv.maxt = keep ? t : tv.maxt;
+    tv.b1 = keep ? b1 : tv.b1;
+    tv.b2 = keep ? b2 : tv.b2;
+    tv.active = stop ? false : tv.active;
+}
+template <int NS>
+RT_DEV void kd_pop_flat(Trav &tv, bool done, const uint2 RT_L *lds_stack, const uint2 RT_G *spill, unsigned n_threads, unsigned gtid) {
+    const bool pop = done && tv.sp > 0;
+    uint2 e = make_uint2(0u, 0u);
+    if (pop) e = stack_pop<NS>(tv, lds_stack, spill, n_threads, gtid);
+    tv.node = pop ? e.x : tv.node;
+    tv.tmin = pop ? tv.tmax : tv.tmin;
+    tv.tmax = pop ? __uint_as_float(e.y) : tv.tmax;
+    tv.at_leaf = done ? false : tv.at_leaf;
+    tv.active = (done && !pop) ? false : tv.active;
+}
+
+// One round of the trace kernel's inner loop: the per-lane order of node visits and primitive tests is that of
+// KdTreeAccel::Intersect / IntersectP, only the interleaving across lanes is chosen here:
+//   A  every descending lane takes up to RT_TRACE_DSTEPS interior steps (a tight loop of nothing but the node step);
+//   B  the lanes that sit at a leaf test one primitive each, repeated while enough lanes still have one;
+//   C  lanes whose leaf is exhausted pop their next subtree.
+template <bool COUNT, int ACCEL, bool EXT, int NS>
+RT_DEV void trace_round(Trav &tv, bool busy, const DevScene &sc, uint2 RT_L *lds_stack, uint2 RT_G *spill, unsigned n_threads, unsigned gtid, TravCounters &cnt) {
+    if (ACCEL == RT_ACCEL_GRID) {
+        if (busy && tv.active && !tv.at_leaf) grid_enter_voxel<COUNT>(tv, sc, cnt);
+    } else {
+#pragma unroll 1
+        for (int k = 0; k < RT_TRACE_DSTEPS; ++k) {
+            const bool desc = busy && tv.active && !tv.at_leaf;
+            if (!__any(desc)) break;
+            kd_step_flat<COUNT, NS>(tv, desc, sc, lds_stack, spill, n_threads, gtid, cnt);
+        }
+    }
+#pragma unroll 1
+    for (;;) {
+        const bool leafw = busy && tv.active && tv.at_leaf && tv.li < tv.ln_;
+        const int nl = __popcll(__ballot(leafw));
+        if (nl == 0) break;
+        if (ACCEL == RT_ACCEL_GRID || EXT) { if (leafw) leaf_test_one<COUNT, ACCEL == RT_ACCEL_GRID, EXT>(tv, sc, cnt); }
+        else leaf_test_flat<COUNT>(tv, leafw, sc, cnt);
+        if (nl < RT_TRACE_LEAF_MIN) break;
+    }
+    const bool done = busy && tv.active && tv.at_leaf && tv.li >= tv.ln_;
+    if (ACCEL == RT_ACCEL_GRID) { if (done) grid_voxel_done(tv, sc); }
+    else kd_pop_flat<NS>(tv, done, lds_stack, spill, n_threads, gtid);
+}
+
+template <bool COUNT, int ACCEL, bool EXT>
+__global__ __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) void pipe_trace_kernel(const DevScene *__restrict__ scp, TraceJob job) {
+    __shared__ uint2 lds_stack[RT_TRACE_STACK * RT_BLOCK];
+    const DevScene &sc = *scp;
+    const unsigned gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const unsigned n_closest = job.q_count[0], total = n_closest + job.q_count[1];
+    TravCounters tc; tc.nodes = tc.leaf_refs = tc.tris = tc.spills = 0;
+    Trav tv; tv.active = false; tv.at_leaf = false; tv.hit_prim = -1; tv.any = false; tv.maxt = 0.f; tv.b1 = tv.b2 = 0.f;
+    unsigned slot = 0; bool busy = false;
+    bool exhausted = false;
+#if RT_TRACE_LOOP == 0
+    for (;;) {
+        // a lane whose ray just ended reports it
+        if (busy && !tv.active) {
+            RT_GPTR(float4, job.hit)[slot] = make_float4(__int_as_float(tv.hit_prim), tv.hit_prim >= 0 ? tv.maxt : 0.f, tv.b1, tv.b2);
+            busy = false;
+        }
+        const unsigned long long idle = __ballot(!busy);
+        if (!exhausted && __popcll(idle) >= RT_TRACE_REFILL) {
+            const int leader = __ffsll((long long)idle) - 1;
+            unsigned base = 0;
+            if (lane == leader) base = atomicAdd(job.q_count + 2, unsigned(__popcll(idle)));
+            base = __shfl(base, leader);
+            if (base + unsigned(__popcll(idle)) >= total) exhausted = true;
+            if (!busy) {
+                const unsigned i = base + unsigned(__popcll(idle & ((1ull << lane) - 1ull)));
+                if (i < total) {
+                    const bool any = i >= n_closest;
+                    const size_t q = any ? size_t(job.n_slots) + (i - n_closest) : size_t(i);
+                    const float4 ro = RT_GPTR(const float4, job.q_o)[q], rd = RT_GPTR(const float4, job.q_d)[q];
+                    slot = job.q_slot ? RT_GPTR(const unsigned, job.q_slot)[q] : unsigned(q);
+                    Ray r; r.o = mk3(ro.x, ro.y, ro.z); r.mint = ro.w; r.d = mk3(rd.x, rd.y, rd.z); r.maxt = rd.w;
+                    accel_begin<ACCEL>(tv, sc, r, any);
+                    busy = true;
+                }
+            }
+            continue;                                                  // rays that died in the slab clip report above
+        }
+        // here busy implies tv.active; no lane busy means the queue is exhausted (else the refill above would have run)
+        if (__popcll(idle) == 64) break;
+        accel_round_batched<COUNT, ACCEL, EXT, RT_TRACE_STACK>(tv, busy, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, job.spill), job.n_threads, gtid, tc);
+    }
+#else
+    // Outer loop: report finished rays, refill the idle lanes from the queue (one wave-aggregated atomic).  Inner loop: rounds of
+    // traversal with nothing else in it, until enough lanes have finished for a refill to pay (or, once the queue is exhausted,
+    // until the wave's last ray ends).
+#pragma unroll 1
+    for (;;) {
+        if (busy && !tv.active) {
+            RT_GPTR(float4, job.hit)[slot] = make_float4(__int_as_float(tv.hit_prim), tv.hit_prim >= 0 ? tv.maxt : 0.f, tv.b1, tv.b2);
+            busy = false;
+        }
+        const unsigned long long idle = __ballot(!busy);
+        const unsigned n_idle = unsigned(__popcll(idle));
+        if (!exhausted && n_idle >= RT_TRACE_REFILL) {
+            const int leader = __ffsll((long long)idle) - 1;
+            unsigned base = 0;
+            if (lane == leader) base = atomicAdd(job.q_count + 2, n_idle);
+            base = __shfl(base, leader);
+            if (base + n_idle >= total) exhausted = true;
+            const unsigned i = base + unsigned(__popcll(idle & ((1ull << lane) - 1ull)));
+            if (!busy && i < total) {
+                const bool any = i >= n_closest;
+                const size_t q = any ? size_t(job.n_slots) + (i - n_closest) : size_t(i);
+                const float4 ro = RT_GPTR(const float4, job.q_o)[q], rd = RT_GPTR(const float4, job.q_d)[q];
+                slot = job.q_slot ? RT_GPTR(const unsigned, job.q_slot)[q] : unsigned(q);
+                Ray r; r.o = mk3(ro.x, ro.y, ro.z); r.mint = ro.w; r.d = mk3(rd.x, rd.y, rd.z); r.maxt = rd.w;
+                accel_begin<ACCEL>(tv, sc, r, any);
+                busy = true;
+            }
+        }
+        const int live0 = __popcll(__ballot(busy && tv.active));
+        if (live0 == 0) { if (exhausted && !__any(busy)) break; else if (exhausted) continue; }
+        // leave the inner loop when RT_TRACE_REFILL more lanes have finished (queue not exhausted) or when all have
+        const int leave_at = exhausted ? 0 : (live0 > RT_TRACE_REFILL ? live0 - RT_TRACE_REFILL : 0);
+#pragma unroll 1
+        do {
+#if RT_TRACE_LOOP == 1
+            accel_round_batched<COUNT, ACCEL, EXT, RT_TRACE_STACK>(tv, busy, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, job.spill), job.n_threads, gtid, tc);
+#else
+            trace_round<COUNT, ACCEL, EXT, RT_TRACE_STACK>(tv, busy, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, job.spill), job.n_threads, gtid, tc);
+#endif
+        } while (__popcll(__ballot(busy && tv.active)) > leave_at);
+    }
+#endif
+    if (COUNT) {
+        unsigned long long v[4] = {tc.nodes, tc.leaf_refs, tc.tris, tc.spills};
+        const int idx[4] = {3, 4, 5, 7};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned long long x = v[k];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+            if (lane == 0 && x) atomicAdd(job.counters + idx[k], x);
+        }
+    }
+}
+
+typedef void (*PipeShadeFn)(const DevScene *, const DevFrame *, const PipePool *, unsigned);
+typedef void (*PipeTraceFn)(const DevScene *, TraceJob);
+
+}  // namespace rt

@@ -1,0 +1,138 @@
+// rt_render_kernel.h -- the persistent-thread megakernel: Scene::Render's sample loop (scene.cpp:42-84) with every lane running
+// the state machine of rt_integrate.h and all lanes of a wave sharing ONE traversal loop.  Used for small, cache-resident scenes
+// (Cornell: VALU-bound); large scenes go through the queue pipeline of rt_pipeline.h.  Instantiated per integrator in
+// rt_mega_{w,d,p}.hip (separate translation units so that the library builds in parallel).
+#pragma once
+#include "rt_integrate.h"
+
+namespace rt {
+
+// ------------------------------------------------------------------------------------------ kernels
+#ifndef RT_MIN_WAVES
+#define RT_MIN_WAVES 1
+#endif
+// waves per SIMD of the high-occupancy flavour: 4 = 128 VGPRs.  5 (96 VGPRs) was marginally faster at one point but its
+// spill placement swings with every code change (measured 108 -> 153 ms on the 1 M-triangle path frame for the same
+// algorithm); 4 is stable: 101 ms there, 138 ms on the 100 k soup.
+#ifndef RT_HIGH_OCC_WAVES
+#define RT_HIGH_OCC_WAVES 4
+#endif
+#ifndef RT_EXIT_THRESH
+#define RT_EXIT_THRESH 0
+#endif
+#ifndef RT_LOCKSTEP
+#define RT_LOCKSTEP 1
+#endif
+// Scene and frame descriptors are read through pointers (uniform addresses -> scalar loads on demand) instead of
+// being passed by value: the by-value form pinned >100 SGPRs and spilled them.
+// MINW = minimum waves per SIMD the register allocator must make room for: 1 = natural allocation (~160 VGPRs, 3 waves/SIMD,
+// best when VALU-bound: tiny cache-resident scenes); RT_HIGH_OCC_WAVES = 4 caps at 128 VGPRs (some spills to scratch) for
+// 4 waves/SIMD: +20 % on the memory-latency-bound 100k..1M-triangle scenes, -15 % on Cornell.
+template <bool COUNT, int INTEG, int ACCEL, bool VOL, int MINW, bool EXT>
+__global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *__restrict__ scp,
+                                                                       const DevFrame *__restrict__ frp) {
+    __shared__ uint2 lds_stack[RT_STACK_LDS * RT_BLOCK];
+    constexpr bool POOL = MINW < RT_HIGH_OCC_WAVES;                       // the pooled-leaf scratch (19 KB) is only carried by the kernels that use it
+    constexpr int PN = POOL ? RT_BLOCK : 64;
+    __shared__ unsigned long long pool_key[PN];
+    __shared__ float4 pool_res[PN];
+    __shared__ unsigned pool_head[PN];
+    __shared__ float4 pool_ray[3 * PN];
+    const DevScene &sc = *scp;
+    const DevFrame &fr = *frp;
+    const unsigned wave0 = POOL ? (threadIdx.x & ~63u) : 0u;
+    const PoolLds pool = {(unsigned long long RT_L *)pool_key + wave0, (float4 RT_L *)pool_res + wave0, (unsigned RT_L *)pool_head + wave0,
+                          (float4 RT_L *)pool_ray + 3 * wave0};
+    const unsigned gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    Lane ln;
+    ln.stage = ST_FETCH; ln.has_ray = false; ln.fsp = 0; ln.tv.active = false; ln.tv.hit_prim = -1;
+    ln.L = mk3(0.f); ln.thr = mk3(1.f); ln.alpha = 0.f; ln.depth = 0; ln.specular = false;
+    TravCounters tc; tc.nodes = tc.leaf_refs = tc.tris = tc.spills = 0;
+    RT_PFT(tc.c_desc = tc.c_leaf = tc.n_chunks = tc.n_pooled = tc.n_iter = 0;)
+    unsigned c_cam = 0, c_closest = 0, c_any = 0, c_bad = 0;
+
+#ifdef RT_PROFILE
+    unsigned long long pf_shade = 0, pf_trav = 0, pf_outer = 0, pf_inner = 0, pf_rounds = 0, pf_act = 0, pf_rays = 0, pf_t0 = 0;
+#define RT_PF(x) x
+#else
+#define RT_PF(x)
+#endif
+    // phase gating (rt_integrate.h, stage_in_phase): sweeps alternate between the two halves of the path state machine;
+    // the first sweep is of the second kind (it contains the work fetch)
+    int phase = (INTEG == RT_INTEGRATOR_PATH && fr.phase_sync) ? 1 : -1;
+    for (;;) {
+        RT_PF(pf_t0 = __builtin_readcyclecounter(); ++pf_outer;)
+        // ---- shade / regenerate: run every lane that is not waiting on a ray until it is (or is out of work)
+        do {
+            RT_PF(++pf_inner;)
+            advance_pass<COUNT, INTEG, VOL, EXT>(sc, fr, ln, gtid, &c_closest, &c_any, &c_bad, phase);
+            const unsigned long long want = phase == 0 ? 0ull : __ballot(!ln.has_ray && ln.stage == ST_FETCH);
+            if (want) {                                                   // wave-aggregated work fetch
+                const int leader = __ffsll((long long)want) - 1;
+                unsigned long long base = 0;
+                if (lane == leader) base = atomicAdd(fr.work_counter, (unsigned long long)__popcll(want));
+                base = __shfl(base, leader);
+                if (!ln.has_ray && ln.stage == ST_FETCH) {
+                    const unsigned long long w = base + __popcll(want & ((1ull << lane) - 1ull));
+                    if (w >= fr.total_work) ln.stage = ST_EXIT;
+                    else {
+                        unsigned long long pixel; int s;
+                        if (work_to_sample(fr, w, pixel, s)) {
+                            Ray ray;
+                            setup_sample(sc, fr, ln, pixel, s, ray);
+                            ln.work = uint32_t(w);
+                            ln.L = mk3(0.f); ln.thr = mk3(1.f); ln.alpha = 0.f; ln.depth = 0; ln.fsp = 0;
+                            ln.specular = false;
+                            if (COUNT) ++c_cam;
+                            accel_begin<ACCEL>(ln.tv, sc, ray, false);
+                            if (VOL) vol_store_ray(fr, 0, gtid, ray);
+                            ln.has_ray = true; ln.stage = ST_VERTEX;
+                        }
+                    }
+                }
+            }
+        } while (__any(!ln.has_ray && stage_in_phase(ln.stage, phase)));
+        if (phase >= 0) phase ^= 1;
+        RT_PF({ unsigned long long t1 = __builtin_readcyclecounter(); pf_shade += t1 - pf_t0; pf_t0 = t1; pf_rays += __popcll(__ballot(ln.has_ray && ln.tv.active)); })
+        if (!__any(ln.has_ray)) {
+            if (!__any(ln.stage != ST_EXIT)) break;
+            continue;                                                     // everybody waits for the other kind of sweep
+        }
+        // ---- extend: one shared traversal loop.  Leave it early when only a few lanes are still traversing AND some
+        // lane could meanwhile shade / fetch (its traversal state stays in registers + LDS and resumes next round).
+        for (;;) {
+            const bool act = ln.has_ray && ln.tv.active;
+            const unsigned long long am = __ballot(act);
+            if (!am) break;
+            RT_PF(++pf_rounds; pf_act += __popcll(am);)
+            if (fr.exit_thresh > 0 && __popcll(am) <= fr.exit_thresh && __any(!act && ln.stage != ST_EXIT)) break;
+            if (fr.trav_mode == 1) accel_round<COUNT, ACCEL, EXT>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc);
+            else if (fr.trav_mode == 2) accel_round_batched<COUNT, ACCEL, EXT>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc);
+            else if (POOL && fr.trav_mode == 3) accel_round_pooled<COUNT, ACCEL, EXT>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc, pool);
+            else if (act) accel_step<COUNT, ACCEL, EXT>(ln.tv, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc);
+        }
+        if (ln.has_ray && !ln.tv.active) ln.has_ray = false;
+        RT_PF(pf_trav += __builtin_readcyclecounter() - pf_t0;)
+    }
+#ifdef RT_PROFILE
+    if (lane == 0) {
+        unsigned long long v[12] = {pf_shade, pf_trav, pf_outer, pf_inner, pf_rounds, pf_act, pf_rays, tc.c_desc, tc.c_leaf, tc.n_chunks, tc.n_pooled, tc.n_iter};
+        for (int k = 0; k < 12; ++k) atomicAdd(fr.counters + 8 + k, v[k]);
+    }
+#endif
+
+    if (COUNT) {
+        unsigned long long v[8] = {c_cam, c_closest, c_any, tc.nodes, tc.leaf_refs, tc.tris, c_bad, tc.spills};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            unsigned long long x = v[k];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+            if (lane == 0 && x) atomicAdd(fr.counters + k, x);
+        }
+    }
+}
+
+typedef void (*RenderKernelFn)(const DevScene *, const DevFrame *);
+
+}  // namespace rt

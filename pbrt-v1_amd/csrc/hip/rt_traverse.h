@@ -205,23 +205,24 @@ RT_DEV bool prim_test(const DevScene &sc, unsigned prim, V3 o, V3 d, float mint,
 // The LDS ring holds the TOP RT_STACK_LDS entries (slot = index mod RT_STACK_LDS); when it is full the OLDEST entry moves to
 // HBM, and a pop below the ring's base reads that entry back.  Pushes and pops cluster at the top of the stack, so a deep
 // tree (depth 34 at 1M triangles) costs a handful of HBM round trips per ray instead of one per push/pop beyond entry 12.
-template <bool COUNT>
+template <bool COUNT, int NS = RT_STACK_LDS>
 RT_DEV void stack_push(Trav &tv, uint2 e, uint2 RT_L *lds_stack, uint2 RT_G *spill, unsigned n_threads, unsigned gtid, TravCounters &cnt) {
-    if (tv.sp - tv.sbase == RT_STACK_LDS) {
-        const volatile uint2 RT_L *slot = (const volatile uint2 RT_L *)lds_stack + (unsigned(tv.sbase) % RT_STACK_LDS) * RT_BLOCK + threadIdx.x;
+    if (tv.sp - tv.sbase == NS) {
+        const volatile uint2 RT_L *slot = (const volatile uint2 RT_L *)lds_stack + (unsigned(tv.sbase) % NS) * RT_BLOCK + threadIdx.x;
         uint2 old; old.x = slot->x; old.y = slot->y;
         spill[size_t(tv.sbase) * n_threads + gtid] = old;
         ++tv.sbase;
         if (COUNT) ++cnt.spills;
     }
-    lds_stack[(unsigned(tv.sp) % RT_STACK_LDS) * RT_BLOCK + threadIdx.x] = e;
+    lds_stack[(unsigned(tv.sp) % NS) * RT_BLOCK + threadIdx.x] = e;
     ++tv.sp;
 }
+template <int NS = RT_STACK_LDS>
 RT_DEV uint2 stack_pop(Trav &tv, const uint2 RT_L *lds_stack, const uint2 RT_G *spill, unsigned n_threads, unsigned gtid) {
     --tv.sp;
     // always a ds_read_b64; the (rare) spilled entry overrides it -- written this way so that the two loads are
     // not merged into one FLAT load through a selected generic pointer
-    const volatile uint2 RT_L *slot = (const volatile uint2 RT_L *)lds_stack + (unsigned(tv.sp) % RT_STACK_LDS) * RT_BLOCK + threadIdx.x;
+    const volatile uint2 RT_L *slot = (const volatile uint2 RT_L *)lds_stack + (unsigned(tv.sp) % NS) * RT_BLOCK + threadIdx.x;
     uint2 e; e.x = slot->x; e.y = slot->y;             // volatile: keeps the LDS read a ds_read
     if (tv.sp < tv.sbase) { e = spill[size_t(tv.sp) * n_threads + gtid]; tv.sbase = tv.sp; }
     return e;
@@ -382,7 +383,7 @@ RT_DEV void grid_step(Trav &tv, const DevScene &sc, TravCounters &cnt) {
 // counters are unchanged); what changes is how the 64 lanes are interleaved: all lanes first walk interior nodes
 // (cheap) until each sits at a leaf, then the expensive ray-triangle tests run with every lane that has a primitive
 // left -- instead of one lane's 8-triangle leaf serialising against 63 lanes doing 20-instruction plane tests.
-template <bool COUNT>
+template <bool COUNT, int NS = RT_STACK_LDS>
 RT_DEV void kd_descend(Trav &tv, const DevScene &sc, uint2 RT_L *lds_stack, uint2 RT_G *spill, unsigned n_threads, unsigned gtid, TravCounters &cnt) {
     if (!tv.any && tv.maxt < tv.tmin) { tv.active = false; return; }      // kdtree.cpp:330
 #ifdef RT_PAIR_FETCH
@@ -410,7 +411,7 @@ RT_DEV void kd_descend(Trav &tv, const DevScene &sc, uint2 RT_L *lds_stack, uint
     if (tplane > tv.tmax || tplane <= 0.f) tv.node = first;
     else if (tplane < tv.tmin) tv.node = second;
     else {
-        stack_push<COUNT>(tv, make_uint2(second, __float_as_uint(tv.tmax)), lds_stack, spill, n_threads, gtid, cnt);
+        stack_push<COUNT, NS>(tv, make_uint2(second, __float_as_uint(tv.tmax)), lds_stack, spill, n_threads, gtid, cnt);
         tv.node = first;
         tv.tmax = tplane;
     }
@@ -433,10 +434,11 @@ RT_DEV void leaf_test_one(Trav &tv, const DevScene &sc, TravCounters &cnt) {
         tv.maxt = t; tv.hit_prim = int(prim); tv.b1 = b1; tv.b2 = b2;
     }
 }
+template <int NS = RT_STACK_LDS>
 RT_DEV void kd_leaf_done(Trav &tv, const uint2 RT_L *lds_stack, const uint2 RT_G *spill, unsigned n_threads, unsigned gtid) {
     tv.at_leaf = false;
     if (tv.sp > 0) {
-        const uint2 e = stack_pop(tv, lds_stack, spill, n_threads, gtid);
+        const uint2 e = stack_pop<NS>(tv, lds_stack, spill, n_threads, gtid);
         tv.node = e.x; tv.tmin = tv.tmax; tv.tmax = __uint_as_float(e.y);
     } else tv.active = false;
 }
@@ -614,7 +616,7 @@ RT_DEV void accel_round_pooled(Trav &tv, bool mine, const DevScene &sc, uint2 RT
 #ifndef RT_BATCH_K
 #define RT_BATCH_K 16
 #endif
-template <bool COUNT, int ACCEL, bool EXT>
+template <bool COUNT, int ACCEL, bool EXT, int NS = RT_STACK_LDS>
 RT_DEV void accel_round_batched(Trav &tv, bool mine, const DevScene &sc, uint2 RT_L *lds_stack, uint2 RT_G *spill, unsigned n_threads,
                                 unsigned gtid, TravCounters &cnt) {
     const bool act = mine && tv.active;
@@ -623,13 +625,13 @@ RT_DEV void accel_round_batched(Trav &tv, bool mine, const DevScene &sc, uint2 R
     const int nd = __popcll(__ballot(desc)), nl = __popcll(__ballot(leafw));
     if (desc) {
         if (ACCEL == RT_ACCEL_GRID) grid_enter_voxel<COUNT>(tv, sc, cnt);
-        else kd_descend<COUNT>(tv, sc, lds_stack, spill, n_threads, gtid, cnt);
+        else kd_descend<COUNT, NS>(tv, sc, lds_stack, spill, n_threads, gtid, cnt);
     }
     if (nl && (nl >= RT_BATCH_K || nd == 0)) {
         if (leafw) leaf_test_one<COUNT, ACCEL == RT_ACCEL_GRID, EXT>(tv, sc, cnt);
     }
     if (mine && tv.active && tv.at_leaf && tv.li >= tv.ln_) {
-        if (ACCEL == RT_ACCEL_GRID) grid_voxel_done(tv, sc); else kd_leaf_done(tv, lds_stack, spill, n_threads, gtid);
+        if (ACCEL == RT_ACCEL_GRID) grid_voxel_done(tv, sc); else kd_leaf_done<NS>(tv, lds_stack, spill, n_threads, gtid);
     }
 }
 

@@ -1,0 +1,62 @@
+"""GPU box: rebuild only rt_trace.hip with -D knobs, relink, and time the 1 M-triangle path frame through the queue pipeline.
+usage: python tools/r02_trace_scan.py <group>"""
+import json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+HIP = os.path.join(ROOT, "pbrt-v1_amd", "csrc", "hip")
+LIBD = os.path.join(ROOT, "pbrt-v1_amd", "lib")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-value"]
+UNITS = ("rt_kernels", "rt_trace", "rt_mega_w", "rt_mega_d", "rt_mega_p", "rt_pipe_w", "rt_pipe_d", "rt_pipe_p", "kd_build", "grid_build")
+
+
+def rebuild(unit, defs):
+    src = os.path.join(HIP, unit + (".cpp" if unit.endswith("build") else ".hip"))
+    subprocess.check_call(["hipcc"] + FLAGS + list(defs) + ["-c", src, "-o", os.path.join(LIBD, "obj", unit + ".o")], stderr=subprocess.DEVNULL)
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + [os.path.join(LIBD, "obj", u + ".o") for u in UNITS] +
+                          ["-o", os.path.join(LIBD, "libpbrt_hip.so")])
+
+
+def bench(tag, env=None, workload="p1000000", steps=3):
+    e = dict(os.environ); e.update(env or {}); e.setdefault("PBRT_HIP_PIPELINE", "1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--steps", str(steps), "--warmup", "1", "--workload", workload],
+                       env=e, capture_output=True, text=True, timeout=400)
+    try:
+        j = json.loads(r.stdout.strip().splitlines()[-1]); ro = j["roofline"]
+        print(json.dumps(dict(tag=tag, workload=workload, Mrays=j["value"], ms=j["ms_per_step"], trace_ms=ro["kernel_ms"], frac=ro["frac"],
+                              render_ms=ro["frame_kernels_ms"]["render"], iters=ro["pipeline_iterations"], slots=ro["pipeline_slots"])), flush=True)
+    except Exception as ex:
+        print(json.dumps(dict(tag=tag, error=str(ex), stderr=r.stderr[-400:])), flush=True)
+
+
+def main():
+    g = sys.argv[1] if len(sys.argv) > 1 else "occ"
+    if g == "occ":
+        for w in (8, 6, 5, 4, 3):
+            rebuild("rt_trace", ["-DRT_TRACE_WAVES=%d" % w])
+            bench("waves%d" % w)
+        rebuild("rt_trace", ["-DRT_TRACE_WAVES=8", "-DRT_TRACE_REFILL=32"]); bench("waves8_refill32")
+        rebuild("rt_trace", ["-DRT_TRACE_WAVES=8", "-DRT_TRACE_REFILL=8"]); bench("waves8_refill8")
+        rebuild("rt_trace", ["-DRT_TRACE_WAVES=8", "-DRT_BATCH_K=8"]); bench("waves8_batch8")
+        rebuild("rt_trace", ["-DRT_TRACE_WAVES=8", "-DRT_BATCH_K=32"]); bench("waves8_batch32")
+        rebuild("rt_trace", [])
+        for sl in (1 << 20, 1 << 23):
+            bench("slots%d" % sl, env={"PBRT_HIP_PIPE_SLOTS": str(sl)})
+    elif g == "loop":
+        for L in (0, 1, 2):
+            rebuild("rt_trace", ["-DRT_TRACE_LOOP=%d" % L, "-DRT_TRACE_REFILL=32"]); bench("loop%d_refill32" % L)
+        for bpc in (8, 6, 4, 3, 2):
+            bench("loop2_blocks%d" % bpc, env={"PBRT_HIP_TRACE_BLOCKS_PER_CU": str(bpc)})
+        for ds, lm in ((2, 12), (8, 12), (4, 4), (4, 24), (16, 24), (64, 1)):
+            rebuild("rt_trace", ["-DRT_TRACE_REFILL=32", "-DRT_TRACE_DSTEPS=%d" % ds, "-DRT_TRACE_LEAF_MIN=%d" % lm]); bench("loop2_dsteps%d_leafmin%d" % (ds, lm))
+        rebuild("rt_trace", ["-DRT_TRACE_REFILL=48"]); bench("loop2_refill48")
+        rebuild("rt_trace", ["-DRT_TRACE_REFILL=64"]); bench("loop2_refill64")
+        rebuild("rt_trace", [])
+    elif g == "defs":
+        defs = sys.argv[2].split(",") if len(sys.argv) > 2 and sys.argv[2] else []
+        rebuild("rt_trace", defs)
+        for wl in sys.argv[3:] or ["p1000000"]:
+            bench("defs:" + " ".join(defs), workload=wl)
+
+
+if __name__ == "__main__":
+    main()
