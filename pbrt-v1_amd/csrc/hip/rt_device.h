@@ -55,6 +55,11 @@ struct DevScene {
                                // the geometric normal and BSDF tangent are constants of the triangle, precomputed on the host with
                                // the reference's expressions (rt_shade.h tri_frame) instead of two normalisations per vertex
     const uint2 *nodes;
+    const uint2 *tnodes;       // trace kernel (rt_pipeline.h): the same nodes, but a leaf's word 1 is the position (in float4 units) of its
+                               // primitives in `ltris`
+    const float4 *ltris;       // triangle records in LEAF order: the n primitives of a leaf are n consecutive 48-byte records (p1, e1, e2 as
+                               // in DevTri, the primitive's index in q2.w), placed so that a leaf touches the fewest 128-byte lines: one
+                               // gather fetches what the mesh-order layout needs a leaf-list read plus 1.25 lines per triangle for
     const unsigned *leaf_refs;
     const DevMaterial *materials;
     const DevLight *lights;

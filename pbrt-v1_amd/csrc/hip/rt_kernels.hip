@@ -207,7 +207,7 @@ using namespace rt;
 // (EXT: powf and the second lobe cost ~17 VGPRs, one wave per SIMD less for DirectLighting).  `variant` keeps round 1's numbering:
 // ((VOL*2 + ACCEL)*2 + COUNT)*3 + INTEG | 24 + (VOL*2 + ACCEL)*3 + INTEG | 36 + (VOL*2 + ACCEL)*3 + INTEG.
 namespace rt { extern const RenderKernelFn g_render_kernels_whitted[16], g_render_kernels_direct[16], g_render_kernels_path[16]; }
-namespace rt { extern const PipeShadeFn g_pipe_shade_whitted[6], g_pipe_shade_direct[6], g_pipe_shade_path[6]; extern const PipeTraceFn g_pipe_trace[6]; }
+namespace rt { extern const PipeShadeFn g_pipe_shade_whitted[6], g_pipe_shade_direct[6], g_pipe_shade_path[6]; extern const PipeTraceFn g_pipe_trace[8]; }
 static RenderKernelFn render_kernel_of(int variant) {
     const RenderKernelFn *t = (variant % 3 == 0) ? g_render_kernels_whitted : (variant % 3 == 1) ? g_render_kernels_direct : g_render_kernels_path;
     return t[variant < 24 ? variant / 3 : variant < 36 ? 8 + (variant - 24) / 3 : 12 + (variant - 36) / 3];
@@ -258,10 +258,11 @@ struct RtScene {
     bool have_timing = false;
     bool counting = true;
     uint32_t n_tris = 0;
+    size_t n_leaf_tri_units = 0;
     // queue pipeline (rt_pipeline.h)
     PipePool pool{}; unsigned pool_cap = 0; int pool_vec = 0; PipePool *dev_pool = nullptr;
     unsigned *h_qcount = nullptr;                       // page-locked mirror of pool.q_count (termination test)
-    unsigned trace_grids[6] = {0};
+    unsigned trace_grids[8] = {0};
     std::vector<hipEvent_t> pipe_ev;                    // [2 * RT_PIPE_TIMED] around the trace launches, [.. + RT_PIPE_QN / 4] batch fences
     std::vector<hipEvent_t> pipe_fence;
     bool last_pipeline = false; int pipe_iters = 0, pipe_timed = 0; unsigned pipe_slots = 0;
@@ -289,6 +290,35 @@ static void host_tri_frame(const float *v, bool flip, float nn[3], float sn[3]) 
     for (int a = 0; a < 3; ++a) { nn[a] = c[a] * inv; if (flip) nn[a] = -1.f * nn[a]; }
     inv = 1.f / sqrtf(dpdu[0] * dpdu[0] + dpdu[1] * dpdu[1] + dpdu[2] * dpdu[2]);
     for (int a = 0; a < 3; ++a) sn[a] = dpdu[a] * inv;
+}
+
+// Triangle records in leaf order for the trace kernel (rt_device.h DevScene::ltris / tnodes).  A leaf with n primitives gets n
+// consecutive 48-byte records; its run starts at a 128-byte boundary whenever starting where the previous leaf ended would make
+// it touch more 128-byte lines than necessary (measured: one L2 miss costs the same whether 8 or 128 bytes of the line are used,
+// ~56 G misses/s for the whole chip, and the 1 M-triangle frame makes 17 triangle tests per ray).
+static void build_leaf_order(const std::vector<Node> &nodes, const std::vector<uint32_t> &leaf_refs, const std::vector<DevTri> &tris,
+                             std::vector<Node> &tnodes, std::vector<float4> &ltris) {
+    tnodes = nodes;
+    ltris.clear();
+    size_t off = 0;                                       // float4 units (16 B); a line is 8 units
+    for (size_t i = 0; i < nodes.size(); ++i) {
+        const Node &n = nodes[i];
+        if ((n.x & 3u) != 3u) continue;
+        const uint32_t np = n.x >> 2;
+        if (np == 0) { tnodes[i].y = 0u; continue; }
+        const size_t units = size_t(np) * 3;
+        const size_t lines_here = (off % 8 + units + 7) / 8, lines_min = (units + 7) / 8;
+        if (lines_here > lines_min) off = (off + 7) / 8 * 8;
+        ltris.resize(off + units, make_float4(0.f, 0.f, 0.f, 0.f));
+        for (uint32_t k = 0; k < np; ++k) {
+            const uint32_t prim = np == 1 ? n.y : leaf_refs[n.y + k];
+            float4 q2 = tris[prim].q2; std::memcpy(&q2.w, &prim, 4);
+            ltris[off + 3 * k] = tris[prim].q0; ltris[off + 3 * k + 1] = tris[prim].q1; ltris[off + 3 * k + 2] = q2;
+        }
+        tnodes[i].y = uint32_t(off);
+        off += units;
+    }
+    if (ltris.empty()) ltris.resize(8, make_float4(0.f, 0.f, 0.f, 0.f));
 }
 
 template <class T>
@@ -326,15 +356,18 @@ static int render_pipeline(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, int
     if (n_slots > s->pool_cap) {
         HIPCHK(hipStreamSynchronize(s->stream));
         HIPWARN(hipFree(s->pool.state)); HIPWARN(hipFree(s->pool.ray_o)); HIPWARN(hipFree(s->pool.hit)); HIPWARN(hipFree(s->pool.q_o)); HIPWARN(hipFree(s->pool.q_slot));
-        s->pool = PipePool{}; s->pool_cap = 0;
+        { unsigned *qc = s->pool.q_count; unsigned long long *ww = s->pool.wave_work; s->pool = PipePool{}; s->pool.q_count = qc; s->pool.wave_work = ww; }
+        s->pool_cap = 0;
         HIPCHK(hipMalloc((void **)&s->pool.state, size_t(vec) * n_slots * sizeof(float4)));
         HIPCHK(hipMalloc((void **)&s->pool.ray_o, size_t(2) * n_slots * sizeof(float4)));
         HIPCHK(hipMalloc((void **)&s->pool.hit, size_t(n_slots) * sizeof(float4)));
         HIPCHK(hipMalloc((void **)&s->pool.q_o, size_t(4) * n_slots * sizeof(float4)));
         HIPCHK(hipMalloc((void **)&s->pool.q_slot, size_t(2) * n_slots * sizeof(unsigned)));
+        HIPWARN(hipFree(s->pool.wave_work)); s->pool.wave_work = nullptr;
+        HIPCHK(hipMalloc((void **)&s->pool.wave_work, size_t(n_slots / 64 + 1) * 2 * sizeof(unsigned long long)));
         s->pool_cap = n_slots;
     }
-    if (!s->pool.q_count) HIPCHK(hipMalloc((void **)&s->pool.q_count, RT_PIPE_QN * 4 * sizeof(unsigned)));
+    if (!s->pool.q_count) HIPCHK(hipMalloc((void **)&s->pool.q_count, size_t(RT_PIPE_QN) * RT_QC_STRIDE * sizeof(unsigned)));
     PipePool pl = s->pool;
     pl.n_slots = n_slots; pl.ray_d = pl.ray_o + n_slots; pl.q_d = pl.q_o + size_t(2) * n_slots;
     // per-slot scratch of the state machine: recursion frames (whitted / directlighting), volume march state
@@ -355,12 +388,13 @@ static int render_pipeline(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, int
     const int f = s->counting ? 1 : (s->has_ext ? 2 : 0);
     const PipeShadeFn *st = integ == RT_INTEGRATOR_WHITTED ? g_pipe_shade_whitted : integ == RT_INTEGRATOR_DIRECT ? g_pipe_shade_direct : g_pipe_shade_path;
     const PipeShadeFn shade = st[(s->volume.present ? 3 : 0) + f];
-    const int tk = (s->accel_kind == RT_ACCEL_GRID ? 3 : 0) + f;
+    const int tk = (s->accel_kind == RT_ACCEL_GRID ? 4 : 0) + (s->counting ? (s->has_ext ? 1 : 3) : (s->has_ext ? 2 : 0));
     const PipeTraceFn trace = g_pipe_trace[tk];
     HIPCHK(hipMemcpyAsync(s->dev_frame, &fr, sizeof(DevFrame), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemcpyAsync(s->dev_pool, &pl, sizeof(PipePool), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemsetAsync(s->work_counter, 0, sizeof(unsigned long long), s->stream));
     HIPCHK(hipMemsetAsync(pl.state + n_slots, 0, size_t(n_slots) * sizeof(float4), s->stream));      // control words: every slot in ST_FETCH
+    HIPCHK(hipMemsetAsync(pl.wave_work, 0, size_t(n_slots / 64 + 1) * 2 * sizeof(unsigned long long), s->stream));
     HIPCHK(hipEventRecord(s->ev0, s->stream));
     int iter = 0, checked = 0, batch = 0;
     bool done = false;
@@ -368,28 +402,36 @@ static int render_pipeline(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, int
     while (!done) {
         for (int k = 0; k < RT_PIPE_BATCH; ++k, ++iter) {
             const unsigned qi = unsigned(iter % RT_PIPE_QN);
-            HIPCHK(hipMemsetAsync(pl.q_count + 4 * qi, 0, 4 * sizeof(unsigned), s->stream));
+            HIPCHK(hipMemsetAsync(pl.q_count + size_t(RT_QC_STRIDE) * qi, 0, RT_QC_STRIDE * sizeof(unsigned), s->stream));
             hipLaunchKernelGGL(shade, dim3(n_slots / RT_BLOCK), dim3(RT_BLOCK), 0, s->stream, (const DevScene *)s->dev_scene,
                                (const DevFrame *)s->dev_frame, (const PipePool *)s->dev_pool, qi);
             TraceJob job{};
-            job.q_o = pl.q_o; job.q_d = pl.q_d; job.q_slot = pl.q_slot; job.q_count = pl.q_count + 4 * qi; job.hit = pl.hit;
+            job.q_o = pl.q_o; job.q_d = pl.q_d; job.q_slot = pl.q_slot; job.q_count = pl.q_count + size_t(RT_QC_STRIDE) * qi; job.hit = pl.hit;
             job.n_slots = n_slots; job.spill = s->spill; job.n_threads = s->n_threads; job.counters = s->counters;
             if (iter < RT_PIPE_TIMED) HIPCHK(hipEventRecord(s->pipe_ev[2 * iter], s->stream));
             hipLaunchKernelGGL(trace, dim3(s->trace_grids[tk]), dim3(RT_BLOCK), 0, s->stream, (const DevScene *)s->dev_scene, job);
             if (iter < RT_PIPE_TIMED) HIPCHK(hipEventRecord(s->pipe_ev[2 * iter + 1], s->stream));
-            HIPCHK(hipMemcpyAsync(s->h_qcount + 4 * qi, pl.q_count + 4 * qi, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
+            HIPCHK(hipMemcpyAsync(s->h_qcount + size_t(RT_QC_STRIDE) * qi, pl.q_count + size_t(RT_QC_STRIDE) * qi, (RT_QC_ANY + 1) * sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(s->pipe_fence[batch % (RT_PIPE_QN / RT_PIPE_BATCH)], s->stream));
         if (batch >= 1) {                                                   // look at the batch before the one just launched
             HIPCHK(hipEventSynchronize(s->pipe_fence[(batch - 1) % (RT_PIPE_QN / RT_PIPE_BATCH)]));
             for (int k = 0; k < RT_PIPE_BATCH; ++k, ++checked) {
-                const unsigned *q = s->h_qcount + 4 * (checked % RT_PIPE_QN);
-                if (q[0] + q[1] == 0) { done = true; break; }
+                const unsigned *q = s->h_qcount + size_t(RT_QC_STRIDE) * (checked % RT_PIPE_QN);
+                if (q[0] + q[RT_QC_ANY] == 0) { done = true; break; }
             }
         }
         ++batch;
         if (iter > max_iters) return fail(RT_ESTATE, "rt_render: the queue pipeline did not terminate");
+    }
+    if (std::getenv("PBRT_HIP_PIPE_TRACE_LOG")) {               // per-iteration queue sizes and trace-kernel times (experiments)
+        HIPCHK(hipStreamSynchronize(s->stream));
+        for (int i = 0; i <= checked && i < RT_PIPE_TIMED; ++i) {
+            float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, s->pipe_ev[2 * i], s->pipe_ev[2 * i + 1]));
+            const unsigned *q = s->h_qcount + size_t(RT_QC_STRIDE) * (i % RT_PIPE_QN);
+            std::fprintf(stderr, "PIPE iter %d closest %u any %u trace_ms %.3f Mrays/s %.0f\n", i, q[0], q[RT_QC_ANY], ms, (q[0] + q[RT_QC_ANY]) / (ms * 1e3 + 1e-9));
+        }
     }
     s->pipe_slots = n_slots; s->pipe_iters = checked + 1; s->pipe_timed = std::min(s->pipe_iters, RT_PIPE_TIMED);
     HIPCHK(hipEventRecord(s->ev1, s->stream));
@@ -499,6 +541,18 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
         if ((rc = upload(s, padded.data(), padded.size(), &nodes_dev))) return rc;
     }
     s->dev.nodes = nodes_dev;
+    s->dev.tnodes = nodes_dev;
+    if (s->accel_kind == RT_ACCEL_KDTREE) {
+        std::vector<Node> tn; std::vector<float4> lt;
+        build_leaf_order(s->tree.nodes, s->tree.leaf_refs, tris, tn, lt);
+        if (lt.size() >= (size_t(1) << 32)) return fail(RT_EINVAL, "rt_scene_create: leaf-ordered triangle array beyond 2^32 float4 units");
+        tn.push_back(Node{3u, 0u});
+        const Node *tdev = nullptr;
+        if ((rc = upload(s, tn.data(), tn.size(), &tdev))) return rc;
+        s->dev.tnodes = reinterpret_cast<const uint2 *>(tdev);
+        if ((rc = upload(s, lt.data(), lt.size(), &s->dev.ltris))) return rc;
+        s->n_leaf_tri_units = lt.size();
+    }
     if ((rc = upload(s, s->tree.leaf_refs.data(), s->tree.leaf_refs.size(), &s->dev.leaf_refs))) return rc;
 
     // materials (OrenNayar constants: reflection.h:268-277)
@@ -594,7 +648,7 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
     HIPCHK(hipMalloc((void **)&s->dev_frame, sizeof(DevFrame)));
     HIPCHK(hipMemcpy(s->dev_scene, &s->dev, sizeof(DevScene), hipMemcpyHostToDevice));
     HIPCHK(hipEventCreate(&s->ev2));
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < 8; ++k) {
         int per_cu = 0;
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)g_pipe_trace[k], RT_BLOCK, 0));
         if (const char *e = std::getenv("PBRT_HIP_TRACE_BLOCKS_PER_CU")) per_cu = std::min(per_cu, std::max(1, std::atoi(e)));   // occupancy experiments
@@ -603,8 +657,8 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
     }
     HIPCHK(hipMalloc((void **)&s->spill, size_t(s->spill_depth) * s->n_threads * sizeof(uint2)));
     HIPCHK(hipMalloc((void **)&s->dev_pool, sizeof(PipePool)));
-    HIPCHK(hipMalloc((void **)&s->trace_qc, 4 * sizeof(unsigned)));
-    HIPCHK(hipHostMalloc((void **)&s->h_qcount, RT_PIPE_QN * 4 * sizeof(unsigned), hipHostMallocDefault));
+    HIPCHK(hipMalloc((void **)&s->trace_qc, RT_QC_STRIDE * sizeof(unsigned)));
+    HIPCHK(hipHostMalloc((void **)&s->h_qcount, size_t(RT_PIPE_QN) * RT_QC_STRIDE * sizeof(unsigned), hipHostMallocDefault));
     HIPCHK(hipStreamSynchronize(s->stream));
     guard.p = nullptr;
     *out = s;
@@ -624,7 +678,7 @@ int rt_scene_destroy(RtScene *s) {
     if (s->vol_buf) HIPWARN(hipFree(s->vol_buf));
     HIPWARN(hipFree(s->dev_scene)); HIPWARN(hipFree(s->dev_frame));
     HIPWARN(hipFree(s->pool.state)); HIPWARN(hipFree(s->pool.ray_o)); HIPWARN(hipFree(s->pool.hit)); HIPWARN(hipFree(s->pool.q_o));
-    HIPWARN(hipFree(s->pool.q_slot)); HIPWARN(hipFree(s->pool.q_count)); HIPWARN(hipFree(s->dev_pool));
+    HIPWARN(hipFree(s->pool.q_slot)); HIPWARN(hipFree(s->pool.q_count)); HIPWARN(hipFree(s->pool.wave_work)); HIPWARN(hipFree(s->dev_pool));
     HIPWARN(hipFree(s->trace_buf)); HIPWARN(hipFree(s->trace_qc));
     if (s->h_qcount) HIPWARN(hipHostFree(s->h_qcount));
     for (hipEvent_t e : s->pipe_ev) HIPWARN(hipEventDestroy(e));
@@ -794,7 +848,7 @@ static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool nee
         if (const char *e = std::getenv("PBRT_HIP_PIPELINE")) fr.pipeline = std::atoi(e) != 0;
         if (fr.max_depth > 250 || fr.max_depth < 0) fr.pipeline = 0;     // the slot's control word holds depth in 8 bits
         if (fr.trav_mode == 3 && fr.high_occupancy) fr.trav_mode = 1;   // the high-occupancy kernels carry no pooled-leaf scratch
-        if (fr.trav_mode < 0 || fr.trav_mode > 3) fr.trav_mode = 1;
+        if (fr.trav_mode < 0 || fr.trav_mode > 4) fr.trav_mode = 1;
     }
     fr.work_counter = s->work_counter; fr.counters = s->counters; fr.spill = s->spill; fr.n_threads = s->n_threads;
     fr.frames = s->frames;
@@ -834,13 +888,14 @@ static int trace_common(RtScene *s, const RtRay *rays, uint32_t n, int any, RtHi
         host[i] = make_float4(rays[i].o[0], rays[i].o[1], rays[i].o[2], rays[i].mint);
         host[size_t(n) + i] = make_float4(rays[i].d[0], rays[i].d[1], rays[i].d[2], rays[i].maxt);
     }
-    const unsigned qc[4] = {any ? 0u : n, any ? n : 0u, 0u, 0u};
+    unsigned qc[RT_QC_STRIDE] = {0};
+    qc[0] = any ? 0u : n; qc[RT_QC_ANY] = any ? n : 0u;
     HIPCHK(hipMemcpyAsync(s->trace_buf, host.data(), host.size() * sizeof(float4), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemcpyAsync(s->trace_qc, qc, sizeof qc, hipMemcpyHostToDevice, s->stream));
     TraceJob job{};
     job.q_o = s->trace_buf; job.q_d = s->trace_buf + n; job.q_slot = nullptr; job.q_count = s->trace_qc; job.hit = s->trace_buf + 2 * size_t(n);
     job.n_slots = 0; job.spill = s->spill; job.n_threads = s->n_threads; job.counters = s->counters;
-    const int k = (s->accel_kind == RT_ACCEL_GRID ? 3 : 0) + 1;
+    const int k = (s->accel_kind == RT_ACCEL_GRID ? 4 : 0) + (s->has_ext ? 1 : 3);
     HIPWARN(hipEventRecord(s->ev0, s->stream));
     hipLaunchKernelGGL(g_pipe_trace[k], dim3(s->trace_grids[k]), dim3(RT_BLOCK), 0, s->stream, (const DevScene *)s->dev_scene, job);
     HIPWARN(hipEventRecord(s->ev1, s->stream)); HIPWARN(hipEventRecord(s->ev2, s->stream)); s->have_timing = true; s->last_pipeline = false;

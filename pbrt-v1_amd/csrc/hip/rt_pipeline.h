@@ -28,7 +28,7 @@
 #define RT_TRACE_STACK 8          // LDS ring entries per lane in the trace kernel: 8 x 8 B x 256 = 16 KB per workgroup, 8 workgroups per CU
 #endif
 #ifndef RT_TRACE_REFILL
-#define RT_TRACE_REFILL 16        // a wave refills its idle lanes from the queue when at least this many are idle
+#define RT_TRACE_REFILL 32        // a wave refills its idle lanes from the queue when at least this many are idle
 #endif
 
 namespace rt {
@@ -42,8 +42,14 @@ struct PipePool {
     float4 *hit;                  // [n_slots] {prim, t, b1, b2} written by the trace kernel
     float4 *q_o, *q_d;            // [2][n_slots] compacted queues: closest-hit rays in [0, n), any-hit rays in [n_slots, n_slots + m)
     unsigned *q_slot;             // [2][n_slots] slot of each queued ray
-    unsigned *q_count;            // [iterations][4] {n closest, n any, consumer head, -}
+    unsigned *q_count;            // [iterations][RT_QC_STRIDE]: n closest at +0, consumer head at +RT_QC_HEAD, n any at +RT_QC_ANY
+                                  // (three different 64-byte lines: each is the target of one kernel's atomics)
+    unsigned long long *wave_work; // [n_slots / 64][2] {next, end}: the chunk of camera samples a wave of the shade kernel owns
 };
+#define RT_QC_STRIDE 64
+#define RT_QC_HEAD 16
+#define RT_QC_ANY 32
+#define RT_WORK_CHUNK 128         // camera samples a shade wave takes from the global work counter at a time
 
 // ---- slot state <-> Lane ----------------------------------------------------------------------------------------
 // ctl word: stage (4 bits) | has_ray << 4 | specular << 5 | any << 6 | depth << 8 | fsp << 16
@@ -115,7 +121,13 @@ __global__ __launch_bounds__(RT_BLOCK) void pipe_shade_kernel(const DevScene *__
     ln.v.p = ln.v.nn = ln.v.sn = ln.v.tn = ln.v.wo = mk3(0.f); ln.v.mat = 0; ln.v.light = -1;
     ln.li = ln.lj = 0; ln.cur_light = 0; ln.Ld = ln.Ld_light = ln.L_all = ln.pend = mk3(0.f); ln.bs1 = ln.bs2 = ln.bcs = 0.f;
     pipe_load<INTEG>(pl, fr, slot, ln);
-    if (!__any(ln.stage != ST_EXIT)) return;
+    if (!__syncthreads_or(ln.stage != ST_EXIT)) return;
+    __shared__ unsigned blk_cnt[2], blk_base[2];
+    if (threadIdx.x < 2) blk_cnt[threadIdx.x] = 0u;
+    // this wave's chunk of the work list (wave-uniform): 64 K waves hammering ONE counter cost more than the shading itself
+    // (measured: 1.1 ms per pass, ~0.15 ms of it arithmetic); a wave now goes to the global counter once per RT_WORK_CHUNK samples
+    unsigned long long RT_G *ww = RT_GPTR(unsigned long long, pl.wave_work) + size_t(slot >> 6) * 2;
+    unsigned long long w_next = ww[0], w_end = ww[1];
     if (ln.has_ray) {                                                   // the ray this slot was waiting for has been traced
         const float4 ro = RT_GPTR(const float4, pl.ray_o)[slot], rd = RT_GPTR(const float4, pl.ray_d)[slot];
         const float4 h = RT_GPTR(const float4, pl.hit)[slot];
@@ -129,13 +141,17 @@ __global__ __launch_bounds__(RT_BLOCK) void pipe_shade_kernel(const DevScene *__
     do {
         advance_pass<COUNT, INTEG, VOL, EXT, true>(sc, fr, ln, slot, &c_closest, &c_any, &c_bad, -1);
         const unsigned long long want = __ballot(!ln.has_ray && ln.stage == ST_FETCH);
-        if (want) {                                                     // wave-aggregated work fetch (as in render_kernel)
-            const int leader = __ffsll((long long)want) - 1;
-            unsigned long long base = 0;
-            if (lane == leader) base = atomicAdd(fr.work_counter, (unsigned long long)__popcll(want));
-            base = __shfl(base, leader);
+        if (want) {                                                     // work fetch from the wave's chunk
+            const unsigned n_want = unsigned(__popcll(want));
+            const unsigned long long have = w_end - w_next;             // what is left of the chunk is used first, the rest comes from a fresh one
+            unsigned long long fresh = 0;
+            if (have < n_want) {                                        // wave-uniform branch
+                if (lane == 0) fresh = atomicAdd(fr.work_counter, (unsigned long long)RT_WORK_CHUNK);
+                fresh = __shfl(fresh, 0);
+            }
             if (!ln.has_ray && ln.stage == ST_FETCH) {
-                const unsigned long long w = base + __popcll(want & ((1ull << lane) - 1ull));
+                const unsigned long long r = __popcll(want & ((1ull << lane) - 1ull));
+                const unsigned long long w = r < have ? w_next + r : fresh + (r - have);
                 if (w >= fr.total_work) ln.stage = ST_EXIT;
                 else {
                     unsigned long long pixel; int s;
@@ -151,20 +167,30 @@ __global__ __launch_bounds__(RT_BLOCK) void pipe_shade_kernel(const DevScene *__
                     }
                 }
             }
+            if (have < n_want) { w_next = fresh + (n_want - have); w_end = fresh + RT_WORK_CHUNK; }
+            else w_next += n_want;
         }
     } while (__any(!ln.has_ray && ln.stage != ST_EXIT));
-    // ---- enqueue: ballot compaction per ray kind, one atomic per wave and kind
+    if (lane == 0) { ww[0] = w_next; ww[1] = w_end; }
+    // ---- enqueue: ballot compaction per ray kind inside the wave, LDS atomics inside the workgroup, ONE global atomic per
+    // workgroup and kind (the two counters sit on different cache lines)
     {
-        unsigned RT_G *qc = RT_GPTR(unsigned, pl.q_count) + size_t(iter) * 4;
+        unsigned RT_G *qc = RT_GPTR(unsigned, pl.q_count) + size_t(iter) * RT_QC_STRIDE;
         const unsigned long long mc = __ballot(ln.has_ray && !ln.tv.any), ma = __ballot(ln.has_ray && ln.tv.any);
-        unsigned bc = 0, ba = 0;
-        if (mc && lane == __ffsll((long long)mc) - 1) bc = atomicAdd((unsigned *)qc, unsigned(__popcll(mc)));
-        if (ma && lane == __ffsll((long long)ma) - 1) ba = atomicAdd((unsigned *)(qc + 1), unsigned(__popcll(ma)));
-        if (mc) bc = __shfl(bc, __ffsll((long long)mc) - 1);
-        if (ma) ba = __shfl(ba, __ffsll((long long)ma) - 1);
+        unsigned wc = 0, wa = 0;
+        __syncthreads();                                                // blk_cnt zeroed
+        if (lane == 0) {
+            if (mc) wc = atomicAdd(&blk_cnt[0], unsigned(__popcll(mc)));
+            if (ma) wa = atomicAdd(&blk_cnt[1], unsigned(__popcll(ma)));
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && blk_cnt[0]) blk_base[0] = atomicAdd((unsigned *)qc, blk_cnt[0]);
+        if (threadIdx.x == 64 && blk_cnt[1]) blk_base[1] = atomicAdd((unsigned *)(qc + RT_QC_ANY), blk_cnt[1]);
+        __syncthreads();
+        wc = __shfl(wc, 0) + blk_base[0]; wa = __shfl(wa, 0) + blk_base[1];
         if (ln.has_ray) {
             const unsigned long long below = (1ull << lane) - 1ull;
-            const size_t q = ln.tv.any ? size_t(pl.n_slots) + ba + __popcll(ma & below) : size_t(bc) + __popcll(mc & below);
+            const size_t q = ln.tv.any ? size_t(pl.n_slots) + wa + __popcll(ma & below) : size_t(wc) + __popcll(mc & below);
             const float4 ro = make_float4(ln.tv.o.x, ln.tv.o.y, ln.tv.o.z, ln.tv.mint), rd = make_float4(ln.tv.d.x, ln.tv.d.y, ln.tv.d.z, ln.tv.maxt);
             RT_GPTR(float4, pl.q_o)[q] = ro; RT_GPTR(float4, pl.q_d)[q] = rd; RT_GPTR(unsigned, pl.q_slot)[q] = slot;
             RT_GPTR(float4, pl.ray_o)[slot] = ro; RT_GPTR(float4, pl.ray_d)[slot] = rd;
@@ -187,128 +213,12 @@ __global__ __launch_bounds__(RT_BLOCK) void pipe_shade_kernel(const DevScene *__
 struct TraceJob {
     const float4 *q_o, *q_d;       // queue rays: closest in [0, n_slots), any in [n_slots, 2 n_slots)
     const unsigned *q_slot;
-    unsigned *q_count;             // {n closest, n any, head, -} of this iteration
+    unsigned *q_count;             // this iteration's counters: n closest at +0, head at +RT_QC_HEAD, n any at +RT_QC_ANY
     float4 *hit;                   // [slot]; for rt_trace_* (q_slot == nullptr) indexed by queue position
     unsigned n_slots;
     uint2 *spill; unsigned n_threads;
     unsigned long long *counters;
 };
-
-#ifndef RT_TRACE_LOOP
-#define RT_TRACE_LOOP 2
-#endif
-#ifndef RT_TRACE_DSTEPS
-#define RT_TRACE_DSTEPS 4         // interior steps a descending lane may take per round before the leaf phase gets its turn
-#endif
-#ifndef RT_TRACE_LEAF_MIN
-#define RT_TRACE_LEAF_MIN 12      // keep testing primitives while at least this many lanes have one left
-#endif
-
-// ---- the trace kernel's own traversal steps ------------------------------------------------------------------------------
-// Same semantics as kd_descend / leaf_test_one / kd_leaf_done of rt_traverse.h (KdTreeAccel::Intersect / IntersectP,
-// kdtree.cpp:313-488; Triangle::Intersect, trianglemesh.cpp:213-246), written as straight-line code with selects: every
-// state variable is updated by ONE predicated assignment at the end of a step instead of inside nested divergent branches
-// with early returns.  The branchy form costs ~30 register copies per step (the structurizer's phi moves); at 135 node
-// visits per ray the trace kernel was bound by VALU issue, not by memory.
-template <bool COUNT, int NS>
-RT_DEV void kd_step_flat(Trav &tv, bool desc, const DevScene &sc, uint2 RT_L *lds_stack, uint2 RT_G *spill, unsigned n_threads, unsigned gtid, TravCounters &cnt) {
-    const bool dead = desc && !tv.any && tv.maxt < tv.tmin;                    // kdtree.cpp:330
-    const bool go = desc && !dead;
-    uint2 nd = make_uint2(3u, 0u);
-    if (go) nd = RT_GPTR(const uint2, sc.nodes)[tv.node];
-    if (COUNT) cnt.nodes += go ? 1u : 0u;
-    const unsigned axis = nd.x & 3u;
-    const bool leaf = axis == 3u;
-    const float split = __uint_as_float(nd.x);                                 // perturbed split, B10
-    const float oa = comp(tv.o, int(axis)), da = comp(tv.d, int(axis)), ia = comp(tv.inv, int(axis));   // by value: stays in registers
-    const float tplane = (split - oa) * ia;
-    const bool belowFirst = (oa < split) || (oa == split && da >= 0.f);
-    const unsigned below = tv.node + 1u, above = nd.y;
-    const unsigned first = belowFirst ? below : above, second = belowFirst ? above : below;
-    const bool only_first = tplane > tv.tmax || tplane <= 0.f;
-    const bool only_second = !only_first && tplane < tv.tmin;
-    const bool interior = go && !leaf;
-    const bool both = interior && !only_first && !only_second;
-    if (both) stack_push<COUNT, NS>(tv, make_uint2(second, __float_as_uint(tv.tmax)), lds_stack, spill, n_threads, gtid, cnt);
-    tv.node = interior ? (only_second ? second : first) : tv.node;
-    tv.tmax = both ? tplane : tv.tmax;
-    const bool enter = go && leaf;
-    tv.at_leaf = enter ? true : tv.at_leaf;
-    tv.li = enter ? 0u : tv.li;
-    tv.ln_ = enter ? (nd.x >> 2) : tv.ln_;
-    tv.ly = enter ? nd.y : tv.ly;
-    tv.active = dead ? false : tv.active;
-}
-template <bool COUNT>
-RT_DEV void leaf_test_flat(Trav &tv, bool leafw, const DevScene &sc, TravCounters &cnt) {
-    const bool single = tv.ln_ == 1u;
-    unsigned prim = tv.ly;
-    if (leafw && !single) prim = RT_GPTR(const unsigned, sc.leaf_refs)[tv.ly + tv.li];
-    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
-    if (leafw) { const DevTri RT_G *gt = RT_GPTR(const DevTri, sc.tris) + prim; q0 = gt->q0; q1 = gt->q1; q2 = gt->q2; }
-    if (COUNT) { cnt.tris += leafw ? 1u : 0u; cnt.leaf_refs += (leafw && !single) ? 1u : 0u; }
-    tv.li += leafw ? 1u : 0u;
-    const V3 p1 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
-    const V3 s1 = cross3(tv.d, e2);
-    const float divisor = dot3(s1, e1);
-    const float invDivisor = 1.f / divisor;
-    const V3 dd = tv.o - p1;
-    const float b1 = dot3(dd, s1) * invDivisor;
-    const V3 s2 = cross3(dd, e1);
-    const float b2 = dot3(tv.d, s2) * invDivisor;
-    const float t = dot3(e2, s2) * invDivisor;
-    const bool miss = (divisor == 0.f) || (b1 < 0.f || b1 > 1.f) || (b2 < 0.f || b1 + b2 > 1.f) || (t < tv.mint || t > tv.maxt);
-    const bool hit = leafw && !miss;
-    const bool stop = hit && tv.any;                                           // kdtree.cpp:432-434
-    const bool keep = hit && !tv.any;                                          // primitive.cpp:120
-    tv.hit_prim = stop ? 0 : (keep ? int(prim) : tv.hit_prim);
-    tv.maxt = keep ? t : tv.maxt;
-    tv.b1 = keep ? b1 : tv.b1;
-    tv.b2 = keep ? b2 : tv.b2;
-    tv.active = stop ? false : tv.active;
-}
-template <int NS>
-RT_DEV void kd_pop_flat(Trav &tv, bool done, const uint2 RT_L *lds_stack, const uint2 RT_G *spill, unsigned n_threads, unsigned gtid) {
-    const bool pop = done && tv.sp > 0;
-    uint2 e = make_uint2(0u, 0u);
-    if (pop) e = stack_pop<NS>(tv, lds_stack, spill, n_threads, gtid);
-    tv.node = pop ? e.x : tv.node;
-    tv.tmin = pop ? tv.tmax : tv.tmin;
-    tv.tmax = pop ? __uint_as_float(e.y) : tv.tmax;
-    tv.at_leaf = done ? false : tv.at_leaf;
-    tv.active = (done && !pop) ? false : tv.active;
-}
-
-// One round of the trace kernel's inner loop: the per-lane order of node visits and primitive tests is that of
-// KdTreeAccel::Intersect / IntersectP, only the interleaving across lanes is chosen here:
-//   A  every descending lane takes up to RT_TRACE_DSTEPS interior steps (a tight loop of nothing but the node step);
-//   B  the lanes that sit at a leaf test one primitive each, repeated while enough lanes still have one;
-//   C  lanes whose leaf is exhausted pop their next subtree.
-template <bool COUNT, int ACCEL, bool EXT, int NS>
-RT_DEV void trace_round(Trav &tv, bool busy, const DevScene &sc, uint2 RT_L *lds_stack, uint2 RT_G *spill, unsigned n_threads, unsigned gtid, TravCounters &cnt) {
-    if (ACCEL == RT_ACCEL_GRID) {
-        if (busy && tv.active && !tv.at_leaf) grid_enter_voxel<COUNT>(tv, sc, cnt);
-    } else {
-#pragma unroll 1
-        for (int k = 0; k < RT_TRACE_DSTEPS; ++k) {
-            const bool desc = busy && tv.active && !tv.at_leaf;
-            if (!__any(desc)) break;
-            kd_step_flat<COUNT, NS>(tv, desc, sc, lds_stack, spill, n_threads, gtid, cnt);
-        }
-    }
-#pragma unroll 1
-    for (;;) {
-        const bool leafw = busy && tv.active && tv.at_leaf && tv.li < tv.ln_;
-        const int nl = __popcll(__ballot(leafw));
-        if (nl == 0) break;
-        if (ACCEL == RT_ACCEL_GRID || EXT) { if (leafw) leaf_test_one<COUNT, ACCEL == RT_ACCEL_GRID, EXT>(tv, sc, cnt); }
-        else leaf_test_flat<COUNT>(tv, leafw, sc, cnt);
-        if (nl < RT_TRACE_LEAF_MIN) break;
-    }
-    const bool done = busy && tv.active && tv.at_leaf && tv.li >= tv.ln_;
-    if (ACCEL == RT_ACCEL_GRID) { if (done) grid_voxel_done(tv, sc); }
-    else kd_pop_flat<NS>(tv, done, lds_stack, spill, n_threads, gtid);
-}
 
 template <bool COUNT, int ACCEL, bool EXT>
 __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) void pipe_trace_kernel(const DevScene *__restrict__ scp, TraceJob job) {
@@ -316,44 +226,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) void pipe_trace_kernel(co
     const DevScene &sc = *scp;
     const unsigned gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const unsigned n_closest = job.q_count[0], total = n_closest + job.q_count[1];
+    const unsigned n_closest = job.q_count[0], total = n_closest + job.q_count[RT_QC_ANY];
     TravCounters tc; tc.nodes = tc.leaf_refs = tc.tris = tc.spills = 0;
     Trav tv; tv.active = false; tv.at_leaf = false; tv.hit_prim = -1; tv.any = false; tv.maxt = 0.f; tv.b1 = tv.b2 = 0.f;
     unsigned slot = 0; bool busy = false;
     bool exhausted = false;
-#if RT_TRACE_LOOP == 0
-    for (;;) {
-        // a lane whose ray just ended reports it
-        if (busy && !tv.active) {
-            RT_GPTR(float4, job.hit)[slot] = make_float4(__int_as_float(tv.hit_prim), tv.hit_prim >= 0 ? tv.maxt : 0.f, tv.b1, tv.b2);
-            busy = false;
-        }
-        const unsigned long long idle = __ballot(!busy);
-        if (!exhausted && __popcll(idle) >= RT_TRACE_REFILL) {
-            const int leader = __ffsll((long long)idle) - 1;
-            unsigned base = 0;
-            if (lane == leader) base = atomicAdd(job.q_count + 2, unsigned(__popcll(idle)));
-            base = __shfl(base, leader);
-            if (base + unsigned(__popcll(idle)) >= total) exhausted = true;
-            if (!busy) {
-                const unsigned i = base + unsigned(__popcll(idle & ((1ull << lane) - 1ull)));
-                if (i < total) {
-                    const bool any = i >= n_closest;
-                    const size_t q = any ? size_t(job.n_slots) + (i - n_closest) : size_t(i);
-                    const float4 ro = RT_GPTR(const float4, job.q_o)[q], rd = RT_GPTR(const float4, job.q_d)[q];
-                    slot = job.q_slot ? RT_GPTR(const unsigned, job.q_slot)[q] : unsigned(q);
-                    Ray r; r.o = mk3(ro.x, ro.y, ro.z); r.mint = ro.w; r.d = mk3(rd.x, rd.y, rd.z); r.maxt = rd.w;
-                    accel_begin<ACCEL>(tv, sc, r, any);
-                    busy = true;
-                }
-            }
-            continue;                                                  // rays that died in the slab clip report above
-        }
-        // here busy implies tv.active; no lane busy means the queue is exhausted (else the refill above would have run)
-        if (__popcll(idle) == 64) break;
-        accel_round_batched<COUNT, ACCEL, EXT, RT_TRACE_STACK>(tv, busy, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, job.spill), job.n_threads, gtid, tc);
-    }
-#else
     // Outer loop: report finished rays, refill the idle lanes from the queue (one wave-aggregated atomic).  Inner loop: rounds of
     // traversal with nothing else in it, until enough lanes have finished for a refill to pay (or, once the queue is exhausted,
     // until the wave's last ray ends).
@@ -368,7 +245,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) void pipe_trace_kernel(co
         if (!exhausted && n_idle >= RT_TRACE_REFILL) {
             const int leader = __ffsll((long long)idle) - 1;
             unsigned base = 0;
-            if (lane == leader) base = atomicAdd(job.q_count + 2, n_idle);
+            if (lane == leader) base = atomicAdd(job.q_count + RT_QC_HEAD, n_idle);
             base = __shfl(base, leader);
             if (base + n_idle >= total) exhausted = true;
             const unsigned i = base + unsigned(__popcll(idle & ((1ull << lane) - 1ull)));
@@ -388,14 +265,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) void pipe_trace_kernel(co
         const int leave_at = exhausted ? 0 : (live0 > RT_TRACE_REFILL ? live0 - RT_TRACE_REFILL : 0);
 #pragma unroll 1
         do {
-#if RT_TRACE_LOOP == 1
-            accel_round_batched<COUNT, ACCEL, EXT, RT_TRACE_STACK>(tv, busy, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, job.spill), job.n_threads, gtid, tc);
-#else
             trace_round<COUNT, ACCEL, EXT, RT_TRACE_STACK>(tv, busy, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, job.spill), job.n_threads, gtid, tc);
-#endif
         } while (__popcll(__ballot(busy && tv.active)) > leave_at);
     }
-#endif
     if (COUNT) {
         unsigned long long v[4] = {tc.nodes, tc.leaf_refs, tc.tris, tc.spills};
         const int idx[4] = {3, 4, 5, 7};

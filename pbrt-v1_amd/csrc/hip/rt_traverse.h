@@ -635,6 +635,121 @@ RT_DEV void accel_round_batched(Trav &tv, bool mine, const DevScene &sc, uint2 R
     }
 }
 
+// ---- flat (select-style) traversal steps and the round built from them: used by the trace kernel of the queue pipeline
+// (rt_pipeline.h) and by the megakernel's trav_mode 2 ----
+#ifndef RT_TRACE_DSTEPS
+#define RT_TRACE_DSTEPS 4         // interior steps a descending lane may take per round before the leaf phase gets its turn
+#endif
+#ifndef RT_TRACE_LEAF_MIN
+#define RT_TRACE_LEAF_MIN 12      // keep testing primitives while at least this many lanes have one left
+#endif
+
+// ---- the trace kernel's own traversal steps ------------------------------------------------------------------------------
+// Same semantics as kd_descend / leaf_test_one / kd_leaf_done of rt_traverse.h (KdTreeAccel::Intersect / IntersectP,
+// kdtree.cpp:313-488; Triangle::Intersect, trianglemesh.cpp:213-246), written as straight-line code with selects: every
+// state variable is updated by ONE predicated assignment at the end of a step instead of inside nested divergent branches
+// with early returns.  The branchy form costs ~30 register copies per step (the structurizer's phi moves); at 135 node
+// visits per ray the trace kernel was bound by VALU issue, not by memory.
+template <bool COUNT, int NS, bool LEAF_ORDER>
+RT_DEV void kd_step_flat(Trav &tv, bool desc, const DevScene &sc, uint2 RT_L *lds_stack, uint2 RT_G *spill, unsigned n_threads, unsigned gtid, TravCounters &cnt) {
+    const bool dead = desc && !tv.any && tv.maxt < tv.tmin;                    // kdtree.cpp:330
+    const bool go = desc && !dead;
+    uint2 nd = make_uint2(3u, 0u);
+    if (go) nd = RT_GPTR(const uint2, LEAF_ORDER ? sc.tnodes : sc.nodes)[tv.node];
+    if (COUNT) cnt.nodes += go ? 1u : 0u;
+    const unsigned axis = nd.x & 3u;
+    const bool leaf = axis == 3u;
+    const float split = __uint_as_float(nd.x);                                 // perturbed split, B10
+    const float oa = comp(tv.o, int(axis)), da = comp(tv.d, int(axis)), ia = comp(tv.inv, int(axis));   // by value: stays in registers
+    const float tplane = (split - oa) * ia;
+    const bool belowFirst = (oa < split) || (oa == split && da >= 0.f);
+    const unsigned below = tv.node + 1u, above = nd.y;
+    const unsigned first = belowFirst ? below : above, second = belowFirst ? above : below;
+    const bool only_first = tplane > tv.tmax || tplane <= 0.f;
+    const bool only_second = !only_first && tplane < tv.tmin;
+    const bool interior = go && !leaf;
+    const bool both = interior && !only_first && !only_second;
+    if (both) stack_push<COUNT, NS>(tv, make_uint2(second, __float_as_uint(tv.tmax)), lds_stack, spill, n_threads, gtid, cnt);
+    tv.node = interior ? (only_second ? second : first) : tv.node;
+    tv.tmax = both ? tplane : tv.tmax;
+    const bool enter = go && leaf;
+    tv.at_leaf = enter ? true : tv.at_leaf;
+    tv.li = enter ? 0u : tv.li;
+    tv.ln_ = enter ? (nd.x >> 2) : tv.ln_;
+    tv.ly = enter ? nd.y : tv.ly;
+    tv.active = dead ? false : tv.active;
+}
+template <bool COUNT>
+RT_DEV void leaf_test_flat(Trav &tv, bool leafw, const DevScene &sc, TravCounters &cnt) {
+    // leaf-ordered records (DevScene::ltris): primitive li of this leaf sits 3 * li float4s behind the leaf's first
+    const bool single = tv.ln_ == 1u;
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
+    if (leafw) { const float4 RT_G *gt = RT_GPTR(const float4, sc.ltris) + (size_t(tv.ly) + 3u * tv.li); q0 = gt[0]; q1 = gt[1]; q2 = gt[2]; }
+    const unsigned prim = __float_as_uint(q2.w);
+    if (COUNT) { cnt.tris += leafw ? 1u : 0u; cnt.leaf_refs += (leafw && !single) ? 1u : 0u; }
+    tv.li += leafw ? 1u : 0u;
+    const V3 p1 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
+    const V3 s1 = cross3(tv.d, e2);
+    const float divisor = dot3(s1, e1);
+    const float invDivisor = 1.f / divisor;
+    const V3 dd = tv.o - p1;
+    const float b1 = dot3(dd, s1) * invDivisor;
+    const V3 s2 = cross3(dd, e1);
+    const float b2 = dot3(tv.d, s2) * invDivisor;
+    const float t = dot3(e2, s2) * invDivisor;
+    const bool miss = (divisor == 0.f) || (b1 < 0.f || b1 > 1.f) || (b2 < 0.f || b1 + b2 > 1.f) || (t < tv.mint || t > tv.maxt);
+    const bool hit = leafw && !miss;
+    const bool stop = hit && tv.any;                                           // kdtree.cpp:432-434
+    const bool keep = hit && !tv.any;                                          // primitive.cpp:120
+    tv.hit_prim = stop ? 0 : (keep ? int(prim) : tv.hit_prim);
+    tv.maxt = keep ? t : tv.maxt;
+    tv.b1 = keep ? b1 : tv.b1;
+    tv.b2 = keep ? b2 : tv.b2;
+    tv.active = stop ? false : tv.active;
+}
+template <int NS>
+RT_DEV void kd_pop_flat(Trav &tv, bool done, const uint2 RT_L *lds_stack, const uint2 RT_G *spill, unsigned n_threads, unsigned gtid) {
+    const bool pop = done && tv.sp > 0;
+    uint2 e = make_uint2(0u, 0u);
+    if (pop) e = stack_pop<NS>(tv, lds_stack, spill, n_threads, gtid);
+    tv.node = pop ? e.x : tv.node;
+    tv.tmin = pop ? tv.tmax : tv.tmin;
+    tv.tmax = pop ? __uint_as_float(e.y) : tv.tmax;
+    tv.at_leaf = done ? false : tv.at_leaf;
+    tv.active = (done && !pop) ? false : tv.active;
+}
+
+// One round of the trace kernel's inner loop: the per-lane order of node visits and primitive tests is that of
+// KdTreeAccel::Intersect / IntersectP, only the interleaving across lanes is chosen here:
+//   A  every descending lane takes up to RT_TRACE_DSTEPS interior steps (a tight loop of nothing but the node step);
+//   B  the lanes that sit at a leaf test one primitive each, repeated while enough lanes still have one;
+//   C  lanes whose leaf is exhausted pop their next subtree.
+template <bool COUNT, int ACCEL, bool EXT, int NS>
+RT_DEV void trace_round(Trav &tv, bool busy, const DevScene &sc, uint2 RT_L *lds_stack, uint2 RT_G *spill, unsigned n_threads, unsigned gtid, TravCounters &cnt) {
+    if (ACCEL == RT_ACCEL_GRID) {
+        if (busy && tv.active && !tv.at_leaf) grid_enter_voxel<COUNT>(tv, sc, cnt);
+    } else {
+#pragma unroll 1
+        for (int k = 0; k < RT_TRACE_DSTEPS; ++k) {
+            const bool desc = busy && tv.active && !tv.at_leaf;
+            if (!__any(desc)) break;
+            kd_step_flat<COUNT, NS, !EXT>(tv, desc, sc, lds_stack, spill, n_threads, gtid, cnt);
+        }
+    }
+#pragma unroll 1
+    for (;;) {
+        const bool leafw = busy && tv.active && tv.at_leaf && tv.li < tv.ln_;
+        const int nl = __popcll(__ballot(leafw));
+        if (nl == 0) break;
+        if (ACCEL == RT_ACCEL_GRID || EXT) { if (leafw) leaf_test_one<COUNT, ACCEL == RT_ACCEL_GRID, EXT>(tv, sc, cnt); }
+        else leaf_test_flat<COUNT>(tv, leafw, sc, cnt);
+        if (nl < RT_TRACE_LEAF_MIN) break;
+    }
+    const bool done = busy && tv.active && tv.at_leaf && tv.li >= tv.ln_;
+    if (ACCEL == RT_ACCEL_GRID) { if (done) grid_voxel_done(tv, sc); }
+    else kd_pop_flat<NS>(tv, done, lds_stack, spill, n_threads, gtid);
+}
+
 // accelerator dispatch (compile-time)
 template <int ACCEL>
 RT_DEV void accel_begin(Trav &tv, const DevScene &sc, const Ray &r, bool any) {

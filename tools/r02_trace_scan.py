@@ -24,6 +24,7 @@ def bench(tag, env=None, workload="p1000000", steps=3):
         j = json.loads(r.stdout.strip().splitlines()[-1]); ro = j["roofline"]
         print(json.dumps(dict(tag=tag, workload=workload, Mrays=j["value"], ms=j["ms_per_step"], trace_ms=ro["kernel_ms"], frac=ro["frac"],
                               render_ms=ro["frame_kernels_ms"]["render"], iters=ro["pipeline_iterations"], slots=ro["pipeline_slots"])), flush=True)
+        open(os.path.join(ROOT, "gpurun_out", "scan_" + tag.replace(":", "_").replace(" ", "_") + ".json"), "w").write(json.dumps(j))
     except Exception as ex:
         print(json.dumps(dict(tag=tag, error=str(ex), stderr=r.stderr[-400:])), flush=True)
 
@@ -51,6 +52,17 @@ def main():
         rebuild("rt_trace", ["-DRT_TRACE_REFILL=48"]); bench("loop2_refill48")
         rebuild("rt_trace", ["-DRT_TRACE_REFILL=64"]); bench("loop2_refill64")
         rebuild("rt_trace", [])
+    elif g == "slots":
+        for sl in (1 << 22, 1 << 23, 1 << 24, 17 << 20):
+            bench("slots%d" % sl, env={"PBRT_HIP_PIPE_SLOTS": str(sl)})
+            bench("slots%d_blocks5" % sl, env={"PBRT_HIP_PIPE_SLOTS": str(sl), "PBRT_HIP_TRACE_BLOCKS_PER_CU": "5"})
+        for sl in (1 << 23, 17 << 20):
+            bench("c3_slots%d" % sl, env={"PBRT_HIP_PIPE_SLOTS": str(sl)}, workload="c3")
+    elif g == "mega":
+        for wl in ("p1000000", "c3", "p100000", "c4", "c5"):
+            bench("mega_flat_" + wl, env={"PBRT_HIP_PIPELINE": "0"}, workload=wl)
+            bench("mega_batched_" + wl, env={"PBRT_HIP_PIPELINE": "0", "PBRT_HIP_TRAV_MODE": "4"}, workload=wl)
+            bench("pipe8M_" + wl, env={"PBRT_HIP_PIPELINE": "1", "PBRT_HIP_PIPE_SLOTS": str(1 << 23)}, workload=wl)
     elif g == "defs":
         defs = sys.argv[2].split(",") if len(sys.argv) > 2 and sys.argv[2] else []
         rebuild("rt_trace", defs)
