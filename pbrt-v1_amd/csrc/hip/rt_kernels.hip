@@ -347,7 +347,7 @@ static int ensure(RtScene *s, T **buf, size_t *cap, size_t need) {
 // iterations launched after the last productive one find every slot in ST_EXIT and return at once.
 static int render_pipeline(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, int vol_levels, int vol_nmax, size_t vol_samp_words) {
     const int integ = rd->integrator;
-    unsigned want = 1u << 22;
+    unsigned want = 1u << 23;
     if (const char *e = std::getenv("PBRT_HIP_PIPE_SLOTS")) want = unsigned(std::max(256, std::atoi(e)));
     unsigned long long tw = fr.total_work ? fr.total_work : 1;
     unsigned n_slots = unsigned(std::min<unsigned long long>(want, tw));
@@ -844,7 +844,9 @@ static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool nee
         fr.phase_sync = tiny ? 1 : 0;                          // C2: 63.6 vs 82.4 ms; 100k/1M soups (early-exit rounds): 8 % slower
         if (const char *e = std::getenv("PBRT_HIP_PHASE_SYNC")) fr.phase_sync = std::atoi(e);
         // large trees (traversal bound by memory latency): the queue pipeline of rt_pipeline.h; tiny cache-resident ones: the megakernel
-        fr.pipeline = tiny ? 0 : 1;
+        // (measured on the 1 M-triangle frames, 1x MI355X: the pipeline's trace kernel is faster than the megakernel's traversal, but its
+        // state traffic and sparse last iterations cost more than that gains, except where shading suspends often: volume marching)
+        fr.pipeline = (!tiny && s->volume.present) ? 1 : 0;
         if (const char *e = std::getenv("PBRT_HIP_PIPELINE")) fr.pipeline = std::atoi(e) != 0;
         if (fr.max_depth > 250 || fr.max_depth < 0) fr.pipeline = 0;     // the slot's control word holds depth in 8 bits
         if (fr.trav_mode == 3 && fr.high_occupancy) fr.trav_mode = 1;   // the high-occupancy kernels carry no pooled-leaf scratch

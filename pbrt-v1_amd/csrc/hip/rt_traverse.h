@@ -576,6 +576,8 @@ RT_DEV void leaf_phase_pooled(Trav &tv, bool need, const DevScene &sc, PoolLds p
         tv.li = tv.ln_;
     }
 }
+template <bool COUNT, int NS, bool LEAF_ORDER>
+RT_DEV void kd_step_flat(Trav &tv, bool desc, const DevScene &sc, uint2 RT_L *lds_stack, uint2 RT_G *spill, unsigned n_threads, unsigned gtid, TravCounters &cnt);
 // lock-step round with the leaf phase pooled when that is cheaper than max(n) per-lane iterations
 template <bool COUNT, int ACCEL, bool EXT>
 RT_DEV void accel_round_pooled(Trav &tv, bool mine, const DevScene &sc, uint2 RT_L *lds_stack, uint2 RT_G *spill, unsigned n_threads,
@@ -584,8 +586,16 @@ RT_DEV void accel_round_pooled(Trav &tv, bool mine, const DevScene &sc, uint2 RT
     if (ACCEL == RT_ACCEL_GRID) {
         if (mine && tv.active && !tv.at_leaf) grid_enter_voxel<COUNT>(tv, sc, cnt);
     } else {
+#ifdef RT_POOLED_BRANCHY_DESCENT
         while (__any(mine && tv.active && !tv.at_leaf))
             if (mine && tv.active && !tv.at_leaf) kd_descend<COUNT>(tv, sc, lds_stack, spill, n_threads, gtid, cnt);
+#else
+        for (;;) {
+            const bool desc = mine && tv.active && !tv.at_leaf;
+            if (!__any(desc)) break;
+            kd_step_flat<COUNT, RT_STACK_LDS, false>(tv, desc, sc, lds_stack, spill, n_threads, gtid, cnt);
+        }
+#endif
     }
     RT_PFT(unsigned long long t1 = __builtin_readcyclecounter(); cnt.c_desc += t1 - t0;)
     const bool need = mine && tv.active && tv.at_leaf;
@@ -641,7 +651,7 @@ RT_DEV void accel_round_batched(Trav &tv, bool mine, const DevScene &sc, uint2 R
 #define RT_TRACE_DSTEPS 4         // interior steps a descending lane may take per round before the leaf phase gets its turn
 #endif
 #ifndef RT_TRACE_LEAF_MIN
-#define RT_TRACE_LEAF_MIN 12      // keep testing primitives while at least this many lanes have one left
+#define RT_TRACE_LEAF_MIN 24      // keep testing primitives while at least this many lanes have one left
 #endif
 
 // ---- the trace kernel's own traversal steps ------------------------------------------------------------------------------

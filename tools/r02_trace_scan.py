@@ -63,6 +63,18 @@ def main():
             bench("mega_flat_" + wl, env={"PBRT_HIP_PIPELINE": "0"}, workload=wl)
             bench("mega_batched_" + wl, env={"PBRT_HIP_PIPELINE": "0", "PBRT_HIP_TRAV_MODE": "4"}, workload=wl)
             bench("pipe8M_" + wl, env={"PBRT_HIP_PIPELINE": "1", "PBRT_HIP_PIPE_SLOTS": str(1 << 23)}, workload=wl)
+    elif g == "c2":
+        for defs in ([], ["-DRT_POOLED_BRANCHY_DESCENT"]):
+            for u in ("rt_mega_p", "rt_mega_d", "rt_mega_w"):
+                rebuild(u, defs)
+            for wl in ("c2", "c2d", "c2w"):
+                bench("c2scan:" + " ".join(defs), env={"PBRT_HIP_PIPELINE": "0"}, workload=wl)
+        for ds, lm in ((2, 12), (8, 12), (4, 4), (4, 24), (8, 32)):
+            rebuild("rt_mega_p", ["-DRT_TRACE_DSTEPS=%d" % ds, "-DRT_TRACE_LEAF_MIN=%d" % lm])
+            bench("mega_dsteps%d_leafmin%d" % (ds, lm), env={"PBRT_HIP_PIPELINE": "0"}, workload="p1000000")
+        rebuild("rt_mega_p", [])
+        for et in (16, 24, 40, 48):
+            bench("mega_exit%d" % et, env={"PBRT_HIP_PIPELINE": "0", "PBRT_HIP_EXIT_THRESH": str(et)}, workload="p1000000")
     elif g == "defs":
         defs = sys.argv[2].split(",") if len(sys.argv) > 2 and sys.argv[2] else []
         rebuild("rt_trace", defs)
