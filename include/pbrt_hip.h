@@ -110,6 +110,19 @@ typedef struct RtQuadric {
     float p1[3], p2[3], a, c;                                /* hyperboloid: end points (after the ctor's swap) and the implicit form's a, c */
 } RtQuadric;
 
+/* ---- per-vertex shading data of triangle meshes: "uv" / "st", "N", "S" (shapes/trianglemesh.cpp:71-133 GetShadingGeometry,
+ * :248-274 the (u,v)-dependent dpdu / dpdv of Triangle::Intersect, :315-328 GetUVs, checks of the factory :350-406).  A triangle
+ * whose mesh has any of them refers to one record.  n and s are object-space (the mesh keeps them so, :155-164) and go through
+ * the mesh's ObjectToWorld at shading time: xform indexes RtSceneDesc::xforms. ---- */
+enum { RT_SHADING_UV = 1, RT_SHADING_N = 2, RT_SHADING_S = 4 };
+typedef struct RtTriShading {
+    uint32_t flags;            /* RT_SHADING_*                                                               */
+    uint32_t xform;
+    float uv[6];               /* uvs[3][2] as GetUVs returns them (the defaults (0,0) (1,0) (1,1) without "uv") */
+    float n[9];                /* normals of the three vertices, object space                                */
+    float s[9];                /* tangents of the three vertices, object space                               */
+} RtTriShading;
+
 /* Scene description = what MakeScene hands to Scene::Scene (core/scene.cpp:100-119),
  * flattened.  Triangles are in the order KdTreeAccel's FullyRefine produces
  * (kdtree.cpp:146-148: per mesh, last triangle first). Vertices are world space
@@ -131,6 +144,11 @@ typedef struct RtSceneDesc {
     RtAccelParams accel;
     uint32_t n_quadrics;          /* may be 0 / NULL                                           */
     const RtQuadric *quadrics;
+    const int32_t *tri_shading;   /* [n_tris] index into shading[] or -1; NULL when no mesh has uv / N / S */
+    uint32_t n_shading;
+    const RtTriShading *shading;
+    uint32_t n_xforms;
+    const float *xforms;          /* [n_xforms][32]: Transform::m then ::mInv of a mesh's ObjectToWorld, row-major */
 } RtSceneDesc;
 
 /* ---- per-frame description ---- */

@@ -214,6 +214,24 @@ def read_exr(path):
     return rgb, alpha, dict(total_res=(info[2], info[3]), offset=(info[4], info[5]))
 
 
+TRI_SHADING_DTYPE = np.dtype([("flags", np.uint32), ("xform", np.uint32), ("uv", np.float32, 6), ("n", np.float32, 9), ("s", np.float32, 9)])
+
+
+def shading_records(parsed):
+    """(tri_shading[n_tris] or None, RtTriShading records, xforms[n][32]) of a ParsedScene: the per-vertex uv / N / S data."""
+    H = host_lib()
+    H.pbrt_host_shading.restype = C.c_int
+    H.pbrt_host_shading.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
+    idx, rec, xf, nrec, nxf = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint(), C.c_uint()
+    H.pbrt_host_shading(parsed.scene_desc, C.byref(idx), C.byref(rec), C.byref(xf), C.byref(nrec), C.byref(nxf))
+    if not idx.value:
+        return None, np.zeros(0, TRI_SHADING_DTYPE), np.zeros((0, 32), np.float32)
+    i = np.ctypeslib.as_array(C.cast(idx, C.POINTER(C.c_int32)), shape=(parsed.n_tris,)).copy()
+    r = np.frombuffer(C.string_at(rec, nrec.value * TRI_SHADING_DTYPE.itemsize), TRI_SHADING_DTYPE).copy()
+    x = np.ctypeslib.as_array(C.cast(xf, C.POINTER(C.c_float)), shape=(nxf.value, 32)).copy() if nxf.value else np.zeros((0, 32), np.float32)
+    return i, r, x
+
+
 def format_f32(values, per_line: int = 9) -> str:
     """Scene-text numbers ("%.9g": round-trips float32) formatted by the host library: 1 s for a 1 M-triangle mesh."""
     v = np.ascontiguousarray(values, np.float32).ravel()

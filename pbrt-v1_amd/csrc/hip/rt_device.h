@@ -18,6 +18,16 @@ struct DevQuadric {          // Sphere (shapes/sphere.cpp:89-99): transforms as 
     float p1[3], p2[3], a, c;   // hyperboloid (hyperboloid.cpp:46-70)
 };
 
+// per-vertex shading data of one triangle (RtTriShading) plus what Triangle::Intersect derives from its uvs (trianglemesh.cpp:248-268)
+#define RT_PRIM_SHADING (1u << 18)      // tri_shade bits: the triangle has per-vertex N and / or S (DevScene::tri_shading)
+struct DevTriShading {
+    unsigned flags, xform;
+    float uv[6];
+    float dpdu[3];             // the geometric dpdu of Triangle::Intersect with this triangle's uvs (not normalised)
+    float n[9], s[9];
+    float pad[3];
+};
+
 struct DevMaterial {
     int type;
     float r[3];      // Kd / Kr
@@ -61,6 +71,9 @@ struct DevScene {
                                // in DevTri, the primitive's index in q2.w), placed so that a leaf touches the fewest 128-byte lines: one
                                // gather fetches what the mesh-order layout needs a leaf-list read plus 1.25 lines per triangle for
     const unsigned *leaf_refs;
+    const int *tri_shading_idx;      // [n_tris] index into tri_shading or -1 (EXT kernels; null when no mesh has N / S)
+    const DevTriShading *tri_shading;
+    const float *xforms;             // [n][32] ObjectToWorld m, mInv of the meshes with N / S
     const DevMaterial *materials;
     const DevLight *lights;
     const float *light_tris;   // [n][16]: 9 vertex floats, per-triangle area, area CDF, pad, emitter normal nl.xyz (flipped), pad

@@ -27,7 +27,7 @@ struct Rng {
     RT_DEV uint32_t next_u32() { return rng_u32(base, ctr++); }
 };
 
-#define RT_FRAME_WORDS 22
+#define RT_FRAME_WORDS 25
 
 struct Lane {
     // --- the camera sample being evaluated
@@ -276,6 +276,7 @@ RT_DEV void frame_push(const DevFrame &fr, Lane &ln, unsigned gtid, V3 f, float 
     q[15 * st] = ln.v.sn.x; q[16 * st] = ln.v.sn.y; q[17 * st] = ln.v.sn.z;
     q[18 * st] = ln.v.wo.x; q[19 * st] = ln.v.wo.y; q[20 * st] = ln.v.wo.z;
     q[21 * st] = __int_as_float(ln.v.mat);
+    q[22 * st] = ln.v.ng.x; q[23 * st] = ln.v.ng.y; q[24 * st] = ln.v.ng.z;
     ++ln.fsp;
 }
 RT_DEV int frame_pop(const DevFrame &fr, Lane &ln, unsigned gtid, V3 child) {
@@ -293,6 +294,7 @@ RT_DEV int frame_pop(const DevFrame &fr, Lane &ln, unsigned gtid, V3 child) {
     ln.v.tn = cross3(ln.v.nn, ln.v.sn);
     ln.v.wo = mk3(q[18 * st], q[19 * st], q[20 * st]);
     ln.v.mat = __float_as_int(q[21 * st]);
+    ln.v.ng = mk3(q[22 * st], q[23 * st], q[24 * st]);
     return after;
 }
 
@@ -435,7 +437,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
             if (ln.depth == 0) { ln.alpha = 1.f; if (VOL) vol_ray_ptr(fr, 0, gtid)[7 * size_t(fr.n_threads)] = ln.tv.maxt; }   // r.maxt = ray.maxt
             else if (VOL) ln.thr = ln.thr * scene_transmittance<VOL>(sc, ln, ln.tv.o, ln.tv.d, ln.tv.mint, ln.tv.maxt);           // path.cpp:89
             if ((ln.depth == 0 || ln.specular) && ln.v.light >= 0)              // path.cpp:91-92
-                ln.L = ln.L + ln.thr * area_L(RT_LIGHT(sc, ln.v.light), ln.v.nn, ln.v.wo);
+                ln.L = ln.L + ln.thr * area_L(RT_LIGHT(sc, ln.v.light), ln.v.ng, ln.v.wo);   // isect.Le: dg.nn, the geometric normal
         } else {
             if (!hit) {                                                         // whitted.cpp:52-59
                 ln.L = mk3(0.f);
@@ -446,7 +448,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
             if (ln.depth == 0) ln.alpha = 1.f;
             if (VOL) vol_ray_ptr(fr, ln.fsp, gtid)[7 * size_t(fr.n_threads)] = ln.tv.maxt;       // the hit shortens this level's ray
             ln.L = mk3(0.f);
-            if (ln.v.light >= 0) ln.L = ln.L + area_L(RT_LIGHT(sc, ln.v.light), ln.v.nn, ln.v.wo);
+            if (ln.v.light >= 0) ln.L = ln.L + area_L(RT_LIGHT(sc, ln.v.light), ln.v.ng, ln.v.wo);
         }
         ln.li = 0; ln.lj = 0; ln.L_all = mk3(0.f); ln.Ld_light = mk3(0.f);
         ln.stage = ST_DIRECT_NEXT;

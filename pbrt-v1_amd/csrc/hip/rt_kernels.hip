@@ -321,6 +321,33 @@ static void build_leaf_order(const std::vector<Node> &nodes, const std::vector<u
     if (ltris.empty()) ltris.resize(8, make_float4(0.f, 0.f, 0.f, 0.f));
 }
 
+// Triangle::Intersect's frame with the mesh's own uvs (trianglemesh.cpp:248-268 incl. the zero-determinant fallback through
+// CoordinateSystem, geometry.h:324-334) + DifferentialGeometry ctor (shape.cpp:43-50): geometric normal, raw dpdu
+static void host_tri_frame_uv(const float *v, const float *uv, bool flip, float nn[3], float dpdu[3]) {
+    const float du1 = uv[0] - uv[4], du2 = uv[2] - uv[4], dv1 = uv[1] - uv[5], dv2 = uv[3] - uv[5];
+    const float determinant = du1 * dv2 - dv1 * du2;
+    float dpdv[3];
+    if (determinant == 0.f) {
+        const float e1[3] = {v[3] - v[0], v[4] - v[1], v[5] - v[2]}, e2[3] = {v[6] - v[0], v[7] - v[1], v[8] - v[2]};
+        float c[3] = {(e2[1] * e1[2]) - (e2[2] * e1[1]), (e2[2] * e1[0]) - (e2[0] * e1[2]), (e2[0] * e1[1]) - (e2[1] * e1[0])};
+        const float inv = 1.f / sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+        const float v1[3] = {c[0] * inv, c[1] * inv, c[2] * inv};
+        if (fabsf(v1[0]) > fabsf(v1[1])) { const float invLen = 1.f / sqrtf(v1[0] * v1[0] + v1[2] * v1[2]); dpdu[0] = -v1[2] * invLen; dpdu[1] = 0.f; dpdu[2] = v1[0] * invLen; }
+        else { const float invLen = 1.f / sqrtf(v1[1] * v1[1] + v1[2] * v1[2]); dpdu[0] = 0.f; dpdu[1] = v1[2] * invLen; dpdu[2] = -v1[1] * invLen; }
+        dpdv[0] = (v1[1] * dpdu[2]) - (v1[2] * dpdu[1]); dpdv[1] = (v1[2] * dpdu[0]) - (v1[0] * dpdu[2]); dpdv[2] = (v1[0] * dpdu[1]) - (v1[1] * dpdu[0]);
+    } else {
+        const float invdet = 1.f / determinant;
+        for (int a = 0; a < 3; ++a) {
+            const float dp1 = v[a] - v[6 + a], dp2 = v[3 + a] - v[6 + a];
+            dpdu[a] = ((dv2 * dp1) - (dv1 * dp2)) * invdet;
+            dpdv[a] = ((-du2 * dp1) + (du1 * dp2)) * invdet;
+        }
+    }
+    const float c[3] = {(dpdu[1] * dpdv[2]) - (dpdu[2] * dpdv[1]), (dpdu[2] * dpdv[0]) - (dpdu[0] * dpdv[2]), (dpdu[0] * dpdv[1]) - (dpdu[1] * dpdv[0])};
+    const float inv = 1.f / sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    for (int a = 0; a < 3; ++a) { nn[a] = c[a] * inv; if (flip) nn[a] = -1.f * nn[a]; }
+}
+
 template <class T>
 static int upload(RtScene *s, const T *host, size_t n, const T **dev) {
     void *p = nullptr;
@@ -508,10 +535,34 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
     std::vector<float4> shade(size_t(2) * d->n_tris);
     if (n_quadric_slots != d->n_quadrics || (d->n_quadrics && !d->quadrics)) return fail(RT_EINVAL, "rt_scene_create: quadric slots do not match n_quadrics");
     s->has_ext = s->has_ext || d->n_quadrics > 0;
+    std::vector<DevTriShading> dshading; std::vector<int> shading_idx;
+    if (d->tri_shading) {
+        if (d->n_shading && !d->shading) return fail(RT_EINVAL, "rt_scene_create: tri_shading without shading records");
+        shading_idx.assign(d->n_tris, -1);
+    }
     for (uint32_t i = 0; i < d->n_tris; ++i) {
         float nn[3] = {0.f, 0.f, 0.f}, sn[3] = {0.f, 0.f, 0.f};
-        if (!(d->tri_flags[i] & 2u)) host_tri_frame(d->tri_verts + size_t(9) * i, (d->tri_flags[i] & 1u) != 0, nn, sn);
-        uint32_t bits = uint32_t(d->tri_material[i]) | (uint32_t(d->tri_flags[i] & 1u) << 16) | ((d->tri_flags[i] & 2u) ? RT_PRIM_QUADRIC : 0u);
+        const int sh = (d->tri_shading && !(d->tri_flags[i] & 2u)) ? d->tri_shading[i] : -1;
+        bool smooth = false;
+        if (sh >= 0) {                                   // the mesh has uv / N / S: the frame depends on its uvs (trianglemesh.cpp:248-268)
+            if (uint32_t(sh) >= d->n_shading) return fail(RT_EINVAL, "rt_scene_create: shading record index out of range");
+            const RtTriShading &r = d->shading[sh];
+            if ((r.flags & (RT_SHADING_N | RT_SHADING_S)) && (r.xform >= d->n_xforms || !d->xforms)) return fail(RT_EINVAL, "rt_scene_create: shading record refers to a transform out of range");
+            float dpdu[3];
+            host_tri_frame_uv(d->tri_verts + size_t(9) * i, r.uv, (d->tri_flags[i] & 1u) != 0, nn, dpdu);
+            const float inv = 1.f / sqrtf(dpdu[0] * dpdu[0] + dpdu[1] * dpdu[1] + dpdu[2] * dpdu[2]);
+            for (int a = 0; a < 3; ++a) sn[a] = dpdu[a] * inv;
+            if (r.flags & (RT_SHADING_N | RT_SHADING_S)) {
+                smooth = true; s->has_ext = true;
+                DevTriShading o; std::memset(&o, 0, sizeof o);
+                o.flags = r.flags; o.xform = r.xform;
+                std::memcpy(o.uv, r.uv, sizeof o.uv); std::memcpy(o.dpdu, dpdu, sizeof o.dpdu);
+                std::memcpy(o.n, r.n, sizeof o.n); std::memcpy(o.s, r.s, sizeof o.s);
+                shading_idx[i] = int(dshading.size()); dshading.push_back(o);
+            }
+        } else if (!(d->tri_flags[i] & 2u)) host_tri_frame(d->tri_verts + size_t(9) * i, (d->tri_flags[i] & 1u) != 0, nn, sn);
+        uint32_t bits = uint32_t(d->tri_material[i]) | (uint32_t(d->tri_flags[i] & 1u) << 16) | ((d->tri_flags[i] & 2u) ? RT_PRIM_QUADRIC : 0u) |
+                        (smooth ? RT_PRIM_SHADING : 0u);
         int32_t light = d->tri_light[i];
         float fb, fl; std::memcpy(&fb, &bits, 4); std::memcpy(&fl, &light, 4);
         shade[2 * i] = make_float4(nn[0], nn[1], nn[2], fb);
@@ -519,6 +570,11 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
     }
     int rc;
     if ((rc = upload(s, shade.data(), shade.size(), &s->dev.tri_shade))) return rc;
+    if (!dshading.empty()) {
+        if ((rc = upload(s, shading_idx.data(), shading_idx.size(), &s->dev.tri_shading_idx))) return rc;
+        if ((rc = upload(s, dshading.data(), dshading.size(), &s->dev.tri_shading))) return rc;
+        if ((rc = upload(s, d->xforms, size_t(d->n_xforms) * 32, &s->dev.xforms))) return rc;
+    }
     if ((rc = upload(s, tris.data(), tris.size(), &s->dev.tris))) return rc;
     {
         std::vector<DevQuadric> dq(d->n_quadrics);

@@ -33,7 +33,7 @@
 
 namespace rt {
 
-#define RT_PIPE_VEC 11            // float4 planes of slot state (the 11th only for DirectLighting "all")
+#define RT_PIPE_VEC 12            // float4 planes of slot state (the 11th only for DirectLighting "all", the 12th for the EXT kernels)
 
 struct PipePool {
     unsigned n_slots;
@@ -53,7 +53,7 @@ struct PipePool {
 
 // ---- slot state <-> Lane ----------------------------------------------------------------------------------------
 // ctl word: stage (4 bits) | has_ray << 4 | specular << 5 | any << 6 | depth << 8 | fsp << 16
-template <int INTEG>
+template <int INTEG, bool EXT>
 RT_DEV void pipe_load(const PipePool &pl, const DevFrame &fr, unsigned slot, Lane &ln) {
     const float4 RT_G *st = RT_GPTR(const float4, pl.state) + slot;
     const size_t n = pl.n_slots;
@@ -85,8 +85,10 @@ RT_DEV void pipe_load(const PipePool &pl, const DevFrame &fr, unsigned slot, Lan
         const float4 a10 = st[10 * n];
         ln.Ld_light = mk3(a9.z, a9.w, a10.x); ln.L_all = mk3(a10.y, a10.z, a10.w);
     }
+    ln.v.ng = ln.v.nn;
+    if (EXT) { const float4 a11 = st[11 * n]; ln.v.ng = mk3(a11.x, a11.y, a11.z); }
 }
-template <int INTEG>
+template <int INTEG, bool EXT>
 RT_DEV void pipe_store(const PipePool &pl, unsigned slot, const Lane &ln) {
     float4 RT_G *st = RT_GPTR(float4, pl.state) + slot;
     const size_t n = pl.n_slots;
@@ -106,6 +108,7 @@ RT_DEV void pipe_store(const PipePool &pl, unsigned slot, const Lane &ln) {
         st[9 * n] = make_float4(ln.pend.y, ln.pend.z, ln.Ld_light.x, ln.Ld_light.y);
         st[10 * n] = make_float4(ln.Ld_light.z, ln.L_all.x, ln.L_all.y, ln.L_all.z);
     } else st[9 * n] = make_float4(ln.pend.y, ln.pend.z, 0.f, 0.f);
+    if (EXT) st[11 * n] = make_float4(ln.v.ng.x, ln.v.ng.y, ln.v.ng.z, 0.f);
 }
 
 // ---- shade: everything between two rays of a path, for every slot ---------------------------------------------------
@@ -118,9 +121,9 @@ __global__ __launch_bounds__(RT_BLOCK) void pipe_shade_kernel(const DevScene *__
     const unsigned slot = blockIdx.x * RT_BLOCK + threadIdx.x;          // n_slots is a multiple of RT_BLOCK
     const int lane = threadIdx.x & 63;
     Lane ln;
-    ln.v.p = ln.v.nn = ln.v.sn = ln.v.tn = ln.v.wo = mk3(0.f); ln.v.mat = 0; ln.v.light = -1;
+    ln.v.p = ln.v.nn = ln.v.ng = ln.v.sn = ln.v.tn = ln.v.wo = mk3(0.f); ln.v.mat = 0; ln.v.light = -1;
     ln.li = ln.lj = 0; ln.cur_light = 0; ln.Ld = ln.Ld_light = ln.L_all = ln.pend = mk3(0.f); ln.bs1 = ln.bs2 = ln.bcs = 0.f;
-    pipe_load<INTEG>(pl, fr, slot, ln);
+    pipe_load<INTEG, EXT>(pl, fr, slot, ln);
     if (!__syncthreads_or(ln.stage != ST_EXIT)) return;
     __shared__ unsigned blk_cnt[2], blk_base[2];
     if (threadIdx.x < 2) blk_cnt[threadIdx.x] = 0u;
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(RT_BLOCK) void pipe_shade_kernel(const DevScene *__
             RT_GPTR(float4, pl.ray_o)[slot] = ro; RT_GPTR(float4, pl.ray_d)[slot] = rd;
         }
     }
-    pipe_store<INTEG>(pl, slot, ln);
+    pipe_store<INTEG, EXT>(pl, slot, ln);
     if (COUNT) {
         unsigned long long v[4] = {c_cam, c_closest, c_any, c_bad};
         const int idx[4] = {0, 1, 2, 6};

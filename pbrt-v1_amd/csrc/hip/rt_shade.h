@@ -11,7 +11,8 @@ enum { BX_REFLECTION = 1, BX_TRANSMISSION = 2, BX_DIFFUSE = 4, BX_GLOSSY = 8, BX
        BX_ALL = 31 };
 
 struct Vertex {
-    V3 p, nn, sn, tn;   // hit point, (geometric == shading) normal, BSDF frame
+    V3 p, nn, sn, tn;   // hit point, shading normal, BSDF frame (BSDF ctor reflection.cpp:471-479)
+    V3 ng;              // geometric normal: equals nn unless the mesh has per-vertex N / S (EXT kernels); the compiler folds the copy
     V3 wo;
     int mat, light;     // material index, area-light index of the primitive or -1
 };
@@ -85,6 +86,64 @@ RT_DEV void quadric_frame(const DevScene &sc, unsigned qi, bool flip, V3 ow, V3 
     if (flip) vnn = vnn * -1.f;
     vsn = normalize3(dpduW);
 }
+// Triangle::GetShadingGeometry (trianglemesh.cpp:71-133) -> Material::Bump with the always-present constant-0 displacement
+// (material.cpp:29-71) -> BSDF ctor (reflection.cpp:471-479) for a triangle with per-vertex N and / or S: the shading normal and
+// the tangent the BSDF frame is built from.  ngeom: geometric normal (flipped), gdpdu: Triangle::Intersect's dpdu (both per-triangle
+// constants evaluated on the host); b1, b2: the hit's barycentrics.
+RT_DEV V3 xform_normal_rm(const float RT_G *mi, V3 n) {                            // Transform::operator()(Normal) transform.h:106-111
+    return mk3(mi[0] * n.x + mi[4] * n.y + mi[8] * n.z, mi[1] * n.x + mi[5] * n.y + mi[9] * n.z, mi[2] * n.x + mi[6] * n.y + mi[10] * n.z);
+}
+RT_DEV V3 xform_vec3_rm(const float RT_G *m, V3 v) {                               // Transform::operator()(Vector) transform.h:93-98
+    return mk3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z);
+}
+RT_DEV void shading_frame(const DevScene &sc, const DevTriShading RT_G &r, float hb1, float hb2, V3 ngeom, bool flip, V3 &nn_out, V3 &sn_dir) {
+    const float RT_G *o2w = RT_GPTR(const float, sc.xforms) + size_t(32) * r.xform;
+    const float RT_G *o2wInv = o2w + 16;
+    float b0, b1, b2;
+    const float hb0 = 1 - hb1 - hb2;                                               // trianglemesh.cpp:270-272
+    const float tu = hb0 * r.uv[0] + hb1 * r.uv[2] + hb2 * r.uv[4];
+    const float tv_ = hb0 * r.uv[1] + hb1 * r.uv[3] + hb2 * r.uv[5];
+    const float A00 = r.uv[2] - r.uv[0], A01 = r.uv[4] - r.uv[0], A10 = r.uv[3] - r.uv[1], A11 = r.uv[5] - r.uv[1];
+    const float C0 = tu - r.uv[0], C1 = tv_ - r.uv[1];
+    const float det = A00 * A11 - A01 * A10;                                       // SolveLinearSystem2x2 util.cpp:99-108
+    if (fabsf(det) < 1e-5) b0 = b1 = b2 = 1.f / 3.f;
+    else {
+        const float invDet = 1.0f / det;
+        b1 = (A11 * C0 - A01 * C1) * invDet;
+        b2 = (A00 * C1 - A10 * C0) * invDet;
+        b0 = 1.f - b1 - b2;
+    }
+    const V3 n0 = mk3(r.n[0], r.n[1], r.n[2]), n1 = mk3(r.n[3], r.n[4], r.n[5]), n2 = mk3(r.n[6], r.n[7], r.n[8]);
+    V3 ns, ss, ts;
+    if (r.flags & RT_SHADING_N) ns = normalize3(xform_normal_rm(o2wInv, (n0 * b0 + n1 * b1) + n2 * b2)); else ns = ngeom;
+    if (r.flags & RT_SHADING_S) {
+        const V3 s0 = mk3(r.s[0], r.s[1], r.s[2]), s1 = mk3(r.s[3], r.s[4], r.s[5]), s2 = mk3(r.s[6], r.s[7], r.s[8]);
+        ss = normalize3(xform_vec3_rm(o2w, (s0 * b0 + s1 * b1) + s2 * b2));
+    } else ss = normalize3(mk3(r.dpdu[0], r.dpdu[1], r.dpdu[2]));
+    ts = normalize3(cross3(ss, ns));
+    ss = cross3(ts, ns);
+    V3 dndu = mk3(0.f), dndv = mk3(0.f);
+    if (r.flags & RT_SHADING_N) {
+        const float du1 = r.uv[0] - r.uv[4], du2 = r.uv[2] - r.uv[4], dv1 = r.uv[1] - r.uv[5], dv2 = r.uv[3] - r.uv[5];
+        const V3 dn1 = n0 - n2, dn2 = n1 - n2;
+        const float determinant = du1 * dv2 - dv1 * du2;
+        if (determinant != 0) {
+            const float invdet = 1.f / determinant;
+            dndu = (dv2 * dn1 - dv1 * dn2) * invdet;
+            dndv = (-du2 * dn1 + du1 * dn2) * invdet;
+        }
+    }
+    dndu = xform_vec3_rm(o2w, dndu); dndv = xform_vec3_rm(o2w, dndv);
+    V3 snn = normalize3(cross3(ss, ts));                                           // DifferentialGeometry ctor shape.cpp:37-51
+    if (flip) snn = snn * -1.f;
+    const float du = .01f, zero = 0.f;                                             // Bump: displacement 0 everywhere; du only divides 0
+    const V3 bdpdu = (ss + snn * ((zero - zero) / du)) + dndu * zero;
+    const V3 bdpdv = (ts + snn * ((zero - zero) / du)) + dndv * zero;
+    V3 bnn = normalize3(cross3(bdpdu, bdpdv));
+    if (flip) bnn = bnn * -1.f;
+    if (dot3(ngeom, bnn) < 0.f) bnn = bnn * -1.f;
+    nn_out = bnn; sn_dir = bdpdu;
+}
 template <bool EXT>
 RT_DEV void make_vertex(const DevScene &sc, const Trav &tv, Vertex &v) {
     const float4 RT_G *q = RT_GPTR(const float4, sc.tri_shade) + size_t(2) * unsigned(tv.hit_prim);
@@ -97,6 +156,13 @@ RT_DEV void make_vertex(const DevScene &sc, const Trav &tv, Vertex &v) {
         v.p = tv.o + tv.d * tv.maxt;                     // ray(t), geometry.h:210
         v.nn = mk3(a.x, a.y, a.z);                       // tri_frame(), precomputed per triangle on the host
         v.sn = mk3(b.x, b.y, b.z);
+    }
+    v.ng = v.nn;
+    if (EXT && (bits & RT_PRIM_SHADING)) {               // per-vertex N / S: the shading frame depends on where the triangle was hit
+        const DevTriShading RT_G &r = RT_GPTR(const DevTriShading, sc.tri_shading)[RT_GPTR(const int, sc.tri_shading_idx)[unsigned(tv.hit_prim)]];
+        V3 sdir;
+        shading_frame(sc, r, tv.b1, tv.b2, v.ng, (bits & 0x10000u) != 0, v.nn, sdir);
+        v.sn = normalize3(sdir);
     }
     v.tn = cross3(v.nn, v.sn);
     v.wo = -tv.d;
@@ -252,7 +318,7 @@ template <bool EXT>
 RT_DEV V3 bsdf_f(MatRef m, const Vertex &v, V3 woW, V3 wiW) {
     if (!mat_has_diffuse<EXT>(m) && !mat_has_glossy<EXT>(m)) return mk3(0.f);
     V3 wi = to_local(v, wiW), wo = to_local(v, woW);
-    if (dot3(wiW, v.nn) * dot3(woW, v.nn) > 0) return bsdf_f_lobes<EXT>(m, wo, wi, BX_ALL & ~BX_TRANSMISSION);   // BRDFs only
+    if (dot3(wiW, v.ng) * dot3(woW, v.ng) > 0) return bsdf_f_lobes<EXT>(m, wo, wi, BX_ALL & ~BX_TRANSMISSION);   // BRDFs only
     return mk3(0.f);                                                                                         // BTDFs only: none
 }
 
@@ -318,7 +384,7 @@ RT_DEV V3 bsdf_sample_f(MatRef m, const Vertex &v, V3 woW, V3 &wiW, float u1, fl
         wiW = to_world(v, wi);
         if (matching > 1) pdf /= matching;
         f = mk3(0.f);
-        if (dot3(wiW, v.nn) * dot3(woW, v.nn) > 0) f = bsdf_f_lobes<EXT>(m, wo, wi, flags & ~BX_TRANSMISSION);
+        if (dot3(wiW, v.ng) * dot3(woW, v.ng) > 0) f = bsdf_f_lobes<EXT>(m, wo, wi, flags & ~BX_TRANSMISSION);
         return f;
     }
     // specular lobes, in the order the material added them (glass.cpp:56-61, mirror.cpp:51-53)

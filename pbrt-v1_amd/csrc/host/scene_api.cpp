@@ -157,9 +157,14 @@ SurfaceIntegrator MakeSurfaceIntegrator(const std::string &name, const ParamSet 
         if (st == "one") si.strategy = RT_STRATEGY_ONE;
         else if (st == "all") si.strategy = RT_STRATEGY_ALL;
         else if (st == "weighted") {
-            Warning("Strategy \"weighted\" keeps a sequentially updated light CDF (directlighting.cpp:75-76, "
-                    "transport.cpp:71-122) that has no parallel definition; using \"one\".");
-            si.strategy = RT_STRATEGY_ONE;
+            // WeightedSampleOneLight (transport.cpp:71-122) picks the light from a CDF of exponentially averaged reflected luminances
+            // that every shading point of the frame updates in program order (avgY / overallAvgY members of the integrator,
+            // directlighting.cpp:75-76): each estimate depends on all earlier ones, the first one of the frame seeds the table.
+            // That is a sequential recurrence over ~10^7 shading points with no parallel (or shard-invariant) definition, so it is
+            // refused rather than replaced by a different estimator.
+            Error("Strategy \"weighted\" for direct lighting is a frame-long sequential recurrence (transport.cpp:71-122) and is not on the "
+                  "accelerated path; use \"all\" or \"one\"");
+            *ok = false; si.strategy = RT_STRATEGY_ONE;
         } else { Warning("Strategy \"%s\" for direct lighting unknown. Using \"all\".", st.c_str()); si.strategy = RT_STRATEGY_ALL; }
     } else { Error("Unable to load plugin \"%s\" (surface integrator)", name.c_str()); *ok = false; si.kind = RT_INTEGRATOR_WHITTED; }
     ps.ReportUnused();
@@ -240,13 +245,16 @@ void SceneDescription::finalize_pointers() {
     scene.n_lights = uint32_t(lights.size()); scene.lights = lights.data();
     scene.n_light_tris = uint32_t(light_tris.size() / 9); scene.light_tris = light_tris.data();
     scene.n_quadrics = uint32_t(quadrics.size()); scene.quadrics = quadrics.empty() ? nullptr : quadrics.data();
+    scene.tri_shading = tri_shading.empty() ? nullptr : tri_shading.data();
+    scene.n_shading = uint32_t(shading.size()); scene.shading = shading.empty() ? nullptr : shading.data();
+    scene.n_xforms = uint32_t(xforms.size() / 32); scene.xforms = xforms.empty() ? nullptr : xforms.data();
 }
 
 PbrtApi::PbrtApi() : state(STATE_OPTIONS), nVolumes(0), inObject(false) {
     // RenderOptions defaults api.cpp:62-71.  The reference's default sampler is "bestcandidate" (a
-    // precomputed 4096-entry tile pattern, samplers/bestcandidate.cpp) which is out of scope; scenes for
-    // this path name their sampler explicitly, and an unnamed one gets the reference's 2x2 stratified.
-    filterOpt.name = "mitchell"; filmOpt.name = "image"; samplerOpt.name = "stratified"; accelOpt.name = "kdtree";
+    // precomputed 4096-entry tile pattern, samplers/bestcandidate.cpp) which is out of scope: a scene that does not name
+    // one of the supported samplers fails loudly in MakeSampler ("Unable to load plugin") and its frame is invalid.
+    filterOpt.name = "mitchell"; filmOpt.name = "image"; samplerOpt.name = "bestcandidate"; accelOpt.name = "kdtree";
     surfOpt.name = "directlighting"; volOpt.name = "emission"; cameraOpt.name = "perspective";
     std::memset(&volume, 0, sizeof volume);
 }
@@ -437,10 +445,35 @@ void PbrtApi::Shape(const std::string &n, const ParamList &p) {                 
     const Float3 *P = ps.FindPoint("P", &npi);
     const float *uvs = ps.FindFloat("uv", &nuvi); if (!uvs) uvs = ps.FindFloat("st", &nuvi);
     if (!vi || !P) return;
+    // the factory's checks, in its order (trianglemesh.cpp:357-393)
+    if (uvs) {
+        if (nuvi < 2 * npi) { Error("Not enough of \"uv\"s for triangle mesh.  Expencted %d, found %d.  Discarding.\n", 2 * npi, nuvi); uvs = nullptr; }
+        else if (nuvi > 2 * npi) Warning("More \"uv\"s provided than will be used for triangle mesh.  (%d expcted, %d found)\n", 2 * npi, nuvi);
+    }
     int nni = 0, nsi = 0;
-    const Float3 *N = ps.FindNormal("N", &nni); const Float3 *S = ps.FindVector("S", &nsi);
-    if (uvs || N || S)
-        Warning("trianglemesh \"uv\"/\"N\"/\"S\" are ignored: per-vertex shading data is not on the accelerated path (constant textures only)");
+    const Float3 *S = ps.FindVector("S", &nsi);
+    if (S && nsi != npi) { Error("Number of \"S\"s for triangle mesh must match \"P\"s"); S = nullptr; }
+    const Float3 *N = ps.FindNormal("N", &nni);
+    if (N && nni != npi) { Error("Number of \"N\"s for triangle mesh must match \"P\"s"); N = nullptr; }
+    for (int i = 0; i < nvi && (uvs && N); ++i)
+        if (vi[i] >= npi || vi[i] < 0) { Error("trianglemesh has out of-bounds vertex index %d (%d \"P\" values were given", vi[i], npi); return; }
+    if (uvs && N) {                                                                 // degenerate mappings: discard all uvs
+        const int *vp = vi;
+        for (int i = 0; i + 2 < nvi; i += 3, vp += 3) {
+            const Float3 a = P[vp[0]], b = P[vp[1]], c = P[vp[2]];
+            const float e1[3] = {a.x - b.x, a.y - b.y, a.z - b.z}, e2[3] = {c.x - b.x, c.y - b.y, c.z - b.z};
+            const float cx = (e1[1] * e2[2]) - (e1[2] * e2[1]), cy = (e1[2] * e2[0]) - (e1[0] * e2[2]), cz = (e1[0] * e2[1]) - (e1[1] * e2[0]);
+            const float area = .5f * sqrtf(cx * cx + cy * cy + cz * cz);
+            if (area < 1e-7) continue;
+            if ((uvs[2 * vp[0]] == uvs[2 * vp[1]] && uvs[2 * vp[0] + 1] == uvs[2 * vp[1] + 1]) ||
+                (uvs[2 * vp[1]] == uvs[2 * vp[2]] && uvs[2 * vp[1] + 1] == uvs[2 * vp[2] + 1]) ||
+                (uvs[2 * vp[2]] == uvs[2 * vp[0]] && uvs[2 * vp[2] + 1] == uvs[2 * vp[0] + 1])) {
+                Warning("Degenerate uv coordinates in triangle mesh.  Discarding all uvs.");
+                uvs = nullptr;
+                break;
+            }
+        }
+    }
     for (int i = 0; i < nvi; ++i)
         if (vi[i] >= npi || vi[i] < 0) { Error("trianglemesh has out of-bounds vertex index %d (%d \"P\" values were given", vi[i], npi); return; }
     if (inObject) { Error("Object instancing is not on the accelerated path (SURVEY.md row 9); shape ignored"); return; }
@@ -453,6 +486,21 @@ void PbrtApi::Shape(const std::string &n, const ParamList &p) {                 
     mesh.verts.resize(size_t(ntris) * 9);
     for (int t = 0; t < ntris; ++t)
         for (int k = 0; k < 3; ++k) std::memcpy(&mesh.verts[size_t(t) * 9 + 3 * k], &world[size_t(3) * vi[3 * t + k]], 3 * sizeof(float));
+    if (uvs || N || S) {                                                            // TriangleMesh ctor :141-169 keeps uv / N / S per vertex
+        mesh.shading.resize(size_t(ntris));
+        std::memcpy(mesh.o2w, ctm.m.m, 16 * sizeof(float)); std::memcpy(mesh.o2w + 16, ctm.inv.m, 16 * sizeof(float));
+        for (int t = 0; t < ntris; ++t) {
+            RtTriShading &r = mesh.shading[size_t(t)]; std::memset(&r, 0, sizeof r);
+            r.flags = (uvs ? RT_SHADING_UV : 0) | (N ? RT_SHADING_N : 0) | (S ? RT_SHADING_S : 0);
+            const float def[6] = {0.f, 0.f, 1.f, 0.f, 1.f, 1.f};                    // GetUVs :321-326
+            for (int k = 0; k < 3; ++k) {
+                const int v = vi[3 * t + k];
+                r.uv[2 * k] = uvs ? uvs[2 * v] : def[2 * k]; r.uv[2 * k + 1] = uvs ? uvs[2 * v + 1] : def[2 * k + 1];
+                if (N) { r.n[3 * k] = N[v].x; r.n[3 * k + 1] = N[v].y; r.n[3 * k + 2] = N[v].z; }
+                if (S) { r.s[3 * k] = S[v].x; r.s[3 * k + 1] = S[v].y; r.s[3 * k + 2] = S[v].z; }
+            }
+        }
+    }
     mesh.light = -1;
     if (!gs.areaLight.empty()) {                                                    // api.cpp:362-366, area.cpp:106-111
         if (gs.areaLight != "area") Error("Unable to load plugin \"%s\" (area light)", gs.areaLight.c_str());
@@ -620,14 +668,22 @@ void PbrtApi::WorldEnd() {                                                      
     if (lights.empty()) Warning("No light sources defined in scene; possibly rendering a black image.");
 
     // primitives in KdTreeAccel order: per mesh, last triangle first (primitive.cpp:40-53, kdtree.cpp:146-148)
+    bool any_shading = false;
+    for (const Mesh &m : meshes) any_shading = any_shading || !m.shading.empty();
     for (const Mesh &m : meshes) {
         const int nt = int(m.verts.size() / 9);
+        uint32_t xf = 0;
+        if (!m.shading.empty()) { xf = uint32_t(sd->xforms.size() / 32); sd->xforms.insert(sd->xforms.end(), m.o2w, m.o2w + 32); }
         for (int t = nt - 1; t >= 0; --t) {
             sd->tri_verts.insert(sd->tri_verts.end(), &m.verts[size_t(t) * 9], &m.verts[size_t(t) * 9] + 9);
             sd->tri_material.push_back(uint16_t(m.material)); sd->tri_light.push_back(m.light); sd->tri_flags.push_back(m.flags);
+            if (any_shading) {
+                if (m.shading.empty()) sd->tri_shading.push_back(-1);
+                else { sd->tri_shading.push_back(int32_t(sd->shading.size())); sd->shading.push_back(m.shading[size_t(t)]); sd->shading.back().xform = xf; }
+            }
         }
     }
-    if (materials.size() > 65535) Error("more than 65535 material instances");
+    if (materials.size() > 65535) { Error("more than 65535 material instances"); all = false; }
     sd->materials = materials; sd->lights = lights; sd->light_tris = light_tris; sd->quadrics = quadrics;
     sd->scene.volume = volume; sd->scene.accel = acc.params;
     RtRenderDesc &r = sd->render;
@@ -693,6 +749,9 @@ void pbrt_host_scene_counts(const RtSceneDesc *s, unsigned *out4) { out4[0] = s-
 const float *pbrt_host_camera(const RtSceneDesc *s) { return s->camera.raster_to_camera; }
 const float *pbrt_host_tri_verts(const RtSceneDesc *s) { return s->tri_verts; }
 const RtAccelParams *pbrt_host_accel_params(const RtSceneDesc *s) { return &s->accel; }
+int pbrt_host_shading(const RtSceneDesc *s, const int32_t **idx, const RtTriShading **rec, const float **xforms, unsigned *n_rec, unsigned *n_xf) {
+    *idx = s->tri_shading; *rec = s->shading; *xforms = s->xforms; *n_rec = s->n_shading; *n_xf = s->n_xforms; return 0;
+}
 // scene-text writers for the synthetic generators (pbrt-v1_amd/scenes.py): "%.9g" round-trips every float32; np.savetxt
 // needs 24 s for the 9 M numbers of a 1 M-triangle mesh, snprintf 1 s.  Returns the bytes written (excluding the NUL), or -1.
 long long pbrt_host_format_f32(const float *v, long long n, int per_line, char *out, long long cap) {

@@ -45,6 +45,7 @@ struct SceneDescription {
     // flattened arrays referenced by `scene`
     std::vector<float> tri_verts; std::vector<uint16_t> tri_material; std::vector<int32_t> tri_light; std::vector<uint8_t> tri_flags;
     std::vector<RtMaterial> materials; std::vector<RtLight> lights; std::vector<float> light_tris; std::vector<RtQuadric> quadrics;
+    std::vector<int32_t> tri_shading; std::vector<RtTriShading> shading; std::vector<float> xforms;   // per-vertex uv / N / S (trianglemesh)
     RtSceneDesc scene; RtRenderDesc render;
     Film film;
     bool valid = false;
@@ -119,7 +120,8 @@ class PbrtApi : public DirectiveSink {
     } gs;
     std::vector<GraphicsState> gsStack; std::vector<Xform> xfStack;
     // world being accumulated
-    struct Mesh { std::vector<float> verts; int material; int light; uint8_t flags; };   // 9 floats per triangle, API order;
+    struct Mesh { std::vector<float> verts; int material; int light; uint8_t flags;
+                  std::vector<RtTriShading> shading; float o2w[32]; };                  // shading: empty or one record per triangle   // 9 floats per triangle, API order;
                                                                                         // flags bit1: a quadric (one slot = its world bound)
     std::vector<RtQuadric> quadrics;
     std::vector<Mesh> meshes;

@@ -178,6 +178,34 @@ def icosphere(center, radius, subdiv=2) -> np.ndarray:
     return (np.asarray(center, np.float64) + radius * tris).astype(np.float32)
 
 
+def smooth_mesh_text(radius=80.0, nu=10, nv=6, with_n=True, with_uv=True, with_s=False, squash=(1.0, 1.0, 1.0), mirror_uv=False) -> str:
+    """A latitude / longitude sphere as one `trianglemesh` with per-vertex "N" / "uv" / "S" (object space, centred at the
+    origin): the input of Triangle::GetShadingGeometry (shapes/trianglemesh.cpp:71-133).  `squash` scales the positions only, so
+    that the shading normals differ from the geometric ones by more than the tessellation; `mirror_uv` flips u (a mapping with
+    negative determinant: dpdu x dpdv then points the other way)."""
+    P, N, UV, S = [], [], [], []
+    for j in range(nv + 1):
+        th = np.pi * j / nv
+        for i in range(nu + 1):
+            ph = 2 * np.pi * i / nu
+            d = np.array([np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), np.cos(th)])
+            P.append(radius * d * np.array(squash)); N.append(d)
+            UV.append(((1.0 - i / nu) if mirror_uv else i / nu, j / nv))
+            S.append((-np.sin(ph), np.cos(ph), 0.0))
+    idx = []
+    for j in range(nv):
+        for i in range(nu):
+            a, b = j * (nu + 1) + i, j * (nu + 1) + i + 1
+            c, d = a + nu + 1, b + nu + 1
+            if j > 0: idx += [a, c, b]
+            if j < nv - 1: idx += [b, c, d]
+    out = 'Shape "trianglemesh" "integer indices" [%s] "point P" [%s]' % (" ".join(map(str, idx)), _fmt(np.array(P, np.float32).ravel()))
+    if with_n: out += ' "normal N" [%s]' % _fmt(np.array(N, np.float32).ravel())
+    if with_uv: out += ' "float uv" [%s]' % _fmt(np.array(UV, np.float32).ravel())
+    if with_s: out += ' "vector S" [%s]' % _fmt(np.array(S, np.float32).ravel())
+    return out + "\n"
+
+
 def options_block(xres=512, yres=512, integrator="whitted", integrator_params="", maxdepth=5,
                   sampler="stratified", xsamples=1, ysamples=1, jitter=False, pixelsamples=None,
                   pixel_filter="box", filter_params="", accelerator="kdtree", accel_params="",

@@ -48,8 +48,29 @@ QUADRICS2 = ('AttributeBegin\nMaterial "matte" "color Kd" [.7 .6 .2]\nTranslate 
              'AttributeBegin\nMaterial "plastic" "color Kd" [.2 .3 .7]\nTranslate 300 330 200\nRotate 40 1 0 1\nScale 60 60 60\nShape "hyperboloid" "point p1" [1 0 -1.2] "point p2" [.8 .9 1.1]\nAttributeEnd\n'
              'AttributeBegin\nMaterial "glass" "float index" [1.3]\nReverseOrientation\nTranslate 120 300 160\nRotate 100 0 1 0\nShape "hyperboloid" "point p1" [40 0 0] "point p2" [20 30 70] "float phimax" [270]\nAttributeEnd\n')
 
+def _mesh(mat, xf, **kw):
+    return "AttributeBegin\n%s\n%s\n%sAttributeEnd\n" % (mat, xf, scenes.smooth_mesh_text(**kw))
+
+# per-vertex N / uv / S (trianglemesh.cpp:71-133): smooth-shaded blobs under several materials and transforms
+MESH_N = (_mesh('Material "matte" "color Kd" [.7 .6 .3]', "Translate 160 110 330", radius=100, with_n=True, with_uv=False) +
+          _mesh('Material "plastic" "color Kd" [.2 .3 .7] "float roughness" [.1]', "Translate 400 130 220\nRotate 40 1 0.3 0\nScale 1 1.4 0.8", radius=80, with_n=True, with_uv=False, squash=(1, 1, .7)))
+MESH_NUV = (_mesh('Material "matte" "color Kd" [.6 .6 .6] "float sigma" [30]', "Translate 170 120 300\nRotate 25 0 1 0", radius=100, with_n=True, with_uv=True, squash=(1, .8, 1)) +
+            _mesh('Material "plastic" "color Kd" [.6 .2 .2] "float roughness" [.2]', "ReverseOrientation\nTranslate 400 300 300\nScale -1 1 1", radius=70, with_n=True, with_uv=True, mirror_uv=True))
+MESH_NSUV = (_mesh('Material "matte" "color Kd" [.5 .6 .7]', "Translate 160 110 330\nRotate 70 1 0 0", radius=95, with_n=True, with_uv=True, with_s=True) +
+             _mesh('Material "glass" "float index" [1.5]', "Translate 390 150 230\nScale 1 1.2 1", radius=85, with_n=True, with_uv=True, with_s=True, squash=(1, 1, .85)))
+MESH_UV = _mesh('Material "matte" "color Kd" [.7 .7 .4]', "Translate 200 130 300\nRotate 30 0 0 1", radius=110, with_n=False, with_uv=True, mirror_uv=True)
+MESH_S = _mesh('Material "plastic" "color Kd" [.3 .6 .3] "float roughness" [.3]', "Translate 300 140 300\nRotate 50 1 1 0", radius=110, with_n=False, with_uv=False, with_s=True)
+MESH_GM = (_mesh('Material "glass" "float index" [1.4]', "Translate 170 130 280", radius=100, with_n=True, with_uv=False, squash=(1, 1, .8)) +
+           _mesh('Material "mirror"', "Translate 410 140 330\nRotate 20 0 1 0", radius=90, with_n=True, with_uv=True))
+
 CONFIGS = {
     # name: cornell_scene kwargs  (all keyed RNG + counted rays)
+    "mesh_n_whitted": dict(xres=40, yres=40, integrator="whitted", world_kwargs=dict(extra=MESH_N, point_light=True)),
+    "mesh_nuv_direct": dict(xres=40, yres=40, integrator="directlighting", xsamples=2, ysamples=1, jitter=True, world_kwargs=dict(extra=MESH_NUV, light_nsamples=2)),
+    "mesh_nsuv_path": dict(xres=40, yres=40, integrator="path", xsamples=2, ysamples=2, jitter=True, world_kwargs=dict(extra=MESH_NSUV)),
+    "mesh_uv_only_path": dict(xres=36, yres=36, integrator="path", xsamples=2, ysamples=2, world_kwargs=dict(extra=MESH_UV)),
+    "mesh_s_only_direct": dict(xres=36, yres=36, integrator="directlighting", world_kwargs=dict(extra=MESH_S)),
+    "mesh_n_glass_mirror_whitted": dict(xres=40, yres=40, integrator="whitted", xsamples=2, ysamples=1, world_kwargs=dict(extra=MESH_GM)),
     "whitted_point": dict(xres=48, yres=48, integrator="whitted", world_kwargs=dict(point_light=True, area_light=False)),
     "whitted_area": dict(xres=48, yres=48, integrator="whitted"),
     "whitted_glass_mirror": dict(xres=48, yres=48, integrator="whitted", world_kwargs=dict(mirror_quad=True, glass_sphere_tris=blob)),

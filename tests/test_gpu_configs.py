@@ -174,3 +174,42 @@ def test_c3_full_size_properties(pkg, scenes):
     for k in COUNTERS:
         assert cb[k] == ca[k], k
     assert np.allclose(b[:3], 2 * a[:3], rtol=1e-5, atol=1e-5) and np.array_equal(b[4], a[4]) and np.array_equal(b[3], a[3])
+
+
+# ---------------------------------------------------------------------------------------------- per-vertex N / uv / S
+@pytest.mark.parametrize("integrator,extra", [("whitted", dict(xsamples=2, ysamples=1)), ("directlighting", dict(xsamples=2, ysamples=2, jitter=True)),
+                                              ("path", dict(xsamples=2, ysamples=2, jitter=True, maxdepth=6))])
+def test_smooth_meshes_against_the_oracle(pkg, scenes, oracle, integrator, extra):
+    """Triangle::GetShadingGeometry (trianglemesh.cpp:71-133) at a size the fixtures do not reach: finely tessellated blobs with
+    N, N + uv (mirrored mapping), N + S + uv and S only, under rotations / non-uniform scales / ReverseOrientation, every material,
+    inside the Cornell box with a 4 k-triangle soup; device (EXT kernels) against the oracle, all kernel flavours bit-identical."""
+    need_gpu(pkg)
+    def mesh(mat, xf, **kw):
+        return "AttributeBegin\n%s\n%s\n%sAttributeEnd\n" % (mat, xf, scenes.smooth_mesh_text(nu=28, nv=18, **kw))
+    world = (mesh('Material "matte" "color Kd" [.7 .6 .3] "float sigma" [20]', "Translate 150 110 330\nRotate 33 1 1 0", radius=95, with_n=True, with_uv=False, squash=(1, .8, 1)) +
+             mesh('Material "plastic" "color Kd" [.2 .3 .7] "float roughness" [.1]', "ReverseOrientation\nTranslate 410 130 220\nScale -1 1.3 .8", radius=75, with_n=True, with_uv=True, mirror_uv=True) +
+             mesh('Material "glass" "float index" [1.45]', "Translate 300 330 300\nRotate 70 0 1 0", radius=80, with_n=True, with_uv=True, with_s=True, squash=(1, 1, .85)) +
+             mesh('Material "mirror"', "Translate 120 400 200", radius=60, with_n=False, with_uv=False, with_s=True) +
+             mesh('Material "uber" "color Kd" [.4 .4 .2] "color Kr" [.2 .2 .2]', "Translate 430 420 420\nRotate 15 0 0 1", radius=55, with_n=True, with_uv=True))
+    ps = pkg.ParsedScene(text=scenes.cornell_scene(xres=112, yres=112, integrator=integrator, soup_tris=4000, keyed=True, seed=5,
+                                                   world_kwargs=dict(extra=world, point_light=(integrator == "whitted")), **extra))
+    assert ps.valid and ps.errors == 0 and ps.warnings == 0
+    ds = pkg.DeviceScene(ps)
+    ds.render()
+    rgb, alpha = ds.film()
+    cnt = ds.counters()
+    acc = ds.film_accum()
+    nodes, refs, bounds, info = accel_of(ds)
+    for env in (dict(PBRT_HIP_PIPELINE="0"), dict(PBRT_HIP_PIPELINE="1")):
+        with pytest.MonkeyPatch.context() as mp:
+            for k, v in env.items():
+                mp.setenv(k, v)
+            ds.set_counting(False); ds.clear_film(); ds.render()
+            assert np.array_equal(ds.film_accum(), acc), env
+    ds.close()
+    orgb, oalpha, _, ocnt = oracle.render(ps, nodes, refs, bounds, info=info)
+    m = check_film("smooth:" + integrator, rgb, alpha, orgb, oalpha, 2 if integrator == "path" else ps.integrator)
+    assert cnt["camera_rays"] == ocnt["camera_rays"] and cnt["bad_samples"] == 0
+    if integrator != "path":
+        for k in COUNTERS:
+            assert cnt[k] == ocnt[k], (k, cnt[k], ocnt[k])

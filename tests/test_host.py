@@ -6,6 +6,7 @@ import pytest
 BASE = '''LookAt 0 0 -5  0 0 0  0 1 0
 Camera "perspective" "float fov" [45]
 Film "image" "integer xresolution" [16] "integer yresolution" [8]
+Sampler "stratified"
 %s
 WorldBegin
 %s
@@ -102,6 +103,41 @@ def test_f4_plugins_are_accepted(pkg):
     # a quadric under AreaLightSource becomes an area light whose shape is the quadric itself (area.cpp:38-39)
     ps = pkg.ParsedScene(text=BASE % ("", 'AreaLightSource "area" "color L" [3 3 3]\nShape "sphere" "float radius" [1]\n' + TRI))
     assert ps.valid and ps.errors == 0 and ps.n_lights == 2 and ps.n_light_tris == 1
+
+
+def test_reference_features_off_the_path_invalidate_the_frame(pkg):
+    """Nothing is silently replaced by something else: the reference's default sampler
+    (bestcandidate, api.cpp:62-71) and the "weighted" light strategy (transport.cpp:71-122) are Errors that leave the frame
+    invalid, exactly like an unknown plugin."""
+    ps = pkg.ParsedScene(text=(BASE % ("", 'LightSource "point"\n' + TRI)).replace('Sampler "stratified"\n', ""))
+    assert not ps.valid and ps.errors >= 1
+    ps = pkg.ParsedScene(text=BASE % ('SurfaceIntegrator "directlighting" "string strategy" ["weighted"]', 'LightSource "point"\n' + TRI))
+    assert not ps.valid and ps.errors >= 1
+    ps = pkg.ParsedScene(text=BASE % ('SurfaceIntegrator "directlighting" "string strategy" ["one"]', 'LightSource "point"\n' + TRI))
+    assert ps.valid and ps.errors == 0 and ps.warnings == 0
+
+
+def test_trianglemesh_vertex_data_and_the_factory_checks(pkg):
+    """"uv" / "st", "N", "S" reach the scene description as per-triangle records (RtTriShading); the checks of
+    shapes/trianglemesh.cpp:357-393 are applied: short uv arrays and N / S of the wrong length are discarded with an Error,
+    degenerate uvs next to normals discard all uvs with a Warning."""
+    import ctypes as C
+    quad = ('Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [0 0 0  1 0 0  1 1 0  0 1 0] %s\n')
+    def records(extra):
+        ps = pkg.ParsedScene(text=BASE % ("", 'LightSource "point"\nAttributeBegin\nTranslate 0 0 1\n' + quad % extra + 'AttributeEnd\n' + TRI))
+        return ps, pkg.shading_records(ps)
+    ps, rec = records('"normal N" [0 0 1  0 0 1  0 1 1  1 0 1] "float uv" [0 0  1 0  1 1  0 1]')
+    assert ps.valid and ps.errors == 0 and ps.warnings == 0 and ps.n_tris == 3
+    idx, sh, xf = rec
+    assert list(idx) == [0, 1, -1] and len(sh) == 2 and xf.shape == (1, 32)
+    assert sh["flags"][0] == 3 and np.allclose(sh["uv"][0], [0, 0, 1, 1, 0, 1]) and np.allclose(sh["n"][1][6:9], [0, 1, 1])   # last triangle first
+    assert np.allclose(xf[0, :16].reshape(4, 4)[:3, 3], [0, 0, 1])
+    ps, rec = records('"float st" [0 0 1 0] "vector S" [1 0 0  1 0 0  1 0 0  1 0 0]')
+    assert ps.errors >= 1 and rec[1]["flags"][0] == 4 and np.allclose(rec[1]["uv"][0], [0, 0, 1, 0, 1, 1])             # uvs discarded -> GetUVs defaults
+    ps, rec = records('"normal N" [0 0 1 0 0 1]')
+    assert ps.errors >= 1 and rec[0] is None
+    ps, rec = records('"normal N" [0 0 1  0 0 1  0 0 1  0 0 1] "float uv" [0 0  0 0  1 1  0 1]')
+    assert ps.errors == 0 and ps.warnings >= 1 and rec[1]["flags"][0] == 2
 
 
 def test_include_and_comments(pkg, tmp_path):
