@@ -253,6 +253,10 @@ int rt_film_resolve(RtScene *s, int premultiply_alpha, float *rgb_out, float *al
  * handle's stream.  rt_sync waits.  Counters accumulate until rt_counters_reset. */
 int rt_render(RtScene *s, const RtRenderDesc *rd);
 int rt_sync(RtScene *s);
+/* per-camera-sample results of the last rt_render, before filtering: out[count][8] = L.rgb, alpha, imageX, imageY, 0, 0 in the
+ * sampler's order (what Scene::Render hands to Film::AddSample, scene.cpp:76).  The reference-side binding
+ * (oracle/ref/hip_adapter.cpp) serves SurfaceIntegrator::Li from it. */
+int rt_samples_read(RtScene *s, uint64_t first, uint64_t count, float *out);
 int rt_counters(RtScene *s, RtCounters *out);             /* synchronises */
 int rt_counters_reset(RtScene *s);
 /* per-ray statistics cost a few VALU ops per node visit: enabled (default) for parity/accounting runs,

@@ -12,6 +12,8 @@
 #include <stdint.h>
 extern "C" void keyed_rng_set_key(uint32_t key);
 extern "C" void keyed_rng_set_seed(uint32_t seed);
+extern "C" const void *g_keyed_inner_sampler;     // ref_driver.cpp: read by hip_adapter.cpp (the description names the inner sampler)
+extern "C" unsigned g_keyed_seed;
 
 class KeyedSampler : public Sampler {
 public:
@@ -35,5 +37,6 @@ extern "C" DLLEXPORT Sampler *CreateSampler(const ParamSet &params, const Film *
     keyed_rng_set_key(0xFFFFFFFFu);           // constructor draws of the inner sampler
     Sampler *in = MakeSampler(innerName, params, film);
     if (!in) return NULL;
+    g_keyed_inner_sampler = in; g_keyed_seed = (unsigned)params.FindOneInt("seed", 0);
     return new KeyedSampler(in);
 }

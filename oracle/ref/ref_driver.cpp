@@ -36,6 +36,8 @@ extern "C" {
 unsigned long long g_ref_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // [0]=Intersect calls [1]=IntersectP calls [2]=Intersect hits [3]=IntersectP hits
 double g_ref_times[4] = {0, 0, 0, 0};                             // [0]=accel build s  [1]=t(build done)  [2]=t(film written)
 double ref_now() { timeval tv; gettimeofday(&tv, NULL); return tv.tv_sec + 1e-6 * tv.tv_usec; }
+const void *g_keyed_inner_sampler = NULL;                         // set by keyed_sampler.cpp, read by hip_adapter.cpp
+unsigned g_keyed_seed = 0;
 }
 
 static string g_outPath;

@@ -25,7 +25,7 @@ def load_ref_film(path: str):
 REF_DIR = os.path.join(_HERE, "_ref")
 
 
-def run_reference(scene_text: str, keyed: bool = True, workdir: str | None = None, timeout: float = 3600):
+def run_reference(scene_text: str, keyed: bool = True, workdir: str | None = None, timeout: float = 3600, env: dict | None = None):
     """Run the compiled reference (oracle/_ref) on a scene; returns (rgb, alpha, stats dict).
     TEST/BENCH infrastructure only -- never on the product path."""
     import json
@@ -38,7 +38,7 @@ def run_reference(scene_text: str, keyed: bool = True, workdir: str | None = Non
     fp = os.path.join(d, "film.bin")
     with open(sp, "w") as f:
         f.write(scene_text)
-    env = dict(os.environ, PBRT_SEARCHPATH=os.path.join(REF_DIR, "bin"))
+    env = dict(os.environ, PBRT_SEARCHPATH=os.path.join(REF_DIR, "bin"), **(env or {}))
     r = subprocess.run([exe, "--out", fp, sp], env=env, capture_output=True, text=True, timeout=timeout, cwd=d)
     if r.returncode != 0:
         raise RuntimeError("reference run failed: %s\n%s" % (r.stdout[-2000:], r.stderr[-2000:]))
@@ -55,3 +55,23 @@ def run_reference(scene_text: str, keyed: bool = True, workdir: str | None = Non
     stats["stats"] = table
     rgb, alpha, _ = load_ref_film(fp)
     return rgb, alpha, stats
+
+
+def as_hip_plugin_scene(scene_text: str) -> str:
+    """The same scene rendered through the reference-side binding oracle/ref/hip_adapter.cpp: the surface integrator and the
+    accelerator become the "hip" plugin (which names the reference plugin it stands for as "inner")."""
+    import re
+    text = re.sub(r'SurfaceIntegrator "(whitted|directlighting|path)"', r'SurfaceIntegrator "hip" "string inner" ["\1"]', scene_text)
+    text = re.sub(r'Accelerator "countaccel" "string inner" \["(\w+)"\]', r'Accelerator "hip" "string inner" ["\1"]', text)
+    text = re.sub(r'Accelerator "(kdtree|grid)"', r'Accelerator "hip" "string inner" ["\1"]', text)
+    assert '"hip"' in text
+    return text
+
+
+def reference_descriptors(scene_text: str, keyed: bool = False) -> bytes:
+    """rt_desc_serialize() of the descriptors the adapter builds from the reference's own objects (PBRT_HIP_DESC_DUMP)."""
+    import tempfile
+    d = tempfile.mkdtemp(prefix="pbrtdesc_")
+    dump = os.path.join(d, "desc.bin")
+    run_reference(as_hip_plugin_scene(scene_text), keyed=keyed, workdir=d, env={"PBRT_HIP_DESC_DUMP": dump})
+    return open(dump, "rb").read()

@@ -23,7 +23,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                "-Wno-unused-value"]
-HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-msse2", "-mfpmath=sse"]
+HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-msse2", "-mfpmath=sse", "-fvisibility=hidden", "-fvisibility-inlines-hidden"]
 
 
 HIP_UNITS = ("rt_kernels.hip", "rt_trace.hip", "rt_mega_w.hip", "rt_mega_d.hip", "rt_mega_p.hip", "rt_pipe_w.hip", "rt_pipe_d.hip",
@@ -72,7 +72,7 @@ def build(force: bool = False, verbose: bool = False, defines=(), jobs: int | No
             print(" ".join(cmd))
         subprocess.check_call(cmd)
     if stale(HOST_LIB, host_dep):
-        cmd = ["g++"] + HOST_FLAGS + host_src + ["-o", HOST_LIB]
+        cmd = ["g++"] + HOST_FLAGS + host_src + ["-Wl,--version-script=" + os.path.join(CSRC, "host", "exports.map"), "-o", HOST_LIB]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
@@ -118,7 +118,7 @@ def hip_lib():
         for name in ("rt_scene_create", "rt_scene_destroy", "rt_scene_set_stream", "rt_scene_accel_info",
                      "rt_scene_accel_copy", "rt_camera_rays", "rt_trace_closest", "rt_trace_any", "rt_film_bind",
                      "rt_film_clear", "rt_film_read", "rt_film_resolve", "rt_render", "rt_sync", "rt_counters",
-                     "rt_counters_reset", "rt_last_render_ms", "rt_last_render_stats", "rt_device_count", "rt_set_counting",
+                     "rt_counters_reset", "rt_last_render_ms", "rt_last_render_stats", "rt_samples_read", "rt_device_count", "rt_set_counting",
                      "rt_kdtree_build", "rt_kdtree_info", "rt_kdtree_copy", "rt_kdtree_destroy",
                      "rt_accel_build", "rt_accel_info", "rt_accel_copy", "rt_accel_destroy"):
             getattr(L, name).restype = C.c_int
@@ -140,6 +140,7 @@ def hip_lib():
         L.rt_counters_reset.argtypes = [C.c_void_p]
         L.rt_last_render_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.rt_last_render_stats.argtypes = [C.c_void_p, C.POINTER(RtRenderStats)]
+        L.rt_samples_read.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
         L.rt_device_count.argtypes = [C.POINTER(C.c_int)]
         L.rt_set_counting.argtypes = [C.c_void_p, C.c_int]
         L.rt_kdtree_build.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p)]
@@ -337,6 +338,16 @@ class ParsedScene:
         p = host_lib().pbrt_host_tri_verts(self.scene_desc)
         return np.ctypeslib.as_array(p, shape=(self.n_tris, 3, 3)).copy()
 
+    def serialize(self) -> bytes:
+        """Canonical byte image of this frame's descriptors (include/pbrt_hip_desc.h rt_desc_serialize)."""
+        H = host_lib()
+        H.pbrt_host_serialize.restype = C.c_longlong
+        H.pbrt_host_serialize.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong]
+        n = H.pbrt_host_serialize(self._h, self.frame, None, 0)
+        buf = C.create_string_buffer(int(n))
+        H.pbrt_host_serialize(self._h, self.frame, buf, n)
+        return buf.raw
+
     def close(self):
         if self._h:
             host_lib().pbrt_host_free(self._h)
@@ -426,6 +437,13 @@ class DeviceScene:
         a, b = C.c_float(0), C.c_float(0)
         _chk(hip_lib().rt_last_render_ms(self._s, C.byref(a), C.byref(b)))
         return float(a.value), float(b.value)
+
+    def samples(self, first: int = 0, count: int | None = None) -> np.ndarray:
+        """The per-camera-sample records of the last render: [n][8] = L.rgb, alpha, imageX, imageY, -, - in the sampler's order."""
+        n = self.parsed.n_camera_samples - first if count is None else count
+        out = np.zeros((n, 8), np.float32)
+        _chk(hip_lib().rt_samples_read(self._s, first, n, out.ctypes.data))
+        return out
 
     def last_stats(self) -> dict:
         st = RtRenderStats()

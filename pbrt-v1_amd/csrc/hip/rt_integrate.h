@@ -260,6 +260,9 @@ RT_DEV void setup_sample(const DevScene &sc, const DevFrame &fr, Lane &ln, unsig
     }
     ln.rng.ctr = ln.dim_base + ((fr.sampler == RT_SAMPLER_LOWDISCREPANCY) ? 0u : fr.lhs_total);
     ray = camera_ray(sc.cam, ln.image_x, ln.image_y, lu, lv);
+    // scene.cpp:47-53 generates the differential's offset rays with ++ / -- on sample->imageX / imageY: Film::AddSample later sees
+    // (x + 1) - 1 in float arithmetic, not x (found by the reference-side binding test, tests/test_boundary.py)
+    ln.image_x = (ln.image_x + 1.f) - 1.f; ln.image_y = (ln.image_y + 1.f) - 1.f;
 }
 
 // ---- recursion frames (whitted / directlighting) ---------------------------------------------------------

@@ -1102,6 +1102,17 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
     return RT_OK;
 }
 
+// The radiance of every camera sample of the last rt_render, before filtering: what Scene::Render's loop hands to
+// Film::AddSample (scene.cpp:76), in the sampler's order (shard-local work order).  8 floats per sample.
+int rt_samples_read(RtScene *s, uint64_t first, uint64_t count, float *out) {
+    if (!s || !out) return fail(RT_EINVAL, "null argument");
+    if (!s->samples || 2 * (first + count) > s->samples_cap) return fail(RT_ESTATE, "rt_samples_read: no frame rendered / range beyond the last frame");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipMemcpy(out, s->samples + 2 * first, size_t(count) * 2 * sizeof(float4), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
 int rt_sync(RtScene *s) {
     if (!s) return fail(RT_EINVAL, "null scene");
     HIPCHK(hipSetDevice(s->device));

@@ -1,5 +1,6 @@
 // scene_api.cpp -- see scene_api.h.  Citations are to the reference tree (/root/reference).
 #include "scene_api.h"
+#include "../../../include/pbrt_hip_desc.h"
 #include "exr_io.h"
 #include <cmath>
 #include <cstdarg>
@@ -137,7 +138,10 @@ Sampler MakeSampler(const std::string &nameIn, const ParamSet &ps, const Film &,
         s.xsamples = ps.FindOneInt("xsamples", 2); s.ysamples = ps.FindOneInt("ysamples", 2);
     } else if (name == "lowdiscrepancy") {                                          // lowdiscrepancy.cpp:129-136
         s.kind = RT_SAMPLER_LOWDISCREPANCY; s.pixelsamples = ps.FindOneInt("pixelsamples", 4);
-        if (s.pixelsamples & (s.pixelsamples - 1)) Warning("Pixel samples being rounded up to power of 2");
+        if (s.pixelsamples & (s.pixelsamples - 1)) {                                // LDSampler ctor lowdiscrepancy.cpp:62-66
+            Warning("Pixel samples being rounded up to power of 2");
+            unsigned v = unsigned(s.pixelsamples); v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; s.pixelsamples = int(v + 1);
+        }
     } else if (name == "random") {                                                  // random.cpp:118-126
         s.kind = RT_SAMPLER_RANDOM; s.xsamples = ps.FindOneInt("xsamples", 2); s.ysamples = ps.FindOneInt("ysamples", 2);
     } else { Error("Unable to load plugin \"%s\" (sampler)", name.c_str()); *ok = false; s.kind = RT_SAMPLER_STRATIFIED; }
@@ -709,6 +713,8 @@ void PbrtApi::WorldEnd() {                                                      
 
 // ------------------------------------------------------------------ C entry points for the Python harness
 using namespace pbrthip;
+// the library is compiled -fvisibility=hidden: these C entry points are its whole dynamic surface
+#pragma GCC visibility push(default)
 extern "C" {
 struct PbrtHostScene { PbrtApi api; };
 
@@ -749,6 +755,12 @@ void pbrt_host_scene_counts(const RtSceneDesc *s, unsigned *out4) { out4[0] = s-
 const float *pbrt_host_camera(const RtSceneDesc *s) { return s->camera.raster_to_camera; }
 const float *pbrt_host_tri_verts(const RtSceneDesc *s) { return s->tri_verts; }
 const RtAccelParams *pbrt_host_accel_params(const RtSceneDesc *s) { return &s->accel; }
+// canonical byte image of a frame's descriptors (include/pbrt_hip_desc.h); returns the size, writes when the buffer is large enough
+long long pbrt_host_serialize(PbrtHostScene *h, int i, unsigned char *out, long long cap) {
+    const size_t n = rt_desc_serialize(&h->api.frames[i]->scene, &h->api.frames[i]->render, nullptr);
+    if (out && (long long)n <= cap) rt_desc_serialize(&h->api.frames[i]->scene, &h->api.frames[i]->render, out);
+    return (long long)n;
+}
 int pbrt_host_shading(const RtSceneDesc *s, const int32_t **idx, const RtTriShading **rec, const float **xforms, unsigned *n_rec, unsigned *n_xf) {
     *idx = s->tri_shading; *rec = s->shading; *xforms = s->xforms; *n_rec = s->n_shading; *n_xf = s->n_xforms; return 0;
 }
@@ -787,3 +799,4 @@ int pbrt_host_read_exr(const char *path, float *rgb, float *alpha) {
     std::memcpy(rgb, img.rgb.data(), img.rgb.size() * sizeof(float)); std::memcpy(alpha, img.alpha.data(), img.alpha.size() * sizeof(float)); return 0;
 }
 }
+#pragma GCC visibility pop
