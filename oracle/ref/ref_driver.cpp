@@ -123,12 +123,57 @@ struct RefSink : pbrthip::DirectiveSink {
 };
 }  // namespace
 
+// ---- the Cornell box of BASELINE.json configs[0] / configs[1] issued through the reference's API (core/api.h:29-85) by hand-written
+// calls: no scene text, no tokenizer, no ParamList -- the reference run that does NOT share the product's parser
+// (tests/test_parity_chain.py compares it with the run of the equivalent scene file).  Numbers are those of
+// pbrt-v1_amd/scenes.py (CORNELL_QUADS, CORNELL_LIGHT); kind: "c1" Whitted 1 spp box filter, "c2" path maxdepth 5 jittered 2x2 mitchell.
+static void one_float(ParamSet &ps, const char *n, float v) { ps.AddFloat(n, &v, 1); }
+static void one_int(ParamSet &ps, const char *n, int v) { ps.AddInt(n, &v, 1); }
+static void one_string(ParamSet &ps, const char *n, const char *v) { string sv(v); ps.AddString(n, &sv, 1); }
+static void one_color(ParamSet &ps, const char *n, float r, float g, float b) { float c[3] = {r, g, b}; Spectrum sp(c); ps.AddSpectrum(n, &sp, 1); }
+static void quad(const float *v12, const char *mat, float r, float g, float b) {
+    pbrtAttributeBegin();
+    { ParamSet m; one_color(m, "Kd", r, g, b); pbrtMaterial(mat, m); }
+    ParamSet ps; int idx[6] = {0, 1, 2, 0, 2, 3};
+    ps.AddInt("indices", idx, 6); ps.AddPoint("P", (const Point *)v12, 4);
+    pbrtShape("trianglemesh", ps);
+    pbrtAttributeEnd();
+}
+static bool BuiltinCornell(const string &kind, int res, bool keyed) {
+    const bool c2 = kind == "c2";
+    pbrtLookAt(278, 273, -800, 278, 273, 0, 0, 1, 0);
+    { ParamSet ps; one_float(ps, "fov", 39.3f); pbrtCamera("perspective", ps); }
+    { ParamSet ps; one_int(ps, "xresolution", res); one_int(ps, "yresolution", res); one_string(ps, "filename", "out.exr"); pbrtFilm("image", ps); }
+    { ParamSet ps; one_int(ps, "xsamples", c2 ? 2 : 1); one_int(ps, "ysamples", c2 ? 2 : 1); bool j = c2; ps.AddBool("jitter", &j, 1);
+      if (keyed) { one_string(ps, "inner", "stratified"); one_int(ps, "seed", 0); pbrtSampler("keyed", ps); } else pbrtSampler("stratified", ps); }
+    { ParamSet ps; pbrtPixelFilter(c2 ? "mitchell" : "box", ps); }
+    { ParamSet ps; one_int(ps, "maxdepth", 5); pbrtSurfaceIntegrator(c2 ? "path" : "whitted", ps); }
+    { ParamSet ps; one_string(ps, "inner", "kdtree"); pbrtAccelerator("countaccel", ps); }
+    pbrtWorldBegin();
+    static const float floor_[12] = {552.8f, 0, 0, 0, 0, 0, 0, 0, 559.2f, 549.6f, 0, 559.2f};
+    static const float ceil_[12] = {556, 548.8f, 0, 556, 548.8f, 559.2f, 0, 548.8f, 559.2f, 0, 548.8f, 0};
+    static const float back_[12] = {549.6f, 0, 559.2f, 0, 0, 559.2f, 0, 548.8f, 559.2f, 556, 548.8f, 559.2f};
+    static const float right_[12] = {0, 0, 559.2f, 0, 0, 0, 0, 548.8f, 0, 0, 548.8f, 559.2f};
+    static const float left_[12] = {552.8f, 0, 0, 549.6f, 0, 559.2f, 556, 548.8f, 559.2f, 556, 548.8f, 0};
+    static const float light_[12] = {343, 548.7f, 227, 343, 548.7f, 332, 213, 548.7f, 332, 213, 548.7f, 227};
+    quad(floor_, "matte", .73f, .73f, .73f); quad(ceil_, "matte", .73f, .73f, .73f); quad(back_, "matte", .73f, .73f, .73f);
+    quad(right_, "matte", .12f, .45f, .15f); quad(left_, "matte", .65f, .05f, .05f);
+    pbrtAttributeBegin();
+    { ParamSet ps; one_color(ps, "L", 17, 12, 4); one_int(ps, "nsamples", 1); pbrtAreaLightSource("area", ps); }
+    quad(light_, "matte", 0, 0, 0);
+    pbrtAttributeEnd();
+    pbrtWorldEnd();
+    return true;
+}
+
 int main(int argc, char **argv) {
-    bool quiet = false; string scene;
+    bool quiet = false; string scene, builtin; int builtin_res = 64; bool builtin_keyed = false;
     for (int i = 1; i < argc; ++i) {
         string a = argv[i];
         if (a == "--out" && i + 1 < argc) g_outPath = argv[++i];
         else if (a == "--quiet") quiet = true;
+        else if (a == "--builtin" && i + 2 < argc) { builtin = argv[++i]; builtin_res = atoi(argv[++i]); scene = "<builtin>"; }
+        else if (a == "--keyed-sampler") builtin_keyed = true;
         else scene = a;
     }
     if (scene.empty()) { fprintf(stderr, "usage: %s [--out film.bin] [--quiet] scene.pbrt\n", argv[0]); return 2; }
@@ -142,7 +187,7 @@ int main(int argc, char **argv) {
     RefSink sink;
     pbrthip::SceneParser parser(sink);
     current_file = scene;
-    bool ok = parser.ParseFile(scene);
+    bool ok = builtin.empty() ? parser.ParseFile(scene) : BuiltinCornell(builtin, builtin_res, builtin_keyed);
     pbrtCleanup();
     double t1 = ref_now();
     if (quiet) { fflush(stdout); dup2(savedOut, 1); close(savedOut); }

@@ -37,9 +37,11 @@ def run_reference(scene_text: str, keyed: bool = True, workdir: str | None = Non
     sp = os.path.join(d, "scene.pbrt")
     fp = os.path.join(d, "film.bin")
     with open(sp, "w") as f:
-        f.write(scene_text)
+        f.write(scene_text if isinstance(scene_text, str) else "")
     env = dict(os.environ, PBRT_SEARCHPATH=os.path.join(REF_DIR, "bin"), **(env or {}))
-    r = subprocess.run([exe, "--out", fp, sp], env=env, capture_output=True, text=True, timeout=timeout, cwd=d)
+    # a tuple ("builtin", kind, res) runs the hand-written API calls of ref_driver.cpp (BuiltinCornell) instead of a scene file
+    args = [sp] if isinstance(scene_text, str) else ["--builtin", scene_text[1], str(scene_text[2])] + (["--keyed-sampler"] if keyed else [])
+    r = subprocess.run([exe, "--out", fp] + args, env=env, capture_output=True, text=True, timeout=timeout, cwd=d)
     if r.returncode != 0:
         raise RuntimeError("reference run failed: %s\n%s" % (r.stdout[-2000:], r.stderr[-2000:]))
     lines = r.stdout.strip().splitlines()
@@ -53,6 +55,8 @@ def run_reference(scene_text: str, keyed: bool = True, workdir: str | None = Non
                 val = ln.split()[-1] if not ln.rstrip().endswith(")") else ln.split()[-2]
                 table[key] = val
     stats["stats"] = table
+    stats["stderr_lines"] = r.stderr.count("\n")
+    stats["radiance_warnings"] = sum(r.stderr.count(k) for k in ("Not-a-number radiance", "Negative luminance", "Infinite luminance"))
     rgb, alpha, _ = load_ref_film(fp)
     return rgb, alpha, stats
 

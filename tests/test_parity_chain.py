@@ -1,0 +1,97 @@
+"""The parity chain beyond the keyed-RNG fixtures (tests/golden/make_parity_chain.py).
+
+  t0_*   films of the RNG-UNTOUCHED reference (own MT19937, own samplers, no helper plugins) on scenes no random draw can reach:
+         the oracle and the device must reproduce them, so the link-time RNG override of pbrt_ref_keyed is out of the loop;
+  api_*  films of the reference driven by hand-written pbrt* API calls (no scene text, no tokenizer in the reference run);
+  t2     a converged Cornell image from the reference's native MT19937 stream, twice: the device's converged image must be as
+         close to it as the reference's second render is;
+  bad_*  Scene::Render's radiance sanity check (scene.cpp:60-74) actually firing;
+  sinc_* the sinc pixel filter on the device path."""
+import glob
+import json
+import os
+import numpy as np
+import pytest
+from conftest import film_metrics
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHAIN = os.path.join(ROOT, "tests", "golden", "chain")
+
+
+def chain_names(prefix):
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(CHAIN, prefix + "*.npz")))
+
+
+def load(name):
+    z = np.load(os.path.join(CHAIN, name + ".npz"))
+    d = {k: z[k] for k in z.files}
+    d["scene"] = str(d["scene"]); d["stats"] = json.loads(str(d["stats"]))
+    return d
+
+
+EXACT = chain_names("t0_") + chain_names("api_") + chain_names("bad_") + chain_names("sinc_")
+
+
+@pytest.mark.parametrize("name", EXACT)
+def test_oracle_reproduces_the_chain_fixture(pkg, oracle, name):
+    g = load(name)
+    ps = pkg.ParsedScene(text=g["scene"])
+    assert ps.valid and ps.errors == 0
+    nodes, refs, bounds, info = ps.kdtree()
+    rgb, alpha, _, cnt = oracle.render(ps, nodes, refs, bounds, info=info)
+    assert np.abs(rgb - g["rgb"]).max() <= 1e-6 and np.abs(alpha - g["alpha"]).max() <= 1e-6, (name, film_metrics(rgb, g["rgb"]))
+    if name.startswith("bad_"):
+        # one "bad sample" per Error line the reference printed (scene.cpp:61,66,71)
+        assert cnt["bad_samples"] == int(g["radiance_warnings"]) > 0
+    elif "closest_rays" in g["stats"] and g["stats"]["closest_rays"]:
+        assert cnt["closest_rays"] == g["stats"]["closest_rays"] and cnt["any_rays"] == g["stats"]["any_rays"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", EXACT)
+def test_device_reproduces_the_chain_fixture(pkg, name):
+    if pkg.device_count() < 1:
+        pytest.fail("no HIP device visible")
+    g = load(name)
+    ps = pkg.ParsedScene(text=g["scene"])
+    ds = pkg.DeviceScene(ps); ds.render()
+    rgb, alpha = ds.film(); cnt = ds.counters(); ds.close()
+    m = film_metrics(rgb, g["rgb"])
+    if ps.integrator == 2:                              # path: cosf / sinf of the device's libm (tests/test_gpu_parity.py)
+        assert m["frac"] >= 0.995 and m["mean_l2"] < 1e-4, (name, m)
+    else:
+        assert m["maxabs"] <= 1e-5 and np.abs(alpha - g["alpha"]).max() <= 1e-5, (name, m)
+    if name.startswith("bad_"):
+        want = int(g["radiance_warnings"])
+        assert abs(cnt["bad_samples"] - want) <= (0 if ps.integrator != 2 else max(4, want // 200)) and cnt["bad_samples"] > 0
+
+
+@pytest.mark.gpu
+def test_t2_converged_image_against_the_native_mt19937_reference(pkg):
+    """statistical parity with what a user running `pbrt` gets.  The device renders the fixture's frame
+    (64x64 @ 1024 spp, its own keyed stream).  Two independent unbiased renders of equal sample count differ by sqrt(2) sigma per
+    pixel on average: the device must be as close to the reference's first render as the reference's second render is (+25 %),
+    and carry the same energy (means within 0.5 %)."""
+    if pkg.device_count() < 1:
+        pytest.fail("no HIP device visible")
+    g = load("t2_cornell")
+    ps = pkg.ParsedScene(text=g["scene"])
+    assert ps.valid and ps.spp == 1024
+    ds = pkg.DeviceScene(ps); ds.render(); rgb, _ = ds.film(); cnt = ds.counters(); ds.close()
+    a, b = g["rgb"], g["rgb_second"]
+    between = float(np.sqrt(((a - b) ** 2).mean()))
+    mine = float(np.sqrt(((rgb - a) ** 2).mean()))
+    assert abs(between - float(g["rmse_between"])) < 1e-9
+    assert mine <= 1.25 * between, (mine, between)
+    assert abs(float(rgb.mean()) - float(a.mean())) <= 0.005 * float(a.mean()), (float(rgb.mean()), float(a.mean()), float(b.mean()))
+    # per-channel energy and a coarse spatial check: 8x8 block means within 3 %
+    blk = lambda im: im.reshape(8, 8, 8, 8, 3).mean((1, 3))
+    assert np.abs(blk(rgb) - blk(a)).max() <= 0.03 * blk(a).max(), float(np.abs(blk(rgb) - blk(a)).max())
+    assert cnt["bad_samples"] == 0
+
+
+def test_t2_fixture_is_self_consistent():
+    g = load("t2_cornell")
+    a, b = g["rgb"], g["rgb_second"]
+    assert a.shape == (64, 64, 3) and abs(float(a.mean()) - float(b.mean())) < 0.01 * float(a.mean())
+    assert 0.002 < float(g["rmse_between"]) < 0.05
