@@ -41,6 +41,10 @@ def workload(name: str):
         text = scenes.cornell_scene(xres=1024, yres=1024, integrator=integ, xsamples=8, ysamples=8, jitter=True, pixel_filter="mitchell")
         label = "Cornell box, %s, 1024x1024 @ 64 spp, mitchell, kd-tree" % integ
         crop = (0.4375, 0.5625, 0.4375, 0.5625)
+    elif name == "tsmall":              # tests/test_multirank_gpu.py
+        text = scenes.cornell_scene(xres=160, yres=120, integrator="path", maxdepth=5, xsamples=2, ysamples=2, jitter=True, pixel_filter="mitchell", soup_tris=3000)
+        label = "test frame: Cornell + 3000-triangle soup, path, 160x120 @ 4 spp"
+        crop = (0.4, 0.6, 0.4, 0.6)
     elif name == "c1":
         text = scenes.cornell_scene(xres=512, yres=512, integrator="whitted", xsamples=1, ysamples=1, jitter=False,
                                     pixel_filter="box")
@@ -104,51 +108,21 @@ def cpu_baseline(pkg, name: str, crop, budget_s: float = 25.0):
         return {"value": None, "unit": "Mrays/s", "cores": 1, "kind": "port", "sample": "oracle/_ref missing on this box"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    # 48: with the 1028-pixel sample rows of the default frame, 64-pixel tiles give 16.06 tiles per row, so one rank owns the
-    # same columns for ~16 consecutive rows and whole 16x16 film-gather blocks fall to a single rank (measured at 8 ranks:
-    # rank share 10.06 ms with 64, 9.61 ms with 48)
-    ap.add_argument("--tile-pixels", type=int, default=48)
-    args = ap.parse_args()
-
+def run_workload(name, args, pkg, torch, dist, world, rank, device_index, steps, warmup, with_cpu, dump_film=None):
+    """Render `steps` timed frames of one workload on this rank's shard; rank 0 returns the record (others None)."""
     import numpy as np
-    import torch
-    import __graft_entry__ as entry
-    pkg = entry.load_package()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-
-    text, label, crop = workload(args.workload)
+    text, label, crop = workload(name)
     ps = pkg.ParsedScene(text=text)
     if not ps.valid or ps.errors:
         raise SystemExit("bench.py: the workload's scene description did not parse cleanly (%d errors): refusing to time a different scene" % ps.errors)
     emu = int(os.environ.get("PBRT_BENCH_EMULATE_WORLD", "0"))      # debugging aid: time rank 0's share of an N-rank job on one GPU
     ps.set_shard(rank, emu if (emu > 1 and world == 1) else world, args.tile_pixels)
-    ds = pkg.DeviceScene(ps, device=local_rank)
+    ds = pkg.DeviceScene(ps, device=device_index)
     info = ds.accel_info()
     film = torch.zeros((5, ps.height, ps.width), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream()
     ds.set_stream(stream.cuda_stream)
     ds.bind_film(film.data_ptr())
-
     # the host side of the boundary: the resolved film lands in page-locked buffers that are reused every frame
     host_rgb = torch.empty((ps.height, ps.width, 3), dtype=torch.float32, pin_memory=True).numpy() if rank == 0 else None
     host_alpha = torch.empty((ps.height, ps.width), dtype=torch.float32, pin_memory=True).numpy() if rank == 0 else None
@@ -173,37 +147,45 @@ def main():
     step(); fence()
     cnt = ds.counters()
     ds.set_counting(False)
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     fence()
     stats = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
         stats.append(ds.last_stats())       # HIP events around the kernels on their stream
     fence()
     elapsed = time.perf_counter() - t0
     rays_local = cnt["closest_rays"] + cnt["any_rays"]
+    k_ms_local = float(np.mean([st["trace_ms"] for st in stats]))
+    render_ms_local = float(np.mean([st["render_ms"] for st in stats]))
     tot = torch.tensor([float(rays_local), float(cnt["camera_rays"])], dtype=torch.float64, device="cuda")
     tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    per_rank = torch.zeros(world * 3, dtype=torch.float64, device="cuda")
+    per_rank[3 * rank] = k_ms_local; per_rank[3 * rank + 1] = render_ms_local; per_rank[3 * rank + 2] = float(rays_local)
     if dist is not None:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
     rays_total, cam_total = float(tot[0].item()), float(tot[1].item())
     elapsed = float(tmax[0].item())
-
+    out = None
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        # the dominant kernel: rt::render_kernel (megakernel, small scenes) or the rt::pipe_trace_kernel launches of the queue pipeline
-        k_ms = float(np.mean([st["trace_ms"] for st in stats]))
+        if dump_film:
+            np.savez(dump_film, rgb=host_rgb, alpha=host_alpha)
+        ms_per_step = elapsed / steps * 1e3
+        # the dominant kernel: rt::render_kernel (megakernel) or the rt::pipe_trace_kernel launches of the queue pipeline
+        k_ms = k_ms_local
         pipeline = bool(stats[-1]["pipeline"])
         alg_bytes = 8 * cnt["nodes_visited"] + 4 * cnt["leaf_refs"] + 48 * cnt["tri_tests"] + 48 * rays_local
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        pr = per_rank.cpu().numpy().reshape(world, 3)
         out = {
             "metric": "Mrays/s (primary+secondary: every Scene::Intersect + Scene::IntersectP)",
-            "value": round(rays_total * args.steps / elapsed / 1e6, 3),
+            "value": round(rays_total * steps / elapsed / 1e6, 3),
             "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(ms_per_step, 3),
             "s_per_frame": round(ms_per_step / 1e3, 5),
             "higher_is_better": True,
@@ -221,17 +203,24 @@ def main():
                          "kernel": ("rt::pipe_trace_kernel<COUNT=false,...> (persistent trace waves of the queue pipeline; all %d launches of a frame summed)" % stats[-1]["iterations"])
                                    if pipeline else "rt::render_kernel<COUNT=false,...> (persistent megakernel)",
                          "kernel_ms": round(k_ms, 3),
-                         "frame_kernels_ms": {"render": round(float(np.mean([st["render_ms"] for st in stats])), 3),
+                         "frame_kernels_ms": {"render": round(render_ms_local, 3),
                                               "film_gather": round(float(np.mean([st["gather_ms"] for st in stats])), 3)},
                          "pipeline_iterations": int(stats[-1]["iterations"]), "pipeline_slots": int(stats[-1]["slots"]),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "bytes_per_ray": round(alg_bytes / max(rays_local, 1), 1),
                          "nodes_per_ray": round(cnt["nodes_visited"] / max(rays_local, 1), 2),
-                         "tri_tests_per_ray": round(cnt["tri_tests"] / max(rays_local, 1), 2)},
+                         "tri_tests_per_ray": round(cnt["tri_tests"] / max(rays_local, 1), 2),
+                         # the ceiling measured for this access pattern (tools/gather_bench.hip, profiles/r02_gather_bench.txt): the chip
+                         # sustains ~56 G dependent gathers/s that miss L2, whatever their width; one gather per node visit, leaf list and
+                         # triangle record is the worst case the layout allows
+                         "gather_ceiling": {"gathers_per_launch": int(cnt["nodes_visited"] + cnt["tri_tests"] + cnt["leaf_refs"] // 2),
+                                            "l2_miss_gathers_per_s_peak": 56e9,
+                                            "ms_if_every_gather_missed_l2": round((cnt["nodes_visited"] + cnt["tri_tests"] + cnt["leaf_refs"] // 2) / 56e9 * 1e3, 2)}},
+            "per_rank": [{"rank": r, "kernel_ms": round(float(pr[r, 0]), 3), "render_ms": round(float(pr[r, 1]), 3), "rays": int(pr[r, 2])} for r in range(world)],
         }
         # HBM traffic of the same kernel from the PMC passes of tools/profile_r.sh (separate rocprofv3 runs of this very
         # command; counters and corrections as MI355X_MICROARCH.md prescribes), committed under profiles/
-        prof = os.path.join(ROOT, "profiles", "latest_%s_render_kernel.json" % args.workload)
+        prof = os.path.join(ROOT, "profiles", "latest_%s_render_kernel.json" % name)
         if world == 1 and os.path.exists(prof):
             pj = json.load(open(prof))
             # profiles/r01_fetch_size_calibration.txt: on this library's gathers FETCH_SIZE tallies 64 B per fabric read request
@@ -239,25 +228,82 @@ def main():
             # conservative figure (reads doubled); the lower bound is reported beside it.
             out["roofline"]["traffic"] = int(pj["hbm_bytes_per_launch_fetch_doubled"])
             out["roofline"]["traffic_lower_bound"] = int(pj["hbm_bytes_per_launch_uncorrected"])
-            out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(os.path.realpath(prof)) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per launch)"
-            busy = "VALUBusy %.0f%%, %.0f%% of lanes active" % (pj["derived"]["VALUBusy_percent"], pj["derived"]["VALUUtilization_percent_active_lanes"])
+            out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(os.path.realpath(prof)) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per frame)"
+            d = pj.get("derived", {})
+            busy = "VALUBusy %.0f%%, %.0f%% of lanes active" % (d.get("VALUBusy_percent", 0), d.get("VALUUtilization_percent_active_lanes", 0))
             if out["roofline"]["traffic"] < 0.1 * alg_bytes:
                 out["roofline"]["note"] = ("this workload's tree and triangles are L1/L2 resident: measured HBM traffic is ~%.0f%% of the algorithmic "
                                            "bytes (mostly the 32-byte sample records written once), so the HBM roofline is not the binding limit "
                                            "here; VALU issue under divergence is (%s)" % (100.0 * out["roofline"]["traffic"] / alg_bytes, busy))
             else:
-                out["roofline"]["note"] = ("fabric traffic %.2f-%.2fx the algorithmic bytes: 64-byte sectors fetched for 8-byte nodes, plus the "
-                                           "register-spill scratch of the 128-VGPR high-occupancy flavour (WRITE_SIZE %.0f GB/launch vs 0.5 GB of "
-                                           "sample records); L2 hit rate %.0f%%; %s" % (out["roofline"]["traffic_lower_bound"] / alg_bytes,
-                                           out["roofline"]["traffic"] / alg_bytes, pj["WRITE_SIZE_KB"] * 1024 / 1e9, 100 * pj["derived"]["L2_hit_rate"], busy))
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pkg, args.workload, crop)
+                out["roofline"]["note"] = ("fabric traffic %.2f-%.2fx the algorithmic bytes (one 64-byte request per gather that misses L2; L2 hit rate %.0f%%); %s"
+                                           % (out["roofline"]["traffic_lower_bound"] / alg_bytes, out["roofline"]["traffic"] / alg_bytes, 100 * d.get("L2_hit_rate", 0), busy))
+        if world == 1 and with_cpu:
+            out["cpu_baseline"] = cpu_baseline(pkg, name, crop)
             if out["cpu_baseline"].get("value"):
                 out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
     ds.close()
+    del film
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    # the other BASELINE.json configs at the size one GPU holds, reported as full sub-records in "workloads" (N = 1 only)
+    ap.add_argument("--extra-workloads", default="p1000000,c3,c4,c5")
+    ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--dump-film", default=None, help="rank 0 writes the last resolved film of the headline workload here (.npz)")
+    # 48: with the 1028-pixel sample rows of the default frame, 64-pixel tiles give 16.06 tiles per row, so one rank owns the
+    # same columns for ~16 consecutive rows and whole 16x16 film-gather blocks fall to a single rank (measured at 8 ranks:
+    # rank share 10.06 ms with 64, 9.61 ms with 48)
+    ap.add_argument("--tile-pixels", type=int, default=48)
+    args = ap.parse_args()
+
+    import torch
+    import __graft_entry__ as entry
+    pkg = entry.load_package()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    # tests/test_multirank_gpu.py runs two ranks on ONE GPU over gloo (films staged through the host by the backend) so that the
+    # N > 1 branch of this file executes before an 8-GPU node is available; the driver's runs use one GPU per rank over RCCL
+    backend = os.environ.get("PBRT_BENCH_BACKEND", "nccl")
+    device_index = 0 if os.environ.get("PBRT_BENCH_SAME_GPU") else local_rank
+    torch.cuda.set_device(device_index)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+
+    out = run_workload(args.workload, args, pkg, torch, dist, world, rank, device_index, args.steps, args.warmup,
+                       with_cpu=not args.no_cpu_baseline, dump_film=args.dump_film)
+    extras = [] if (world > 1 or args.no_extra or args.workload != "c2") else [w for w in args.extra_workloads.split(",") if w]
+    records = []
+    for w in extras:
+        rec = run_workload(w, args, pkg, torch, dist, world, rank, device_index, min(args.steps, 3), 1, with_cpu=not args.no_cpu_baseline)
+        if rec is not None:
+            records.append({k: rec[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "roofline", "cpu_baseline") if k in rec} |
+                           ({"speedup_vs_cpu_baseline": rec["speedup_vs_cpu_baseline"]} if "speedup_vs_cpu_baseline" in rec else {}) | {"workload": w})
+    if rank == 0:
+        if records:
+            out["workloads"] = records
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -61,7 +61,16 @@ def build(force: bool = False, verbose: bool = False, defines=(), jobs: int | No
         def run(cmd):
             if verbose:
                 print(" ".join(cmd))
-            subprocess.check_call(cmd)
+            if not cmd[-3].endswith(".hip"):
+                subprocess.check_call(cmd)
+                return
+            # keep the compiler's per-kernel resource report (VGPRs, spills, occupancy) next to the object: tests/test_abi.py checks
+            # that the timed kernels stay inside their occupancy step (gfx950: <= 168 VGPRs for 3 waves per SIMD, <= 64 for 8)
+            r = subprocess.run(cmd + ["-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+            keep = [ln for ln in r.stderr.splitlines() if "remark:" in ln and any(k in ln for k in ("Function Name", " VGPRs:", "VGPRs Spill", "Occupancy", "ScratchSize", "LDS Size"))]
+            open(cmd[-1][:-2] + ".resources.txt", "w").write("\n".join(keep) + "\n")
+            if r.returncode != 0:
+                raise RuntimeError("hipcc failed:\n" + r.stderr[-4000:])
         with ThreadPoolExecutor(max_workers=jobs or min(len(todo), os.cpu_count() or 4)) as ex:
             list(ex.map(run, todo))
         open(stamp, "w").write(dtext)

@@ -269,6 +269,7 @@ RT_DEV void setup_sample(const DevScene &sc, const DevFrame &fr, Lane &ln, unsig
 RT_DEV float RT_G *frame_ptr(const DevFrame &fr, int frame, unsigned gtid) {
     return RT_GPTR(float, fr.frames) + (size_t(frame) * RT_FRAME_WORDS) * fr.n_threads + gtid;
 }
+template <bool EXT>
 RT_DEV void frame_push(const DevFrame &fr, Lane &ln, unsigned gtid, V3 f, float absdot, int after) {
     float RT_G *q = frame_ptr(fr, ln.fsp, gtid); const size_t st = fr.n_threads;
     q[0 * st] = ln.L.x; q[1 * st] = ln.L.y; q[2 * st] = ln.L.z;
@@ -279,9 +280,10 @@ RT_DEV void frame_push(const DevFrame &fr, Lane &ln, unsigned gtid, V3 f, float 
     q[15 * st] = ln.v.sn.x; q[16 * st] = ln.v.sn.y; q[17 * st] = ln.v.sn.z;
     q[18 * st] = ln.v.wo.x; q[19 * st] = ln.v.wo.y; q[20 * st] = ln.v.wo.z;
     q[21 * st] = __int_as_float(ln.v.mat);
-    q[22 * st] = ln.v.ng.x; q[23 * st] = ln.v.ng.y; q[24 * st] = ln.v.ng.z;
+    if (EXT) { q[22 * st] = ln.v.ng.x; q[23 * st] = ln.v.ng.y; q[24 * st] = ln.v.ng.z; }
     ++ln.fsp;
 }
+template <bool EXT>
 RT_DEV int frame_pop(const DevFrame &fr, Lane &ln, unsigned gtid, V3 child) {
     --ln.fsp;
     const float RT_G *q = frame_ptr(fr, ln.fsp, gtid); const size_t st = fr.n_threads;
@@ -297,7 +299,7 @@ RT_DEV int frame_pop(const DevFrame &fr, Lane &ln, unsigned gtid, V3 child) {
     ln.v.tn = cross3(ln.v.nn, ln.v.sn);
     ln.v.wo = mk3(q[18 * st], q[19 * st], q[20 * st]);
     ln.v.mat = __float_as_int(q[21 * st]);
-    ln.v.ng = mk3(q[22 * st], q[23 * st], q[24 * st]);
+    if (EXT) ln.v.ng = mk3(q[22 * st], q[23 * st], q[24 * st]);
     return after;
 }
 
@@ -440,7 +442,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
             if (ln.depth == 0) { ln.alpha = 1.f; if (VOL) vol_ray_ptr(fr, 0, gtid)[7 * size_t(fr.n_threads)] = ln.tv.maxt; }   // r.maxt = ray.maxt
             else if (VOL) ln.thr = ln.thr * scene_transmittance<VOL>(sc, ln, ln.tv.o, ln.tv.d, ln.tv.mint, ln.tv.maxt);           // path.cpp:89
             if ((ln.depth == 0 || ln.specular) && ln.v.light >= 0)              // path.cpp:91-92
-                ln.L = ln.L + ln.thr * area_L(RT_LIGHT(sc, ln.v.light), ln.v.ng, ln.v.wo);   // isect.Le: dg.nn, the geometric normal
+                ln.L = ln.L + ln.thr * area_L(RT_LIGHT(sc, ln.v.light), vertex_ng<EXT>(ln.v), ln.v.wo);   // isect.Le: dg.nn, the geometric normal
         } else {
             if (!hit) {                                                         // whitted.cpp:52-59
                 ln.L = mk3(0.f);
@@ -451,7 +453,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
             if (ln.depth == 0) ln.alpha = 1.f;
             if (VOL) vol_ray_ptr(fr, ln.fsp, gtid)[7 * size_t(fr.n_threads)] = ln.tv.maxt;       // the hit shortens this level's ray
             ln.L = mk3(0.f);
-            if (ln.v.light >= 0) ln.L = ln.L + area_L(RT_LIGHT(sc, ln.v.light), ln.v.ng, ln.v.wo);
+            if (ln.v.light >= 0) ln.L = ln.L + area_L(RT_LIGHT(sc, ln.v.light), vertex_ng<EXT>(ln.v), ln.v.wo);
         }
         ln.li = 0; ln.lj = 0; ln.L_all = mk3(0.f); ln.Ld_light = mk3(0.f);
         ln.stage = ST_DIRECT_NEXT;
@@ -598,7 +600,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
         if (!is_black(f) && pdf > 0.f) f = div_s(f, pdf);                       // reflection.cpp:399
         const float ad = absdot3(wi, ln.v.nn);
         if (!is_black(f) && ad > 0.f) {
-            frame_push(fr, ln, gtid, f, ad, ST_SPEC_TRANS);
+            frame_push<EXT>(fr, ln, gtid, f, ad, ST_SPEC_TRANS);
             ++ln.depth;
             launch_ray<DEFER>(ln, sc, ln.v.p, wi, RT_RAY_EPSILON, RT_INF, false, ST_VERTEX);
             if (VOL) { Ray cr; cr.o = ln.v.p; cr.d = wi; cr.mint = RT_RAY_EPSILON; cr.maxt = RT_INF; vol_store_ray(fr, ln.fsp, gtid, cr); }
@@ -615,7 +617,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
         if (!is_black(f) && pdf > 0.f) f = div_s(f, pdf);
         const float ad = absdot3(wi, ln.v.nn);
         if (!is_black(f) && ad > 0.f) {
-            frame_push(fr, ln, gtid, f, ad, ST_RETURN);
+            frame_push<EXT>(fr, ln, gtid, f, ad, ST_RETURN);
             ++ln.depth;
             launch_ray<DEFER>(ln, sc, ln.v.p, wi, RT_RAY_EPSILON, RT_INF, false, ST_VERTEX);
             if (VOL) { Ray cr; cr.o = ln.v.p; cr.d = wi; cr.mint = RT_RAY_EPSILON; cr.maxt = RT_INF; vol_store_ray(fr, ln.fsp, gtid, cr); }
@@ -713,7 +715,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
     }
     if constexpr (STAGE == ST_POP) {
         if (ln.fsp == 0) { ln.stage = ST_FINISH; return; }
-        ln.stage = frame_pop(fr, ln, gtid, ln.L);
+        ln.stage = frame_pop<EXT>(fr, ln, gtid, ln.L);
         return;
     }
     if constexpr (STAGE == ST_FINISH) {

@@ -85,7 +85,6 @@ RT_DEV void pipe_load(const PipePool &pl, const DevFrame &fr, unsigned slot, Lan
         const float4 a10 = st[10 * n];
         ln.Ld_light = mk3(a9.z, a9.w, a10.x); ln.L_all = mk3(a10.y, a10.z, a10.w);
     }
-    ln.v.ng = ln.v.nn;
     if (EXT) { const float4 a11 = st[11 * n]; ln.v.ng = mk3(a11.x, a11.y, a11.z); }
 }
 template <int INTEG, bool EXT>

@@ -12,7 +12,8 @@ enum { BX_REFLECTION = 1, BX_TRANSMISSION = 2, BX_DIFFUSE = 4, BX_GLOSSY = 8, BX
 
 struct Vertex {
     V3 p, nn, sn, tn;   // hit point, shading normal, BSDF frame (BSDF ctor reflection.cpp:471-479)
-    V3 ng;              // geometric normal: equals nn unless the mesh has per-vertex N / S (EXT kernels); the compiler folds the copy
+    V3 ng;              // geometric normal, carried by the EXT kernels only (per-vertex N / S make it differ from nn): every read goes
+                        // through vertex_ng<EXT>(), so the other kernels never keep it alive (3 VGPRs decide 3 vs 2 waves per SIMD on C2)
     V3 wo;
     int mat, light;     // material index, area-light index of the primitive or -1
 };
@@ -144,6 +145,7 @@ RT_DEV void shading_frame(const DevScene &sc, const DevTriShading RT_G &r, float
     if (dot3(ngeom, bnn) < 0.f) bnn = bnn * -1.f;
     nn_out = bnn; sn_dir = bdpdu;
 }
+template <bool EXT> RT_DEV V3 vertex_ng(const Vertex &v) { return EXT ? v.ng : v.nn; }
 template <bool EXT>
 RT_DEV void make_vertex(const DevScene &sc, const Trav &tv, Vertex &v) {
     const float4 RT_G *q = RT_GPTR(const float4, sc.tri_shade) + size_t(2) * unsigned(tv.hit_prim);
@@ -157,7 +159,7 @@ RT_DEV void make_vertex(const DevScene &sc, const Trav &tv, Vertex &v) {
         v.nn = mk3(a.x, a.y, a.z);                       // tri_frame(), precomputed per triangle on the host
         v.sn = mk3(b.x, b.y, b.z);
     }
-    v.ng = v.nn;
+    if (EXT) v.ng = v.nn;
     if (EXT && (bits & RT_PRIM_SHADING)) {               // per-vertex N / S: the shading frame depends on where the triangle was hit
         const DevTriShading RT_G &r = RT_GPTR(const DevTriShading, sc.tri_shading)[RT_GPTR(const int, sc.tri_shading_idx)[unsigned(tv.hit_prim)]];
         V3 sdir;
@@ -318,7 +320,7 @@ template <bool EXT>
 RT_DEV V3 bsdf_f(MatRef m, const Vertex &v, V3 woW, V3 wiW) {
     if (!mat_has_diffuse<EXT>(m) && !mat_has_glossy<EXT>(m)) return mk3(0.f);
     V3 wi = to_local(v, wiW), wo = to_local(v, woW);
-    if (dot3(wiW, v.ng) * dot3(woW, v.ng) > 0) return bsdf_f_lobes<EXT>(m, wo, wi, BX_ALL & ~BX_TRANSMISSION);   // BRDFs only
+    if (dot3(wiW, vertex_ng<EXT>(v)) * dot3(woW, vertex_ng<EXT>(v)) > 0) return bsdf_f_lobes<EXT>(m, wo, wi, BX_ALL & ~BX_TRANSMISSION);   // BRDFs only
     return mk3(0.f);                                                                                         // BTDFs only: none
 }
 
@@ -384,7 +386,7 @@ RT_DEV V3 bsdf_sample_f(MatRef m, const Vertex &v, V3 woW, V3 &wiW, float u1, fl
         wiW = to_world(v, wi);
         if (matching > 1) pdf /= matching;
         f = mk3(0.f);
-        if (dot3(wiW, v.ng) * dot3(woW, v.ng) > 0) f = bsdf_f_lobes<EXT>(m, wo, wi, flags & ~BX_TRANSMISSION);
+        if (dot3(wiW, vertex_ng<EXT>(v)) * dot3(woW, vertex_ng<EXT>(v)) > 0) f = bsdf_f_lobes<EXT>(m, wo, wi, flags & ~BX_TRANSMISSION);
         return f;
     }
     // specular lobes, in the order the material added them (glass.cpp:56-61, mirror.cpp:51-53)
