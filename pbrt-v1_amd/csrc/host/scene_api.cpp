@@ -794,6 +794,12 @@ int pbrt_host_read_exr_info(const char *path, int *out6) {
     ExrImage img; if (!ReadRGBAImage(path, img)) return -1;
     out6[0] = img.xRes; out6[1] = img.yRes; out6[2] = img.totalXRes; out6[3] = img.totalYRes; out6[4] = img.xOffset; out6[5] = img.yOffset; return 0;
 }
+// tools/exrassemble.cpp: merge crop-window renders (one EXR per tile / process) into the full image; `paths` is newline-separated
+float pbrt_host_assemble_exr(const char *paths, const char *out) {
+    std::vector<std::string> in; std::string cur;
+    for (const char *c = paths; ; ++c) { if (*c == '\n' || *c == 0) { if (!cur.empty()) in.push_back(cur); cur.clear(); if (!*c) break; } else cur.push_back(*c); }
+    return AssembleRGBAImages(in, out);
+}
 int pbrt_host_read_exr(const char *path, float *rgb, float *alpha) {
     ExrImage img; if (!ReadRGBAImage(path, img)) return -1;
     std::memcpy(rgb, img.rgb.data(), img.rgb.size() * sizeof(float)); std::memcpy(alpha, img.alpha.data(), img.alpha.size() * sizeof(float)); return 0;

@@ -213,3 +213,31 @@ def test_smooth_meshes_against_the_oracle(pkg, scenes, oracle, integrator, extra
     if integrator != "path":
         for k in COUNTERS:
             assert cnt[k] == ocnt[k], (k, cnt[k], ocnt[k])
+
+
+def test_crop_window_tiles_to_exr_and_assembled(pkg, scenes, tmp_path):
+    """The reference's own multi-process mode: one `cropwindow` render per tile (film/image.cpp:220-228), each
+    written as an EXR whose data window sits inside the full display window (exrio.cpp:75-96), merged by exrassemble
+    (tools/exrassemble.cpp:42-75).  Device films -> rt_film_resolve -> write_exr -> assemble_exr must equal the EXR of the full
+    frame (a scene no random draw reaches, so tiles and full frame take identical samples)."""
+    need_gpu(pkg)
+    kw = dict(xres=96, yres=64, integrator="whitted", xsamples=2, ysamples=2, jitter=False, pixel_filter="mitchell", soup_tris=2000,
+              world_kwargs=dict(point_light=True, area_light=False))
+    rgb, alpha, _, _ = pkg.render_text(scenes.cornell_scene(**kw))
+    full = str(tmp_path / "full.exr"); pkg.write_exr(full, rgb, alpha)
+    paths = []
+    for k, crop in enumerate([(0, .5, 0, .5), (.5, 1, 0, .5), (0, .25, .5, 1), (.25, 1, .5, 1)]):
+        ps = pkg.ParsedScene(text=scenes.cornell_scene(crop=crop, **kw))
+        ds = pkg.DeviceScene(ps); ds.render(); r, a = ds.film(); ds.close()
+        x0, y0 = int(np.ceil(96 * crop[0])), int(np.ceil(64 * crop[2]))
+        assert r.shape[:2] == (ps.height, ps.width)
+        p = str(tmp_path / ("tile%d.exr" % k)); paths.append(p)
+        pkg.write_exr(p, r, a, total_res=(96, 64), offset=(x0, y0))
+    out = str(tmp_path / "assembled.exr")
+    assert pkg.assemble_exr(paths, out) == 1.0
+    a_rgb, a_alpha, meta = pkg.read_exr(out)
+    f_rgb, f_alpha, _ = pkg.read_exr(full)
+    assert meta == dict(total_res=(96, 64), offset=(0, 0))
+    assert np.array_equal(a_rgb, f_rgb) and np.array_equal(a_alpha, f_alpha)
+    with np.errstate(over="ignore"):
+        assert np.array_equal(f_rgb, rgb.astype(np.float16).astype(np.float32))

@@ -176,3 +176,37 @@ def test_exr_writer_round_trip_and_half_rounding(pkg, tmp_path):
         assert np.array_equal(a, alpha.astype(np.float16).astype(np.float32))
     raw = open(p, "rb").read()
     assert raw[:8] == bytes([0x76, 0x2f, 0x31, 0x01, 2, 0, 0, 0]) and b"dataWindow\x00box2i" in raw and b"displayWindow" in raw
+
+
+def test_exr_reader_refuses_truncated_and_foreign_files(pkg, tmp_path):
+    """every size / offset in the file is checked; nothing is read out of bounds, foreign files are refused."""
+    rgb = np.random.default_rng(2).uniform(0, 1, (9, 13, 3)).astype(np.float32); alpha = np.ones((9, 13), np.float32)
+    p = str(tmp_path / "a.exr"); pkg.write_exr(p, rgb, alpha, total_res=(20, 20), offset=(3, 4))
+    raw = open(p, "rb").read()
+    bad = {"trunc_header": raw[:40], "trunc_table": raw[:raw.index(b"screenWindowWidth") + 30], "trunc_rows": raw[:-50],
+           "piz": raw.replace(b"compression\0compression\0\x01\0\0\0\0", b"compression\0compression\0\x01\0\0\0\x04"),
+           "huge_window": raw.replace(np.array([3, 4, 15, 12], np.int32).tobytes(), np.array([3, 4, 2000000000, 12], np.int32).tobytes()),
+           "tiled_flag": raw[:5] + b"\x02" + raw[6:], "empty": b""}
+    off_table = raw.index(b"screenWindowWidth\0float\0") + len(b"screenWindowWidth\0float\0") + 4 + 4 + 1
+    bad["wild_offset"] = raw[:off_table] + np.array([1 << 40], np.uint64).tobytes() + raw[off_table + 8:]
+    for name, data in bad.items():
+        q = str(tmp_path / (name + ".exr")); open(q, "wb").write(data)
+        with pytest.raises(IOError):
+            pkg.read_exr(q)
+    assert pkg.read_exr(p)[2] == dict(total_res=(20, 20), offset=(3, 4))
+
+
+def test_exr_assemble_merges_crop_windows(pkg, tmp_path):
+    """tools/exrassemble.cpp:42-75: crop-window images (data window inside a common display window) -> one full image."""
+    rng = np.random.default_rng(3)
+    full = rng.uniform(0, 4, (30, 40, 3)).astype(np.float32); fa = rng.uniform(0, 1, (30, 40)).astype(np.float32)
+    paths = []
+    for k, (x0, x1, y0, y1) in enumerate([(0, 20, 0, 15), (20, 40, 0, 15), (0, 40, 15, 30)]):
+        p = str(tmp_path / ("tile%d.exr" % k)); paths.append(p)
+        pkg.write_exr(p, full[y0:y1, x0:x1], fa[y0:y1, x0:x1], total_res=(40, 30), offset=(x0, y0))
+    out = str(tmp_path / "full.exr")
+    assert pkg.assemble_exr(paths, out) == 1.0
+    rgb, a, meta = pkg.read_exr(out)
+    assert meta == dict(total_res=(40, 30), offset=(0, 0))
+    assert np.array_equal(rgb, full.astype(np.float16).astype(np.float32)) and np.array_equal(a, fa.astype(np.float16).astype(np.float32))
+    assert abs(pkg.assemble_exr(paths[:2], out) - 0.5) < 1e-6 and np.all(pkg.read_exr(out)[0][15:] == 0)

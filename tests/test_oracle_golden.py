@@ -149,3 +149,31 @@ def test_one_ulp_libm_sensitivity_probe(pkg, oracle):
         out[name] = film_metrics(b, a)
         assert film_metrics(a, g["rgb"])["maxabs"] <= 1e-6          # unperturbed: still the reference's film
     assert out["path_box_4spp"]["frac"] >= 0.995 and out["sphere_path_soup"]["frac"] < 0.99, out
+
+
+def test_parallel_kd_build_equals_serial_and_the_reference_at_60k(pkg, scenes):
+    """The task-pool build (kd_build.cpp, >= 20 000 primitives) must produce the serial build's arrays exactly, and the reference's
+    tree: node / leaf / reference counts of KdTreeAccel's own StatsPrint on the same 60 012-primitive scene
+    (tests/golden/chain/kd_soup60k.npz, generated by the unmodified reference)."""
+    import ctypes as C, json, os
+    from conftest import ROOT
+    ps = pkg.ParsedScene(text=scenes.cornell_scene(xres=4, yres=4, integrator="whitted", soup_tris=60000, world_kwargs=dict(point_light=True, area_light=False)))
+    tv = np.ascontiguousarray(ps.tri_verts(), np.float32).reshape(-1, 9)
+    class P(C.Structure):
+        _fields_ = [("kind", C.c_int32), ("isect_cost", C.c_int32), ("trav_cost", C.c_int32), ("max_prims", C.c_int32), ("max_depth", C.c_int32),
+                    ("empty_bonus", C.c_float), ("build_threads", C.c_int32)]
+    out = {}
+    for threads in (1, 8):
+        p = P(0, 80, 1, 1, -1, 0.5, threads)
+        out[threads] = pkg.build_kdtree(tv, C.addressof(p))
+    (n1, r1, b1, i1), (n8, r8, b8, i8) = out[1], out[8]
+    assert np.array_equal(n1, n8) and np.array_equal(r1, r8) and np.array_equal(b1, b8) and i1.max_depth == i8.max_depth
+    table = json.loads(str(np.load(os.path.join(ROOT, "tests", "golden", "chain", "kd_soup60k.npz"))["stats"]))
+    leaf = (n8[:, 0] & 3) == 3
+    for key, mine in (("Interior kd-tree nodes made", int((~leaf).sum())), ("Leaf kd-tree nodes made", int(leaf.sum()))):
+        ref, exact = stat_int(table[key])
+        assert (mine == ref) if exact else abs(mine - ref) <= 0.0006 * ref + 50, (key, mine, table[key])
+    nprims = n8[leaf, 0] >> 2
+    ref_refs, ref_leaves = (stat_int(x)[0] for x in table["Avg. number of primitives in leaf nodes"].split(":"))
+    assert abs(int(nprims.sum()) - ref_refs) <= 0.0006 * ref_refs + 50 and abs(int(leaf.sum()) - ref_leaves) <= 0.0006 * ref_leaves + 50
+    assert int(nprims.max()) == int(table["Maximum number of primitives in leaf node"])
