@@ -75,6 +75,25 @@ def main():
         rebuild("rt_mega_p", [])
         for et in (16, 24, 40, 48):
             bench("mega_exit%d" % et, env={"PBRT_HIP_PIPELINE": "0", "PBRT_HIP_EXIT_THRESH": str(et)}, workload="p1000000")
+    elif g == "occ2":
+        for wl in ("p1000000", "c3", "c4"):
+            bench("mega_highocc1_" + wl, env={"PBRT_HIP_PIPELINE": "0", "PBRT_HIP_HIGH_OCC": "1"}, workload=wl)
+            bench("mega_highocc0_" + wl, env={"PBRT_HIP_PIPELINE": "0", "PBRT_HIP_HIGH_OCC": "0"}, workload=wl)
+    elif g == "prof":
+        rebuild("rt_mega_p", ["-DRT_PROFILE"]); rebuild("rt_kernels", ["-DRT_PROFILE"])
+        for wl in ("p1000000", "c2"):
+            e = dict(os.environ); e["PBRT_HIP_PIPELINE"] = "0"
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-extra", "--steps", "1", "--warmup", "0", "--workload", wl], env=e, capture_output=True, text=True, timeout=400)
+            print(wl, "\n".join([l for l in r.stderr.splitlines() if l.startswith("RT_PROFILE")][-2:]), flush=True)
+        rebuild("rt_mega_p", []); rebuild("rt_kernels", [])
+    elif g == "stack":
+        for ns in (16, 8):
+            for u in ("rt_mega_p", "rt_mega_d"):
+                rebuild(u, ["-DRT_STACK_LDS=%d" % ns])
+            for wl in ("p1000000", "c3", "c2"):
+                bench("mega_stack%d_%s" % (ns, wl), env={"PBRT_HIP_PIPELINE": "0"}, workload=wl)
+        for u in ("rt_mega_p", "rt_mega_d"):
+            rebuild(u, [])
     elif g == "defs":
         defs = sys.argv[2].split(",") if len(sys.argv) > 2 and sys.argv[2] else []
         rebuild("rt_trace", defs)
