@@ -12,10 +12,18 @@ Scene data is resident in HBM before the timed region; the frame is fixed, so N 
 
 Prints ONE JSON line on rank 0 (see the contract in the task description) including
   roofline     : algorithmic bytes (8 B/node visit + 4 B/leaf ref + 48 B/triangle test + 48 B/ray,
-                 SURVEY.md section 8d) of one launch / its HIP-event duration, against 8 TB/s HBM
+                 SURVEY.md section 8d) of one frame / the HIP-event duration of the dominant kernel
+                 (rt::render_kernel, or the rt::pipe_trace_kernel launches of a frame summed), against
+                 8 TB/s HBM; `gather_ceiling` = the same work priced in L2-missing line requests at the
+                 56 G/s this chip sustains; `traffic` from the committed rocprofv3
+                 PMC summary of the same command (profiles/)
   cpu_baseline : the *reference itself* (oracle/_ref/pbrt_ref, built from /root/reference with its own
                  flags, single thread, its own MT19937 stream) timed on this box's host cores on a
-                 centre crop window of the same frame.
+                 centre crop window of the same frame
+  per_rank     : kernel / render ms and rays of every rank (load balance)
+  workloads    : (N = 1, default run) full sub-records -- value, ms_per_step, roofline, cpu_baseline --
+                 for the other BASELINE configs at the size one GPU holds: the 1 M-triangle path frame
+                 (the north star's case), C3, C4, C5.
 """
 from __future__ import annotations
 
