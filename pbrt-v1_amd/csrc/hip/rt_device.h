@@ -67,6 +67,12 @@ struct DevScene {
     const uint2 *nodes;
     const uint2 *tnodes;       // trace kernel (rt_pipeline.h): the same nodes, but a leaf's word 1 is the position (in float4 units) of its
                                // primitives in `ltris`
+    const uint4 *tpairs;       // the same tree as sibling PAIRS for the flat traversal round: {below.x, below.y, above.x, above.y}; an interior
+                               // node's word 1 is the index of its children's pair, a leaf's word 1 its position in `ltris`.  Both children
+                               // arrive with ONE 16-byte gather, and because the traversal carries node CONTENTS (in registers and in the
+                               // stack entries) instead of indices, a leaf and a popped subtree root need no fetch of their own: gathers per
+                               // ray = interior nodes visited, not nodes visited (-44 % at 1 M triangles).  Pairs are stored depth-first.
+    unsigned root_x, root_y;   // contents of the root in that encoding
     const float4 *ltris;       // triangle records in LEAF order: the n primitives of a leaf are n consecutive 48-byte records (p1, e1, e2 as
                                // in DevTri, the primitive's index in q2.w), placed so that a leaf touches the fewest 128-byte lines: one
                                // gather fetches what the mesh-order layout needs a leaf-list read plus 1.25 lines per triangle for

@@ -348,6 +348,29 @@ static void host_tri_frame_uv(const float *v, const float *uv, bool flip, float 
     for (int a = 0; a < 3; ++a) { nn[a] = c[a] * inv; if (flip) nn[a] = -1.f * nn[a]; }
 }
 
+// The tree as sibling pairs (rt_device.h DevScene::tpairs), depth-first: the pair of a node's children is followed by the pairs of the
+// below child's subtree, then by those of the above child's.  `tn` = nodes with leaf payloads already pointing into `ltris`.
+static void build_pairs(const std::vector<Node> &tn, std::vector<uint4> &pairs, uint32_t &root_x, uint32_t &root_y) {
+    pairs.clear();
+    if (tn.empty()) { root_x = 3u; root_y = 0u; pairs.push_back(make_uint4(3u, 0u, 3u, 0u)); return; }
+    pairs.reserve(tn.size() / 2 + 1);
+    struct Rec {
+        const std::vector<Node> &tn; std::vector<uint4> &pairs;
+        uint32_t children(uint32_t parent) {                  // emits the pair of `parent`'s children and everything below; returns its index
+            const uint32_t b = parent + 1u, a = tn[parent].y;
+            const uint32_t p = uint32_t(pairs.size());
+            pairs.push_back(make_uint4(0u, 0u, 0u, 0u));
+            const uint32_t by = (tn[b].x & 3u) != 3u ? children(b) : tn[b].y;
+            const uint32_t ay = (tn[a].x & 3u) != 3u ? children(a) : tn[a].y;
+            pairs[p] = make_uint4(tn[b].x, by, tn[a].x, ay);
+            return p;
+        }
+    } rec{tn, pairs};
+    root_x = tn[0].x;
+    root_y = (tn[0].x & 3u) != 3u ? rec.children(0u) : tn[0].y;
+    if (pairs.empty()) pairs.push_back(make_uint4(3u, 0u, 3u, 0u));
+}
+
 template <class T>
 static int upload(RtScene *s, const T *host, size_t n, const T **dev) {
     void *p = nullptr;
@@ -608,6 +631,10 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
         s->dev.tnodes = reinterpret_cast<const uint2 *>(tdev);
         if ((rc = upload(s, lt.data(), lt.size(), &s->dev.ltris))) return rc;
         s->n_leaf_tri_units = lt.size();
+        tn.pop_back();
+        std::vector<uint4> pairs;
+        build_pairs(tn, pairs, s->dev.root_x, s->dev.root_y);
+        if ((rc = upload(s, pairs.data(), pairs.size(), &s->dev.tpairs))) return rc;
     }
     if ((rc = upload(s, s->tree.leaf_refs.data(), s->tree.leaf_refs.size(), &s->dev.leaf_refs))) return rc;
 
@@ -711,7 +738,7 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
         s->trace_grids[k] = unsigned(prop.multiProcessorCount) * unsigned(per_cu < 1 ? 1 : per_cu);
         if (s->trace_grids[k] * RT_BLOCK > s->n_threads) s->n_threads = s->trace_grids[k] * RT_BLOCK;      // the spill area is shared
     }
-    HIPCHK(hipMalloc((void **)&s->spill, size_t(s->spill_depth) * s->n_threads * sizeof(uint2)));
+    HIPCHK(hipMalloc((void **)&s->spill, size_t(s->spill_depth) * s->n_threads * sizeof(uint4)));     // uint4 entries in the pair form, uint2 otherwise
     HIPCHK(hipMalloc((void **)&s->dev_pool, sizeof(PipePool)));
     HIPCHK(hipMalloc((void **)&s->trace_qc, RT_QC_STRIDE * sizeof(unsigned)));
     HIPCHK(hipHostMalloc((void **)&s->h_qcount, size_t(RT_PIPE_QN) * RT_QC_STRIDE * sizeof(unsigned), hipHostMallocDefault));

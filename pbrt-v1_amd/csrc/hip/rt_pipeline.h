@@ -225,6 +225,7 @@ struct TraceJob {
 template <bool COUNT, int ACCEL, bool EXT>
 __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) void pipe_trace_kernel(const DevScene *__restrict__ scp, TraceJob job) {
     __shared__ uint2 lds_stack[RT_TRACE_STACK * RT_BLOCK];
+    __shared__ float lds_tm[(ACCEL != RT_ACCEL_GRID && !EXT) ? RT_TRACE_STACK * RT_BLOCK : 1];       // second plane of the pair-form stack
     const DevScene &sc = *scp;
     const unsigned gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) void pipe_trace_kernel(co
         const int leave_at = exhausted ? 0 : (live0 > RT_TRACE_REFILL ? live0 - RT_TRACE_REFILL : 0);
 #pragma unroll 1
         do {
-            trace_round<COUNT, ACCEL, EXT, RT_TRACE_STACK>(tv, busy, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, job.spill), job.n_threads, gtid, tc);
+            trace_round<COUNT, ACCEL, EXT, RT_TRACE_STACK>(tv, busy, sc, (uint2 RT_L *)lds_stack, (float RT_L *)lds_tm, RT_GPTR(uint2, job.spill), job.n_threads, gtid, tc);
         } while (__popcll(__ballot(busy && tv.active)) > leave_at);
     }
     if (COUNT) {

@@ -38,6 +38,10 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
     __shared__ float4 pool_res[PN];
     __shared__ unsigned pool_head[PN];
     __shared__ float4 pool_ray[3 * PN];
+    // second plane of the pair-form stack (trace_round).  Only the register-capped flavour (MINW >= RT_HIGH_OCC_WAVES: the one large trees
+    // use) runs the pair form; the natural-allocation kernels keep the index form (C2's kernel sits 2 VGPRs below the 3-wave step)
+    __shared__ float lds_tm_own[POOL ? 1 : RT_STACK_LDS * RT_BLOCK];
+    float RT_L *lds_tm = (float RT_L *)lds_tm_own;
     const DevScene &sc = *scp;
     const DevFrame &fr = *frp;
     const unsigned wave0 = POOL ? (threadIdx.x & ~63u) : 0u;
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
             RT_PF(++pf_rounds; pf_act += __popcll(am);)
             if (fr.exit_thresh > 0 && __popcll(am) <= fr.exit_thresh && __any(!act && ln.stage != ST_EXIT)) break;
             if (fr.trav_mode == 1) accel_round<COUNT, ACCEL, EXT>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc);
-            else if (fr.trav_mode == 2) trace_round<COUNT, ACCEL, EXT, RT_STACK_LDS>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc);
+            else if (fr.trav_mode == 2) trace_round<COUNT, ACCEL, EXT, RT_STACK_LDS, !POOL>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, lds_tm, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc);
             else if (fr.trav_mode == 4) accel_round_batched<COUNT, ACCEL, EXT>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc);
             else if (POOL && fr.trav_mode == 3) accel_round_pooled<COUNT, ACCEL, EXT>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc, pool);
             else if (act) accel_step<COUNT, ACCEL, EXT>(ln.tv, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc);

@@ -46,6 +46,7 @@ struct Trav {
     float mint, maxt;
     // traversal cursor
     unsigned node;
+    unsigned cx, cy;               // sibling-pair form (kdp_step): the CONTENTS of the current node instead of its index
     float tmin, tmax;
     int sp, sbase;                 // todo stack: entries [sbase, sp) live in the LDS ring, [0, sbase) in HBM
 #ifdef RT_PAIR_FETCH
@@ -248,6 +249,7 @@ RT_DEV void trav_begin(Trav &tv, const DevScene &sc, const Ray &r, bool any) {
         if (t0 > t1) ok = false;     // reference returns at the first failing slab; later slabs cannot un-fail it
     }
     tv.tmin = t0; tv.tmax = t1;
+    tv.cx = sc.root_x; tv.cy = sc.root_y;
     tv.inv = mk3(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z);
     tv.active = ok && sc.n_tris > 0;
 }
@@ -729,13 +731,84 @@ RT_DEV void kd_pop_flat(Trav &tv, bool done, const uint2 RT_L *lds_stack, const 
     tv.active = (done && !pop) ? false : tv.active;
 }
 
+// ---- sibling-pair form of the node step and the pop (DevScene::tpairs) -----------------------------------------------------
+// Stack entry = {far child's node words, tmax}: 8 + 4 bytes in two LDS planes [NS][RT_BLOCK]; the oldest entries spill to HBM as
+// uint4.  Visit order, tie rules and counters are those of kd_step_flat (kdtree.cpp:313-488); what changes is what is fetched.
+struct PairStack { uint2 RT_L *xy; float RT_L *tm; uint4 RT_G *spill; };
+template <bool COUNT, int NS>
+RT_DEV void kdp_step(Trav &tv, bool desc, const DevScene &sc, PairStack st, unsigned n_threads, unsigned gtid, TravCounters &cnt) {
+    const bool dead = desc && !tv.any && tv.maxt < tv.tmin;                    // kdtree.cpp:330
+    const bool go = desc && !dead;
+    if (COUNT) cnt.nodes += go ? 1u : 0u;
+    const unsigned axis = tv.cx & 3u;
+    const bool leaf = axis == 3u;
+    const bool interior = go && !leaf;
+    uint4 pr = make_uint4(3u, 0u, 3u, 0u);
+    if (interior) pr = RT_GPTR(const uint4, sc.tpairs)[tv.cy];
+    const float split = __uint_as_float(tv.cx);                                // perturbed split, B10
+    const float oa = comp(tv.o, int(axis)), da = comp(tv.d, int(axis)), ia = comp(tv.inv, int(axis));
+    const float tplane = (split - oa) * ia;
+    const bool belowFirst = (oa < split) || (oa == split && da >= 0.f);
+    const unsigned fx = belowFirst ? pr.x : pr.z, fy = belowFirst ? pr.y : pr.w;
+    const unsigned sx = belowFirst ? pr.z : pr.x, sy = belowFirst ? pr.w : pr.y;
+    const bool only_first = tplane > tv.tmax || tplane <= 0.f;
+    const bool only_second = !only_first && tplane < tv.tmin;
+    const bool both = interior && !only_first && !only_second;
+    if (both) {
+        if (tv.sp - tv.sbase == NS) {                                          // ring full: the oldest entry moves to HBM
+            const unsigned o = (unsigned(tv.sbase) % NS) * RT_BLOCK + threadIdx.x;
+            const volatile uint2 RT_L *ox = (const volatile uint2 RT_L *)st.xy + o;
+            const volatile float RT_L *ot = (const volatile float RT_L *)st.tm + o;
+            st.spill[size_t(tv.sbase) * n_threads + gtid] = make_uint4(ox->x, ox->y, __float_as_uint(*ot), 0u);
+            ++tv.sbase;
+            if (COUNT) ++cnt.spills;
+        }
+        const unsigned w = (unsigned(tv.sp) % NS) * RT_BLOCK + threadIdx.x;
+        st.xy[w] = make_uint2(sx, sy); st.tm[w] = tv.tmax;
+        ++tv.sp;
+    }
+    tv.cx = interior ? (only_second ? sx : fx) : tv.cx;
+    tv.cy = interior ? (only_second ? sy : fy) : tv.cy;
+    tv.tmax = both ? tplane : tv.tmax;
+    const bool enter = go && leaf;
+    tv.at_leaf = enter ? true : tv.at_leaf;
+    tv.li = enter ? 0u : tv.li;
+    tv.ln_ = enter ? (tv.cx >> 2) : tv.ln_;
+    tv.ly = enter ? tv.cy : tv.ly;
+    tv.active = dead ? false : tv.active;
+}
+template <int NS>
+RT_DEV void kdp_pop(Trav &tv, bool done, PairStack st, unsigned n_threads, unsigned gtid) {
+    const bool pop = done && tv.sp > 0;
+    unsigned ex = 0, ey = 0; float et = 0.f;
+    if (pop) {
+        --tv.sp;
+        const unsigned r = (unsigned(tv.sp) % NS) * RT_BLOCK + threadIdx.x;
+        const volatile uint2 RT_L *px = (const volatile uint2 RT_L *)st.xy + r;
+        const volatile float RT_L *pt = (const volatile float RT_L *)st.tm + r;
+        ex = px->x; ey = px->y; et = *pt;
+        if (tv.sp < tv.sbase) { const uint4 e = st.spill[size_t(tv.sp) * n_threads + gtid]; ex = e.x; ey = e.y; et = __uint_as_float(e.z); tv.sbase = tv.sp; }
+    }
+    tv.cx = pop ? ex : tv.cx;
+    tv.cy = pop ? ey : tv.cy;
+    tv.tmin = pop ? tv.tmax : tv.tmin;
+    tv.tmax = pop ? et : tv.tmax;
+    tv.at_leaf = done ? false : tv.at_leaf;
+    tv.active = (done && !pop) ? false : tv.active;
+}
+
 // One round of the trace kernel's inner loop: the per-lane order of node visits and primitive tests is that of
 // KdTreeAccel::Intersect / IntersectP, only the interleaving across lanes is chosen here:
 //   A  every descending lane takes up to RT_TRACE_DSTEPS interior steps (a tight loop of nothing but the node step);
 //   B  the lanes that sit at a leaf test one primitive each, repeated while enough lanes still have one;
 //   C  lanes whose leaf is exhausted pop their next subtree.
-template <bool COUNT, int ACCEL, bool EXT, int NS>
-RT_DEV void trace_round(Trav &tv, bool busy, const DevScene &sc, uint2 RT_L *lds_stack, uint2 RT_G *spill, unsigned n_threads, unsigned gtid, TravCounters &cnt) {
+//   With the kd-tree and without the EXT code the steps are the sibling-pair ones (kdp_step / kdp_pop): `lds_tm` is the second LDS plane
+//   of their stack and `spill` is addressed as uint4.
+//   PAIRS_OK = false (the megakernel flavours that live at a VGPR step, e.g. C2's): index form over `tnodes`, 8 registers fewer.
+template <bool COUNT, int ACCEL, bool EXT, int NS, bool PAIRS_OK = true>
+RT_DEV void trace_round(Trav &tv, bool busy, const DevScene &sc, uint2 RT_L *lds_stack, float RT_L *lds_tm, uint2 RT_G *spill, unsigned n_threads, unsigned gtid, TravCounters &cnt) {
+    constexpr bool PAIRS = PAIRS_OK && ACCEL != RT_ACCEL_GRID && !EXT;
+    const PairStack pst = {lds_stack, lds_tm, (uint4 RT_G *)spill};
     if (ACCEL == RT_ACCEL_GRID) {
         if (busy && tv.active && !tv.at_leaf) grid_enter_voxel<COUNT>(tv, sc, cnt);
     } else {
@@ -743,7 +816,8 @@ RT_DEV void trace_round(Trav &tv, bool busy, const DevScene &sc, uint2 RT_L *lds
         for (int k = 0; k < RT_TRACE_DSTEPS; ++k) {
             const bool desc = busy && tv.active && !tv.at_leaf;
             if (!__any(desc)) break;
-            kd_step_flat<COUNT, NS, !EXT>(tv, desc, sc, lds_stack, spill, n_threads, gtid, cnt);
+            if (PAIRS) kdp_step<COUNT, NS>(tv, desc, sc, pst, n_threads, gtid, cnt);
+            else kd_step_flat<COUNT, NS, !EXT>(tv, desc, sc, lds_stack, spill, n_threads, gtid, cnt);
         }
     }
 #pragma unroll 1
@@ -757,6 +831,7 @@ RT_DEV void trace_round(Trav &tv, bool busy, const DevScene &sc, uint2 RT_L *lds
     }
     const bool done = busy && tv.active && tv.at_leaf && tv.li >= tv.ln_;
     if (ACCEL == RT_ACCEL_GRID) { if (done) grid_voxel_done(tv, sc); }
+    else if (PAIRS) kdp_pop<NS>(tv, done, pst, n_threads, gtid);
     else kd_pop_flat<NS>(tv, done, lds_stack, spill, n_threads, gtid);
 }
 

@@ -3,7 +3,7 @@
 # Pass 1: --kernel-trace --stats.  Passes 2..: PMC counters, each group in its own run (no tracing domains next to --pmc).
 set -u
 WL=$1
-OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_r02_$WL
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_r02_$WL${PROF_TAG:-}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --workload $WL"
@@ -13,4 +13,4 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_
   i=$((i+1))
   timeout 900 rocprofv3 --pmc $set --output-format csv -d $OUT/pmc$i -o t -- $CMD > $OUT/pmc$i.log 2>&1
 done
-python $GRAFT_REPO_ROOT/tools/publish_profile_r02.py $WL
+python $GRAFT_REPO_ROOT/tools/publish_profile_r02.py $WL${PROF_TAG:-}

@@ -6,6 +6,7 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 wl = sys.argv[1]
 src = os.path.join(ROOT, "gpurun_out", "prof_r02_" + wl)
+wl = wl.split("_pipe")[0]
 FRAMES = 5
 out = {"workload": wl, "command": "rocprofv3 --kernel-trace --stats | --pmc <group> (one group per run) -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --workload " + wl,
        "frames_per_run": FRAMES, "kernels": {}, "pmc_per_frame": {}}
