@@ -166,6 +166,8 @@ def run_workload(name, args, pkg, torch, dist, world, rank, device_index, steps,
     fence()
     elapsed = time.perf_counter() - t0
     rays_local = cnt["closest_rays"] + cnt["any_rays"]
+    if os.environ.get("PBRT_BENCH_COUNTERS"):
+        print("COUNTERS " + json.dumps({k: int(v) for k, v in cnt.items()}), file=sys.stderr, flush=True)
     k_ms_local = float(np.mean([st["trace_ms"] for st in stats]))
     render_ms_local = float(np.mean([st["render_ms"] for st in stats]))
     tot = torch.tensor([float(rays_local), float(cnt["camera_rays"])], dtype=torch.float64, device="cuda")

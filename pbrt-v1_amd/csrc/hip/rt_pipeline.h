@@ -22,13 +22,19 @@
 #include "rt_integrate.h"
 
 #ifndef RT_TRACE_WAVES
-#define RT_TRACE_WAVES 8          // waves per SIMD the trace kernel is register-capped for (8 = 64 VGPRs)
+#define RT_TRACE_WAVES 6          // waves per SIMD the trace kernel is built for: its 24 KB of LDS stack planes allow 6 workgroups per CU (80 VGPRs)
 #endif
 #ifndef RT_TRACE_STACK
 #define RT_TRACE_STACK 8          // LDS ring entries per lane in the trace kernel: 8 x 8 B x 256 = 16 KB per workgroup, 8 workgroups per CU
 #endif
 #ifndef RT_TRACE_REFILL
-#define RT_TRACE_REFILL 32        // a wave refills its idle lanes from the queue when at least this many are idle
+#define RT_TRACE_REFILL 16        // a wave refills its idle lanes from the queue when at least this many are idle
+#endif
+#ifndef RT_TRACE_CHUNK_MAX
+#define RT_TRACE_CHUNK_MAX 256    // queue rays a trace wave takes from the global head at a time: remaining / (2 * waves), clamped
+#endif
+#ifndef RT_TRACE_CHUNK_MIN
+#define RT_TRACE_CHUNK_MIN 32
 #endif
 
 namespace rt {
@@ -234,6 +240,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) void pipe_trace_kernel(co
     Trav tv; tv.active = false; tv.at_leaf = false; tv.hit_prim = -1; tv.any = false; tv.maxt = 0.f; tv.b1 = tv.b2 = 0.f;
     unsigned slot = 0; bool busy = false;
     bool exhausted = false;
+    unsigned w_next = 0, w_end = 0;                                     // this wave's chunk of the queue (wave-uniform)
+    bool head_done = false;                                             // the global head has passed the end of the queue
+    const unsigned n_waves = gridDim.x * (RT_BLOCK / 64);
     // Outer loop: report finished rays, refill the idle lanes from the queue (one wave-aggregated atomic).  Inner loop: rounds of
     // traversal with nothing else in it, until enough lanes have finished for a refill to pay (or, once the queue is exhausted,
     // until the wave's last ray ends).
@@ -244,14 +253,35 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) void pipe_trace_kernel(co
             busy = false;
         }
         const unsigned long long idle = __ballot(!busy);
-        const unsigned n_idle = unsigned(__popcll(idle));
+        const unsigned n_idle = unsigned(__builtin_amdgcn_readfirstlane(__popcll(idle)));
         if (!exhausted && n_idle >= RT_TRACE_REFILL) {
-            const int leader = __ffsll((long long)idle) - 1;
-            unsigned base = 0;
-            if (lane == leader) base = atomicAdd(job.q_count + RT_QC_HEAD, n_idle);
-            base = __shfl(base, leader);
-            if (base + n_idle >= total) exhausted = true;
-            const unsigned i = base + unsigned(__popcll(idle & ((1ull << lane) - 1ull)));
+            // Rays come from the wave's private chunk of the queue; the global head is touched once per chunk (one device-scope counter
+            // serves ~6-8 ns per atomic whoever asks: with one atomic per refill the head, not the traversal, set this kernel's pace below
+            // 32 idle lanes per refill -- profiles/r02_scan_util3.jsonl).  Chunks shrink as the queue drains (guided self-scheduling), so
+            // the launch's tail stays a few rays per wave.
+            const unsigned have = w_end - w_next;                       // w_end never exceeds total
+            unsigned f_lo = 0, f_hi = 0;                                 // the fresh chunk, clipped to the queue
+            if (have < n_idle && !head_done) {                          // wave-uniform branch
+                const unsigned left = total - w_end;                    // w_end: the head as this wave last saw it
+                unsigned want = left / (2u * n_waves);
+                want = want < RT_TRACE_CHUNK_MIN ? RT_TRACE_CHUNK_MIN : (want > RT_TRACE_CHUNK_MAX ? RT_TRACE_CHUNK_MAX : want);
+                want = want < n_idle - have ? n_idle - have : want;
+                const int leader = __ffsll((long long)idle) - 1;
+                unsigned base = 0;
+                if (lane == leader) base = atomicAdd(job.q_count + RT_QC_HEAD, want);
+                base = __builtin_amdgcn_readfirstlane(__shfl(base, leader));
+                head_done = base + want >= total;
+                f_lo = base < total ? base : total; f_hi = base + want < total ? base + want : total;
+            }
+            const unsigned rk = unsigned(__popcll(idle & ((1ull << lane) - 1ull)));
+            const unsigned fi = f_lo + (rk - have);
+            const unsigned i = rk < have ? w_next + rk : (fi < f_hi ? fi : total);     // total = no ray for this lane
+            if (have < n_idle) {
+                const unsigned took = n_idle - have < f_hi - f_lo ? n_idle - have : f_hi - f_lo;
+                if (f_hi > f_lo) { w_next = f_lo + took; w_end = f_hi; } else w_next = w_end;
+            } else w_next += n_idle;
+            w_next = __builtin_amdgcn_readfirstlane(w_next); w_end = __builtin_amdgcn_readfirstlane(w_end);      // wave-uniform: scalar registers
+            exhausted = head_done && w_next >= w_end;
             if (!busy && i < total) {
                 const bool any = i >= n_closest;
                 const size_t q = any ? size_t(job.n_slots) + (i - n_closest) : size_t(i);

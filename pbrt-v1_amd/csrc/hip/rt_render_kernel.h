@@ -7,6 +7,17 @@
 
 namespace rt {
 
+#ifndef RT_MEGA_CHUNK
+#define RT_MEGA_CHUNK 64          // camera samples a megakernel wave takes from the global work counter at a time
+#endif
+static_assert(RT_MEGA_CHUNK >= 64, "one fresh chunk must cover a whole wave's fetch");
+// a value every lane of the wave holds equally, moved to scalar registers
+RT_DEV unsigned long long uniform64(unsigned long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane(unsigned(v)), hi = __builtin_amdgcn_readfirstlane(unsigned(v >> 32));
+    return (unsigned long long)hi << 32 | lo;
+}
+
+
 // ------------------------------------------------------------------------------------------ kernels
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 1
@@ -62,6 +73,7 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
 #else
 #define RT_PF(x)
 #endif
+    unsigned long long w_next = 0, w_end = 0;                              // this wave's chunk of the sample list (wave-uniform)
     // phase gating (rt_integrate.h, stage_in_phase): sweeps alternate between the two halves of the path state machine;
     // the first sweep is of the second kind (it contains the work fetch)
     int phase = (INTEG == RT_INTEGRATOR_PATH && fr.phase_sync) ? 1 : -1;
@@ -72,13 +84,23 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
             RT_PF(++pf_inner;)
             advance_pass<COUNT, INTEG, VOL, EXT>(sc, fr, ln, gtid, &c_closest, &c_any, &c_bad, phase);
             const unsigned long long want = phase == 0 ? 0ull : __ballot(!ln.has_ray && ln.stage == ST_FETCH);
-            if (want) {                                                   // wave-aggregated work fetch
-                const int leader = __ffsll((long long)want) - 1;
-                unsigned long long base = 0;
-                if (lane == leader) base = atomicAdd(fr.work_counter, (unsigned long long)__popcll(want));
-                base = __shfl(base, leader);
+            if (want) {                                                   // work fetch from the wave's private chunk of the sample list
+                // One device-scope counter serves ~6-8 ns per atomic whoever asks (measured through the trace kernel's refill rate,
+                // profiles/r02_scan_util3.jsonl), so a wave goes to it once per RT_MEGA_CHUNK samples, not once per fetch.
+                const unsigned n_want = unsigned(__popcll(want));
+                const unsigned long long have = w_end - w_next;
+                unsigned long long fresh = 0;
+                if (have < n_want) {                                      // wave-uniform branch
+                    const int leader = __ffsll((long long)want) - 1;
+                    if (lane == leader) fresh = atomicAdd(fr.work_counter, (unsigned long long)RT_MEGA_CHUNK);
+                    fresh = uniform64(__shfl(fresh, leader));
+                }
+                const unsigned long long rk = __popcll(want & ((1ull << lane) - 1ull));
+                const unsigned long long w_mine = rk < have ? w_next + rk : fresh + (rk - have);
+                if (have < n_want) { w_next = fresh + (n_want - have); w_end = fresh + RT_MEGA_CHUNK; }
+                else w_next += n_want;
                 if (!ln.has_ray && ln.stage == ST_FETCH) {
-                    const unsigned long long w = base + __popcll(want & ((1ull << lane) - 1ull));
+                    const unsigned long long w = w_mine;
                     if (w >= fr.total_work) ln.stage = ST_EXIT;
                     else {
                         unsigned long long pixel; int s;

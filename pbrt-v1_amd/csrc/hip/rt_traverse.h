@@ -652,6 +652,9 @@ RT_DEV void accel_round_batched(Trav &tv, bool mine, const DevScene &sc, uint2 R
 #ifndef RT_TRACE_DSTEPS
 #define RT_TRACE_DSTEPS 4         // interior steps a descending lane may take per round before the leaf phase gets its turn
 #endif
+#ifndef RT_TRACE_FOLD
+#define RT_TRACE_FOLD 1            // pair form: a leaf child (or popped leaf) is entered in the step that selects it
+#endif
 #ifndef RT_TRACE_LEAF_MIN
 #define RT_TRACE_LEAF_MIN 24      // keep testing primitives while at least this many lanes have one left
 #endif
@@ -668,7 +671,11 @@ RT_DEV void kd_step_flat(Trav &tv, bool desc, const DevScene &sc, uint2 RT_L *ld
     const bool go = desc && !dead;
     uint2 nd = make_uint2(3u, 0u);
     if (go) nd = RT_GPTR(const uint2, LEAF_ORDER ? sc.tnodes : sc.nodes)[tv.node];
+#ifdef RT_PROBE_UTIL
+    if (COUNT) cnt.nodes += 1u;          // lane slots, not visits: tools/r02_trace_scan.py group util
+#else
     if (COUNT) cnt.nodes += go ? 1u : 0u;
+#endif
     const unsigned axis = nd.x & 3u;
     const bool leaf = axis == 3u;
     const float split = __uint_as_float(nd.x);                                 // perturbed split, B10
@@ -698,7 +705,11 @@ RT_DEV void leaf_test_flat(Trav &tv, bool leafw, const DevScene &sc, TravCounter
     float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
     if (leafw) { const float4 RT_G *gt = RT_GPTR(const float4, sc.ltris) + (size_t(tv.ly) + 3u * tv.li); q0 = gt[0]; q1 = gt[1]; q2 = gt[2]; }
     const unsigned prim = __float_as_uint(q2.w);
+#ifdef RT_PROBE_UTIL
+    if (COUNT) cnt.tris += 1u;
+#else
     if (COUNT) { cnt.tris += leafw ? 1u : 0u; cnt.leaf_refs += (leafw && !single) ? 1u : 0u; }
+#endif
     tv.li += leafw ? 1u : 0u;
     const V3 p1 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
     const V3 s1 = cross3(tv.d, e2);
@@ -739,7 +750,11 @@ template <bool COUNT, int NS>
 RT_DEV void kdp_step(Trav &tv, bool desc, const DevScene &sc, PairStack st, unsigned n_threads, unsigned gtid, TravCounters &cnt) {
     const bool dead = desc && !tv.any && tv.maxt < tv.tmin;                    // kdtree.cpp:330
     const bool go = desc && !dead;
+#ifdef RT_PROBE_UTIL
+    if (COUNT) cnt.nodes += 1u;          // lane slots, not visits: tools/r02_trace_scan.py group util
+#else
     if (COUNT) cnt.nodes += go ? 1u : 0u;
+#endif
     const unsigned axis = tv.cx & 3u;
     const bool leaf = axis == 3u;
     const bool interior = go && !leaf;
@@ -770,15 +785,20 @@ RT_DEV void kdp_step(Trav &tv, bool desc, const DevScene &sc, PairStack st, unsi
     tv.cx = interior ? (only_second ? sx : fx) : tv.cx;
     tv.cy = interior ? (only_second ? sy : fy) : tv.cy;
     tv.tmax = both ? tplane : tv.tmax;
-    const bool enter = go && leaf;
+    // The chosen child's words are in hand, so a leaf child is entered in this very step (the reference's next iteration re-checks
+    // maxt < tmin with unchanged values, kdtree.cpp:330, and then is in the leaf); `leaf` itself is only ever a root that is a leaf.
+    const bool enter = RT_TRACE_FOLD ? go && (tv.cx & 3u) == 3u : go && leaf;
+#ifndef RT_PROBE_UTIL
+    if (COUNT && RT_TRACE_FOLD) cnt.nodes += (interior && enter) ? 1u : 0u;
+#endif
     tv.at_leaf = enter ? true : tv.at_leaf;
     tv.li = enter ? 0u : tv.li;
     tv.ln_ = enter ? (tv.cx >> 2) : tv.ln_;
     tv.ly = enter ? tv.cy : tv.ly;
     tv.active = dead ? false : tv.active;
 }
-template <int NS>
-RT_DEV void kdp_pop(Trav &tv, bool done, PairStack st, unsigned n_threads, unsigned gtid) {
+template <bool COUNT, int NS>
+RT_DEV void kdp_pop(Trav &tv, bool done, PairStack st, unsigned n_threads, unsigned gtid, TravCounters &cnt) {
     const bool pop = done && tv.sp > 0;
     unsigned ex = 0, ey = 0; float et = 0.f;
     if (pop) {
@@ -793,31 +813,54 @@ RT_DEV void kdp_pop(Trav &tv, bool done, PairStack st, unsigned n_threads, unsig
     tv.cy = pop ? ey : tv.cy;
     tv.tmin = pop ? tv.tmax : tv.tmin;
     tv.tmax = pop ? et : tv.tmax;
-    tv.at_leaf = done ? false : tv.at_leaf;
-    tv.active = (done && !pop) ? false : tv.active;
+    // the popped node's words are in hand: the reference's next iteration checks maxt < tmin (kdtree.cpp:330) and, for a leaf, is in it
+    const bool dead = RT_TRACE_FOLD && pop && !tv.any && tv.maxt < tv.tmin;
+    const bool enter = RT_TRACE_FOLD && pop && !dead && (ex & 3u) == 3u;
+#ifndef RT_PROBE_UTIL
+    if (COUNT) cnt.nodes += enter ? 1u : 0u;
+#endif
+    tv.at_leaf = done ? enter : tv.at_leaf;
+    tv.li = enter ? 0u : tv.li;
+    tv.ln_ = enter ? (ex >> 2) : tv.ln_;
+    tv.ly = enter ? ey : tv.ly;
+    tv.active = (done && (!pop || dead)) ? false : tv.active;
 }
 
-// One round of the trace kernel's inner loop: the per-lane order of node visits and primitive tests is that of
-// KdTreeAccel::Intersect / IntersectP, only the interleaving across lanes is chosen here:
-//   A  every descending lane takes up to RT_TRACE_DSTEPS interior steps (a tight loop of nothing but the node step);
-//   B  the lanes that sit at a leaf test one primitive each, repeated while enough lanes still have one;
-//   C  lanes whose leaf is exhausted pop their next subtree.
-//   With the kd-tree and without the EXT code the steps are the sibling-pair ones (kdp_step / kdp_pop): `lds_tm` is the second LDS plane
-//   of their stack and `spill` is addressed as uint4.
-//   PAIRS_OK = false (the megakernel flavours that live at a VGPR step, e.g. C2's): index form over `tnodes`, 8 registers fewer.
+#ifndef RT_TRACE_POP_IN_LOOP
+#define RT_TRACE_POP_IN_LOOP 0
+#endif
+#ifndef RT_TRACE_LEAF_GO
+#define RT_TRACE_LEAF_GO 65       // leave the descent steps early once this many lanes hold an untested primitive (65 = never)
+#endif
 template <bool COUNT, int ACCEL, bool EXT, int NS, bool PAIRS_OK = true>
 RT_DEV void trace_round(Trav &tv, bool busy, const DevScene &sc, uint2 RT_L *lds_stack, float RT_L *lds_tm, uint2 RT_G *spill, unsigned n_threads, unsigned gtid, TravCounters &cnt) {
     constexpr bool PAIRS = PAIRS_OK && ACCEL != RT_ACCEL_GRID && !EXT;
     const PairStack pst = {lds_stack, lds_tm, (uint4 RT_G *)spill};
     if (ACCEL == RT_ACCEL_GRID) {
         if (busy && tv.active && !tv.at_leaf) grid_enter_voxel<COUNT>(tv, sc, cnt);
+    } else if (PAIRS) {
+        // RT_TRACE_POP_IN_LOOP: a lane leaves a finished (or empty) leaf inside the descent loop instead of at the end of the round
+#pragma unroll 1
+        for (int k = 0; k < RT_TRACE_DSTEPS; ++k) {
+            const bool desc = busy && tv.active && !tv.at_leaf;
+            const bool fin = RT_TRACE_POP_IN_LOOP && busy && tv.active && tv.at_leaf && tv.li >= tv.ln_;
+            if (!__any(desc || fin)) break;
+#ifdef RT_PROBE_UTIL
+            if (COUNT) { cnt.leaf_refs += (busy && tv.active) ? 0u : 1u; cnt.spills += (busy && tv.active && tv.at_leaf && tv.li < tv.ln_) ? 1u : 0u; }
+#endif
+            if (__any(desc)) kdp_step<COUNT, NS>(tv, desc, sc, pst, n_threads, gtid, cnt);
+            if (RT_TRACE_POP_IN_LOOP) {
+                const bool done = busy && tv.active && tv.at_leaf && tv.li >= tv.ln_;
+                if (__any(done)) kdp_pop<COUNT, NS>(tv, done, pst, n_threads, gtid, cnt);
+            }
+            if (RT_TRACE_LEAF_GO < 65 && __popcll(__ballot(busy && tv.active && tv.at_leaf && tv.li < tv.ln_)) >= RT_TRACE_LEAF_GO) break;
+        }
     } else {
 #pragma unroll 1
         for (int k = 0; k < RT_TRACE_DSTEPS; ++k) {
             const bool desc = busy && tv.active && !tv.at_leaf;
             if (!__any(desc)) break;
-            if (PAIRS) kdp_step<COUNT, NS>(tv, desc, sc, pst, n_threads, gtid, cnt);
-            else kd_step_flat<COUNT, NS, !EXT>(tv, desc, sc, lds_stack, spill, n_threads, gtid, cnt);
+            kd_step_flat<COUNT, NS, !EXT>(tv, desc, sc, lds_stack, spill, n_threads, gtid, cnt);
         }
     }
 #pragma unroll 1
@@ -831,7 +874,7 @@ RT_DEV void trace_round(Trav &tv, bool busy, const DevScene &sc, uint2 RT_L *lds
     }
     const bool done = busy && tv.active && tv.at_leaf && tv.li >= tv.ln_;
     if (ACCEL == RT_ACCEL_GRID) { if (done) grid_voxel_done(tv, sc); }
-    else if (PAIRS) kdp_pop<NS>(tv, done, pst, n_threads, gtid);
+    else if (PAIRS) { if (__any(done)) kdp_pop<COUNT, NS>(tv, done, pst, n_threads, gtid, cnt); }
     else kd_pop_flat<NS>(tv, done, lds_stack, spill, n_threads, gtid);
 }
 

@@ -1,10 +1,14 @@
 """Summarise gpurun_out/prof_r02_<workload>/ (tools/profile_r02.sh) into gpurun_out/prof_r02_<workload>/summary.json: per kernel
 {calls, total / average ms} from --kernel-trace --stats and per-kernel PMC sums PER FRAME (the bench command renders 1 counted
-+ 1 warm-up + 3 timed frames = 5 frames).  Copy the summary into profiles/ to publish it."""
-import csv, glob, json, os, sys
++ 1 warm-up + 3 timed frames = 5 frames).  `--publish` also writes
+profiles/r02_<tag>{_kernel_stats.csv,_summary.json} and, for the workload's dominant timed kernel, profiles/r02_<tag>_render_kernel.json
+(what bench.py reads `roofline.traffic` from, through the latest_<workload> symlink)."""
+import csv, glob, json, os, shutil, sys
 from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 wl = sys.argv[1]
+tag = wl
+publish = "--publish" in sys.argv[2:]
 src = os.path.join(ROOT, "gpurun_out", "prof_r02_" + wl)
 wl = wl.split("_pipe")[0]
 FRAMES = 5
@@ -40,3 +44,28 @@ for n, d in acc.items():
     out["pmc_per_frame"][n]["derived"] = dv
 json.dump(out, open(os.path.join(src, "summary.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:5000])
+
+if publish:
+    prof = os.path.join(ROOT, "profiles")
+    for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
+        shutil.copy(f, os.path.join(prof, "r02_%s_kernel_stats.csv" % tag))
+    json.dump(out, open(os.path.join(prof, "r02_%s_summary.json" % tag), "w"), indent=1)
+    # dominant timed kernel = the timed (COUNT=false) kernel with the most time per frame
+    timed = {n: k for n, k in out["kernels"].items() if "<false" in n and ("render_kernel" in n or "pipe_trace" in n)}
+    name = max(timed, key=lambda n: timed[n]["total_ms"])
+    p = dict(out["pmc_per_frame"][name]); d = p.pop("derived")
+    frames_timed = FRAMES - 1
+    rk = {"round": 2, "workload": wl, "kernel": name, "command": out["command"],
+          "ms_per_frame_kernel_trace": round(timed[name]["total_ms"] / frames_timed, 3), "calls": timed[name]["calls"],
+          "FETCH_SIZE_KB": p["FETCH_SIZE"], "WRITE_SIZE_KB": p["WRITE_SIZE"],
+          "hbm_bytes_per_launch_uncorrected": d["fabric_bytes_lower_bound"], "hbm_bytes_per_launch_fetch_doubled": d["fabric_bytes_fetch_doubled"],
+          "note_traffic": "per FRAME (all launches of the kernel in one frame); MI355X_MICROARCH.md HBM section: bytes = (FETCH_SIZE + WRITE_SIZE)*1024; "
+                          "FETCH_SIZE tallies 64 B per fabric read request (profiles/r01_fetch_size_calibration.txt), hence the doubled upper bound",
+          "pmc": p,
+          "derived": {"VALUBusy_percent": d.get("VALUBusy_percent"), "VALUUtilization_percent_active_lanes": d.get("lanes_active_percent"),
+                      "L2_hit_rate": d.get("L2_hit_rate"), "L2_misses_per_frame": d.get("L2_misses_per_frame")}}
+    json.dump(rk, open(os.path.join(prof, "r02_%s_render_kernel.json" % tag), "w"), indent=1)
+    if tag == wl:
+        link = os.path.join(prof, "latest_%s_render_kernel.json" % wl)
+        if os.path.lexists(link): os.remove(link)
+        os.symlink("r02_%s_render_kernel.json" % wl, link)

@@ -23,7 +23,7 @@ def bench(tag, env=None, workload="p1000000", steps=3):
     try:
         j = json.loads(r.stdout.strip().splitlines()[-1]); ro = j["roofline"]
         print(json.dumps(dict(tag=tag, workload=workload, Mrays=j["value"], ms=j["ms_per_step"], trace_ms=ro["kernel_ms"], frac=ro["frac"],
-                              render_ms=ro["frame_kernels_ms"]["render"], iters=ro["pipeline_iterations"], slots=ro["pipeline_slots"])), flush=True)
+                              nodes_per_ray=ro["nodes_per_ray"], tris_per_ray=ro["tri_tests_per_ray"], render_ms=ro["frame_kernels_ms"]["render"], iters=ro["pipeline_iterations"], slots=ro["pipeline_slots"])), flush=True)
         open(os.path.join(ROOT, "gpurun_out", "scan_" + tag.replace(":", "_").replace(" ", "_") + ".json"), "w").write(json.dumps(j))
     except Exception as ex:
         print(json.dumps(dict(tag=tag, error=str(ex), stderr=r.stderr[-400:])), flush=True)
@@ -94,6 +94,57 @@ def main():
                 bench("mega_stack%d_%s" % (ns, wl), env={"PBRT_HIP_PIPELINE": "0"}, workload=wl)
         for u in ("rt_mega_p", "rt_mega_d"):
             rebuild(u, [])
+    elif g == "util3":
+        # slot categories of the descent steps (probe build: nodes = step slots, leaf_refs = of which the lane is idle, spills = of which the
+        # lane holds an untested primitive, tris = test slots), then timings of the same knobs without the probe
+        sets = [[], ["-DRT_TRACE_POP_IN_LOOP=1"], ["-DRT_TRACE_REFILL=16"], ["-DRT_TRACE_REFILL=8"], ["-DRT_TRACE_DSTEPS=8"], ["-DRT_TRACE_DSTEPS=2"],
+                ["-DRT_TRACE_LEAF_MIN=12"], ["-DRT_TRACE_LEAF_MIN=40"], ["-DRT_TRACE_DSTEPS=16", "-DRT_TRACE_LEAF_GO=24"], ["-DRT_TRACE_DSTEPS=16", "-DRT_TRACE_LEAF_GO=32", "-DRT_TRACE_LEAF_MIN=16"]]
+        for defs in sets:
+            rebuild("rt_trace", defs + ["-DRT_PROBE_UTIL"])
+            e = dict(os.environ); e.update({"PBRT_HIP_PIPELINE": "1", "PBRT_BENCH_COUNTERS": "1"})
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-extra", "--steps", "1", "--warmup", "0", "--workload", "p1000000"], env=e, capture_output=True, text=True, timeout=400)
+            c = [json.loads(l[9:]) for l in r.stderr.splitlines() if l.startswith("COUNTERS ")][-1]
+            rays = c["closest_rays"] + c["any_rays"]
+            print(json.dumps(dict(tag="probe:" + " ".join(defs), step_slots=round(c["nodes_visited"] / rays, 1), idle=round(c["leaf_refs"] / rays, 1), leaf_pending=round(c["stack_overflows"] / rays, 1), test_slots=round(c["tri_tests"] / rays, 1))), flush=True)
+            rebuild("rt_trace", defs)
+            bench("time:" + " ".join(defs), steps=2)
+        rebuild("rt_trace", [])
+    elif g == "chunk":
+        for defs in ([], ["-DRT_TRACE_REFILL=8"], ["-DRT_TRACE_REFILL=24"], ["-DRT_TRACE_REFILL=32"], ["-DRT_TRACE_CHUNK_MAX=128"], ["-DRT_TRACE_CHUNK_MAX=512"],
+                     ["-DRT_TRACE_REFILL=8", "-DRT_TRACE_CHUNK_MAX=512"], ["-DRT_TRACE_REFILL=4", "-DRT_TRACE_CHUNK_MAX=512"]):
+            rebuild("rt_trace", defs)
+            bench("chunk:" + " ".join(defs), steps=2)
+        rebuild("rt_trace", [])
+        bench("chunk:default c5", workload="c5", steps=2); bench("chunk:default c3", workload="c3", steps=2)
+    elif g == "fold":
+        for defs in (["-DRT_TRACE_FOLD=0"], []):
+            rebuild("rt_trace", defs); rebuild("rt_mega_p", defs); rebuild("rt_mega_d", defs)
+            for wl in ("p1000000", "c5"):
+                bench("pipe fold:" + " ".join(defs), workload=wl, steps=2)
+            for wl in ("p1000000", "c3", "c4", "p100000"):
+                bench("mega fold:" + " ".join(defs), env={"PBRT_HIP_PIPELINE": "0"}, workload=wl, steps=2)
+    elif g == "occ3":
+        for w in (3, 5, 6):
+            for u in ("rt_mega_p", "rt_mega_d"):
+                rebuild(u, ["-DRT_HIGH_OCC_WAVES=%d" % w])
+            for wl in ("p1000000", "c3", "c4"):
+                bench("mega highocc_waves%d" % w, env={"PBRT_HIP_PIPELINE": "0"}, workload=wl, steps=2)
+        for u in ("rt_mega_p", "rt_mega_d"):
+            rebuild(u, [])
+    elif g == "megachunk":
+        for ch in (128, 256):
+            rebuild("rt_mega_p", ["-DRT_MEGA_CHUNK=%d" % ch])
+            for wl in ("c2", "p1000000"):
+                bench("megachunk%d" % ch, env={"PBRT_HIP_PIPELINE": "0"}, workload=wl, steps=2)
+        rebuild("rt_mega_p", [])
+        for wl in ("c2", "p1000000", "c3", "c4"):
+            bench("megachunk64", env={"PBRT_HIP_PIPELINE": "0"}, workload=wl, steps=2)
+    elif g == "util":
+        # lane slots per ray (every lane of a wave that executes a step / a leaf test counts) next to the useful visits
+        for defs in (["-DRT_PROBE_UTIL"], []):
+            rebuild("rt_trace", defs)
+            for wl in ("p1000000", "c5", "c3"):
+                bench("util:" + " ".join(defs), workload=wl, steps=1)
     elif g == "defs":
         defs = sys.argv[2].split(",") if len(sys.argv) > 2 and sys.argv[2] else []
         rebuild("rt_trace", defs)
