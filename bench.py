@@ -240,6 +240,16 @@ def run_workload(name, args, pkg, torch, dist, world, rank, device_index, steps,
             out["roofline"]["traffic_lower_bound"] = int(pj["hbm_bytes_per_launch_uncorrected"])
             out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(os.path.realpath(prof)) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per frame)"
             d = pj.get("derived", {})
+            # the VALU-issue ceiling of the same kernel (what binds the cache-resident workloads): wave-level VALU instructions per frame from
+            # the SQ_INSTS_VALU pass of the same profile, against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction
+            iv = pj.get("pmc", {}).get("SQ_INSTS_VALU")
+            if iv:
+                peak = 256 * 4 * 2.4e9 / 4
+                out["roofline"]["valu_issue"] = {"wave_insts_per_launch": int(iv), "peak_wave_insts_per_s": peak,
+                                                 "ms_at_peak_issue": round(iv / peak * 1e3, 2),
+                                                 "frac": round(iv / peak * 1e3 / max(out["roofline"]["kernel_ms"], 1e-9), 4),
+                                                 "lanes_active": round(d.get("VALUUtilization_percent_active_lanes", 0) / 100.0, 3),
+                                                 "ms_at_peak_issue_with_full_lanes": round(iv / peak * 1e3 * d.get("VALUUtilization_percent_active_lanes", 0) / 100.0, 2)}
             busy = "VALUBusy %.0f%%, %.0f%% of lanes active" % (d.get("VALUBusy_percent", 0), d.get("VALUUtilization_percent_active_lanes", 0))
             if out["roofline"]["traffic"] < 0.1 * alg_bytes:
                 out["roofline"]["note"] = ("this workload's tree and triangles are L1/L2 resident: measured HBM traffic is ~%.0f%% of the algorithmic "
