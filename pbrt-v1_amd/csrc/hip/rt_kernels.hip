@@ -348,27 +348,51 @@ static void host_tri_frame_uv(const float *v, const float *uv, bool flip, float 
     for (int a = 0; a < 3; ++a) { nn[a] = c[a] * inv; if (flip) nn[a] = -1.f * nn[a]; }
 }
 
-// The tree as sibling pairs (rt_device.h DevScene::tpairs), depth-first: the pair of a node's children is followed by the pairs of the
-// below child's subtree, then by those of the above child's.  `tn` = nodes with leaf payloads already pointing into `ltris`.
-static void build_pairs(const std::vector<Node> &tn, std::vector<uint4> &pairs, uint32_t &root_x, uint32_t &root_y) {
+// The tree as sibling pairs (rt_device.h DevScene::tpairs).  A pair is addressed by its absolute index, so the ORDER of the records is
+// free: the traversal (visit order, tie rules, counters) does not depend on it, only which records share a cache line does.
+// `treelet` <= 1: depth-first (the pair of a node's children, then the below child's subtree, then the above child's).
+// `treelet` = T: the tree is cut into treelets of up to T pairs grown breadth-first from their root (the root's pair, its children's
+// pairs, its grandchildren's ... until T records are taken); a treelet's records are consecutive (T = 8: one 128-byte line), the
+// treelets left hanging below it follow depth-first.  A ray walking down k levels inside a treelet touches one line, not k.
+#ifndef RT_TREELET_PAIRS
+#define RT_TREELET_PAIRS 8          // records per treelet of the pair layout (8 x 16 B = one 128-byte line); 1 = depth-first order
+#endif
+#ifndef RT_TREELET_ALIGN
+#define RT_TREELET_ALIGN 1          // treelets never straddle a line (next-fit padding)
+#endif
+static void build_pairs(const std::vector<Node> &tn, std::vector<uint4> &pairs, uint32_t &root_x, uint32_t &root_y, int treelet, bool align) {
     pairs.clear();
     if (tn.empty()) { root_x = 3u; root_y = 0u; pairs.push_back(make_uint4(3u, 0u, 3u, 0u)); return; }
-    pairs.reserve(tn.size() / 2 + 1);
-    struct Rec {
-        const std::vector<Node> &tn; std::vector<uint4> &pairs;
-        uint32_t children(uint32_t parent) {                  // emits the pair of `parent`'s children and everything below; returns its index
-            const uint32_t b = parent + 1u, a = tn[parent].y;
-            const uint32_t p = uint32_t(pairs.size());
-            pairs.push_back(make_uint4(0u, 0u, 0u, 0u));
-            const uint32_t by = (tn[b].x & 3u) != 3u ? children(b) : tn[b].y;
-            const uint32_t ay = (tn[a].x & 3u) != 3u ? children(a) : tn[a].y;
-            pairs[p] = make_uint4(tn[b].x, by, tn[a].x, ay);
-            return p;
-        }
-    } rec{tn, pairs};
     root_x = tn[0].x;
-    root_y = (tn[0].x & 3u) != 3u ? rec.children(0u) : tn[0].y;
-    if (pairs.empty()) pairs.push_back(make_uint4(3u, 0u, 3u, 0u));
+    if ((tn[0].x & 3u) == 3u) { root_y = tn[0].y; pairs.push_back(make_uint4(3u, 0u, 3u, 0u)); return; }
+    auto interior = [&](uint32_t n) { return (tn[n].x & 3u) != 3u; };
+    std::vector<uint32_t> order; order.reserve(tn.size() / 2 + 1);            // parent node of each emitted pair (~0u = padding record)
+    std::vector<uint32_t> pos(tn.size(), ~0u);                                // parent node -> index of its children's pair
+    std::vector<uint32_t> roots{0u}, frontier;
+    const size_t T = treelet <= 1 ? 1 : size_t(treelet);
+    while (!roots.empty()) {
+        frontier.clear(); frontier.push_back(roots.back()); roots.pop_back();
+        size_t head = 0;
+        while (head < frontier.size() && head < T) {
+            const uint32_t P = frontier[head++];
+            const uint32_t b = P + 1u, a = tn[P].y;
+            if (interior(b)) frontier.push_back(b);
+            if (interior(a)) frontier.push_back(a);
+        }
+        // `align`: a treelet never straddles a T-record boundary (next-fit: pad up to the boundary when it would)
+        if (align && T > 1 && (order.size() % T) + head > T) while (order.size() % T) order.push_back(~0u);
+        for (size_t k = 0; k < head; ++k) { pos[frontier[k]] = uint32_t(order.size()); order.push_back(frontier[k]); }
+        for (size_t k = frontier.size(); k > head; --k) roots.push_back(frontier[k - 1]);     // the first one left over is taken up next
+    }
+    if (order.size() >= (size_t(1) << 32)) { pairs.clear(); return; }
+    pairs.resize(order.size());
+    for (size_t i = 0; i < order.size(); ++i) {
+        const uint32_t P = order[i];
+        if (P == ~0u) { pairs[i] = make_uint4(3u, 0u, 3u, 0u); continue; }
+        const uint32_t b = P + 1u, a = tn[P].y;
+        pairs[i] = make_uint4(tn[b].x, interior(b) ? pos[b] : tn[b].y, tn[a].x, interior(a) ? pos[a] : tn[a].y);
+    }
+    root_y = pos[0];
 }
 
 template <class T>
@@ -633,7 +657,13 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
         s->n_leaf_tri_units = lt.size();
         tn.pop_back();
         std::vector<uint4> pairs;
-        build_pairs(tn, pairs, s->dev.root_x, s->dev.root_y);
+        int treelet = RT_TREELET_PAIRS;
+        if (const char *e = std::getenv("PBRT_HIP_TREELET_PAIRS")) treelet = std::max(1, std::atoi(e));                  // layout experiments
+        bool align = RT_TREELET_ALIGN != 0;
+        if (const char *e = std::getenv("PBRT_HIP_TREELET_ALIGN")) align = std::atoi(e) != 0;
+        build_pairs(tn, pairs, s->dev.root_x, s->dev.root_y, treelet, align);
+        if (pairs.empty()) return fail(RT_EINVAL, "rt_scene_create: pair records beyond 2^32");
+        if (std::getenv("PBRT_HIP_TREELET_LOG")) std::fprintf(stderr, "TREELET pairs=%d align=%d interior_nodes=%zu records=%zu\n", treelet, int(align), tn.size() / 2, pairs.size());
         if ((rc = upload(s, pairs.data(), pairs.size(), &s->dev.tpairs))) return rc;
     }
     if ((rc = upload(s, s->tree.leaf_refs.data(), s->tree.leaf_refs.size(), &s->dev.leaf_refs))) return rc;

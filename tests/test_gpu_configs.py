@@ -125,6 +125,39 @@ def test_1m_trace_bit_exact_with_identical_work_counters(pkg, oracle, soup1m):
     assert dc["stack_overflows"] > 0 or ds.counters()["nodes_visited"] > 0
 
 
+def test_pair_record_order_never_changes_a_result(pkg, scenes, monkeypatch):
+    """The sibling-pair records of the kd-tree are addressed by absolute index, so their order in HBM (depth-first, breadth-first
+    treelets of 4 / 8 / 32 records, with or without line-aligned padding) is a pure layout choice: hits, barycentrics and the work
+    counters of closest-hit and any-hit rays must be bit-identical for every order (and the default order is pinned against the
+    oracle by the tests above)."""
+    need_gpu(pkg)
+    text = scenes.cornell_scene(xres=64, yres=64, integrator="path", maxdepth=5, xsamples=2, ysamples=2, jitter=True, soup_tris=60000, keyed=True)
+    rng = np.random.default_rng(5)
+    n = 60_000
+    rays = np.zeros(n, pkg.RAY_DTYPE)
+    rays["o"] = rng.uniform(-20, 580, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays["d"] = d.astype(np.float32); rays["mint"] = 1e-3; rays["maxt"] = np.inf
+    seg = rays.copy(); seg["maxt"] = rng.uniform(50, 600, n).astype(np.float32)
+    results = []
+    for pairs, align in ((1, 0), (4, 0), (8, 1), (8, 0), (32, 1)):
+        monkeypatch.setenv("PBRT_HIP_TREELET_PAIRS", str(pairs)); monkeypatch.setenv("PBRT_HIP_TREELET_ALIGN", str(align))
+        ps = pkg.ParsedScene(text=text)
+        ds = pkg.DeviceScene(ps)
+        ds.reset_counters(); h = ds.trace_closest(rays); c1 = ds.counters()
+        ds.reset_counters(); o = ds.trace_any(seg); c2 = ds.counters()
+        ds.render(); film = ds.film()[0].copy()
+        ds.close()
+        results.append((h, o, {k: (c1[k], c2[k]) for k in ("nodes_visited", "leaf_refs", "tri_tests")}, film))
+    h0, o0, k0, f0 = results[0]
+    assert (h0["prim"] >= 0).mean() > 0.3 and o0.mean() > 0.05
+    for h, o, k, f in results[1:]:
+        for field in ("prim", "t", "b1", "b2"):
+            assert np.array_equal(h[field], h0[field]), field
+        assert np.array_equal(o, o0) and k == k0
+        assert np.array_equal(f, f0)
+
+
 def test_1m_direct_lighting_frame_against_the_oracle(pkg, oracle, soup1m, monkeypatch):
     """A C3 frame (reduced resolution) rendered by every kernel flavour: the counting twin against the oracle (bit-exact film,
     identical counters), then the timed flavours (3 waves/SIMD, 4 waves/SIMD, the queue pipeline) against the twin."""

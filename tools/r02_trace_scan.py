@@ -18,6 +18,7 @@ def rebuild(unit, defs):
 
 def bench(tag, env=None, workload="p1000000", steps=3):
     e = dict(os.environ); e.update(env or {}); e.setdefault("PBRT_HIP_PIPELINE", "1")
+    if e["PBRT_HIP_PIPELINE"] == "": del e["PBRT_HIP_PIPELINE"]
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--steps", str(steps), "--warmup", "1", "--workload", workload],
                        env=e, capture_output=True, text=True, timeout=400)
     try:
@@ -131,6 +132,17 @@ def main():
                 bench("mega highocc_waves%d" % w, env={"PBRT_HIP_PIPELINE": "0"}, workload=wl, steps=2)
         for u in ("rt_mega_p", "rt_mega_d"):
             rebuild(u, [])
+    elif g == "treelet":
+        # order of the sibling-pair records: depth-first vs breadth-first treelets of T records, with / without line alignment
+        for T, al in ((1, 0), (4, 0), (8, 0), (8, 1), (16, 0), (16, 1), (32, 1)):
+            e = {"PBRT_HIP_TREELET_PAIRS": str(T), "PBRT_HIP_TREELET_ALIGN": str(al)}
+            bench("treelet%d_align%d mega" % (T, al), env=dict(e, PBRT_HIP_PIPELINE="0"), steps=2)
+            bench("treelet%d_align%d pipe" % (T, al), env=dict(e, PBRT_HIP_PIPELINE="1"), steps=2)
+    elif g == "treelet2":
+        for T, al in ((1, 0), (8, 1)):
+            e = {"PBRT_HIP_TREELET_PAIRS": str(T), "PBRT_HIP_TREELET_ALIGN": str(al)}
+            for wl in ("c5", "c3", "c4", "p100000"):
+                bench("treelet%d_align%d default-arch" % (T, al), env=dict(e, PBRT_HIP_PIPELINE=""), workload=wl, steps=3)
     elif g == "megachunk":
         for ch in (128, 256):
             rebuild("rt_mega_p", ["-DRT_MEGA_CHUNK=%d" % ch])
