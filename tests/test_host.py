@@ -1,5 +1,6 @@
 """Host front end (pbrt-v1_amd/csrc/host): scene parser, ParamSet semantics, API state machine, plugin factory
 defaults.  Reference behaviours cited per test.  CPU only."""
+import os
 import numpy as np
 import pytest
 
@@ -194,6 +195,24 @@ def test_exr_reader_refuses_truncated_and_foreign_files(pkg, tmp_path):
         with pytest.raises(IOError):
             pkg.read_exr(q)
     assert pkg.read_exr(p)[2] == dict(total_res=(20, 20), offset=(3, 4))
+
+
+def test_exr_reader_opens_a_file_written_by_the_openexr_library(pkg, tmp_path):
+    """The one EXR file in this image that the product's writer did not produce: CPython's imghdr test datum (tests/golden/third_party),
+    an RGBA-half scanline file written by the OpenEXR library (channels A B G R in the library's alphabetical order, no compression), with
+    the same picture as an 8-bit PPM beside it.  The reader must decode it to the PPM's values within half precision, and the product's
+    writer must reproduce the file's pixel data byte for byte (same channel order, same half encoding, same scanline layout)."""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "third_party")
+    rgb, alpha, info = pkg.read_exr(os.path.join(here, "python.exr"))
+    assert rgb.shape == (16, 16, 3) and info == dict(total_res=(16, 16), offset=(0, 0))
+    head, dims, mx, data = open(os.path.join(here, "python.ppm"), "rb").read().split(b"\n", 3)
+    assert head == b"P6" and dims == b"16 16" and mx == b"255"
+    ppm = np.frombuffer(data, np.uint8).reshape(16, 16, 3) / 255.0
+    assert np.abs(rgb - ppm).max() < 4.9e-4                                   # half has 11 significant bits: 2^-11 relative
+    assert alpha.min() == 0.0 and alpha.max() == 1.0 and 0.2 < alpha.mean() < 1.0   # the logo on a transparent ground
+    # write what was read: header attributes, offset table and scanline blocks come out byte for byte as the library wrote them
+    q = str(tmp_path / "again.exr"); pkg.write_exr(q, rgb, alpha)
+    assert open(os.path.join(here, "python.exr"), "rb").read() == open(q, "rb").read()
 
 
 def test_exr_assemble_merges_crop_windows(pkg, tmp_path):
