@@ -143,6 +143,14 @@ def main():
             e = {"PBRT_HIP_TREELET_PAIRS": str(T), "PBRT_HIP_TREELET_ALIGN": str(al)}
             for wl in ("c5", "c3", "c4", "p100000"):
                 bench("treelet%d_align%d default-arch" % (T, al), env=dict(e, PBRT_HIP_PIPELINE=""), workload=wl, steps=3)
+    elif g == "gather":
+        # where the film gather's time goes on the C2 frame: staging only / accumulation only / both
+        for defs in (["-DRT_GATHER_NOACC"], ["-DRT_GATHER_NOSTAGE"], []):
+            rebuild("rt_kernels", defs)
+            e = dict(os.environ)
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-extra", "--steps", "3", "--warmup", "1"], env=e, capture_output=True, text=True, timeout=400)
+            j = json.loads(r.stdout.strip().splitlines()[-1])
+            print(json.dumps(dict(tag="gather:" + " ".join(defs), ms=j["ms_per_step"], kernels=j["roofline"]["frame_kernels_ms"])), flush=True)
     elif g == "megachunk":
         for ch in (128, 256):
             rebuild("rt_mega_p", ["-DRT_MEGA_CHUNK=%d" % ch])
