@@ -26,8 +26,8 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-msse2", "-mfpmath=sse", "-fvisibility=hidden", "-fvisibility-inlines-hidden"]
 
 
-HIP_UNITS = ("rt_kernels.hip", "rt_trace.hip", "rt_mega_w.hip", "rt_mega_d.hip", "rt_mega_p.hip", "rt_pipe_w.hip", "rt_pipe_d.hip",
-             "rt_pipe_p.hip", "kd_build.cpp", "grid_build.cpp")
+HIP_UNITS = ("rt_kernels.hip", "rt_sort.hip", "rt_trace.hip", "rt_mega_w.hip", "rt_mega_d.hip", "rt_mega_p.hip", "rt_pipe_w.hip", "rt_pipe_d.hip",
+             "rt_pipe_p.hip", "rt_pipe_v.hip", "kd_build.cpp", "grid_build.cpp")
 
 
 def build(force: bool = False, verbose: bool = False, defines=(), jobs: int | None = None) -> None:
@@ -48,6 +48,17 @@ def build(force: bool = False, verbose: bool = False, defines=(), jobs: int | No
     def stale(out, deps):
         return force or not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
 
+    def closure(path, seen=None):
+        """the files `path` includes with #include "..." (transitively): a unit is rebuilt only when one of ITS headers changed"""
+        import re
+        seen = set() if seen is None else seen
+        if path in seen or not os.path.exists(path):
+            return seen
+        seen.add(path)
+        for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(path).read(), re.M):
+            closure(os.path.normpath(os.path.join(os.path.dirname(path), inc)), seen)
+        return seen
+
     stamp = os.path.join(obj_dir, "defines.txt")
     dtext = " ".join(defines)
     if (open(stamp).read() if os.path.exists(stamp) else "") != dtext:
@@ -55,7 +66,7 @@ def build(force: bool = False, verbose: bool = False, defines=(), jobs: int | No
     todo = []
     for u in HIP_UNITS:
         obj = os.path.join(obj_dir, u.rsplit(".", 1)[0] + ".o")
-        if stale(obj, [os.path.join(hip_dir, u)] + headers):
+        if stale(obj, sorted(closure(os.path.join(hip_dir, u)))):
             todo.append(["hipcc"] + [f for f in HIPCC_FLAGS if f != "-shared"] + list(defines) + ["-c", os.path.join(hip_dir, u), "-o", obj])
     if todo:
         def run(cmd):

@@ -13,7 +13,9 @@
 // Compile: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (parity with the reference's non-FMA build).
 #include "rt_render_kernel.h"
 #include "rt_pipeline.h"
+#include "rt_pipe_vertex.h"
 #include "rt_internal.h"
+#include "rt_sort.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -207,7 +209,7 @@ using namespace rt;
 // (EXT: powf and the second lobe cost ~17 VGPRs, one wave per SIMD less for DirectLighting).  `variant` keeps round 1's numbering:
 // ((VOL*2 + ACCEL)*2 + COUNT)*3 + INTEG | 24 + (VOL*2 + ACCEL)*3 + INTEG | 36 + (VOL*2 + ACCEL)*3 + INTEG.
 namespace rt { extern const RenderKernelFn g_render_kernels_whitted[16], g_render_kernels_direct[16], g_render_kernels_path[16]; }
-namespace rt { extern const PipeShadeFn g_pipe_shade_whitted[6], g_pipe_shade_direct[6], g_pipe_shade_path[6]; extern const PipeTraceFn g_pipe_trace[8]; }
+namespace rt { extern const PipeShadeFn g_pipe_shade_whitted[6], g_pipe_shade_direct[6], g_pipe_shade_path[6]; extern const PipeTraceFn g_pipe_trace[8]; extern const PipeShadeFn g_pipe_vertex[3]; }
 static RenderKernelFn render_kernel_of(int variant) {
     const RenderKernelFn *t = (variant % 3 == 0) ? g_render_kernels_whitted : (variant % 3 == 1) ? g_render_kernels_direct : g_render_kernels_path;
     return t[variant < 24 ? variant / 3 : variant < 36 ? 8 + (variant - 24) / 3 : 12 + (variant - 36) / 3];
@@ -267,6 +269,9 @@ struct RtScene {
     std::vector<hipEvent_t> pipe_fence;
     bool last_pipeline = false; int pipe_iters = 0, pipe_timed = 0; unsigned pipe_slots = 0;
     float4 *trace_buf = nullptr; size_t trace_cap = 0;   // rt_trace_*: rays (2 x float4) and hits, reused across calls
+    // sorted queue (rt_sort.hip): keys written by the shade kernel, sorted with their queue positions before every trace launch
+    unsigned *sort_keys = nullptr, *sort_keys_out = nullptr, *sort_iota = nullptr, *sort_perm = nullptr; void *sort_temp = nullptr;
+    size_t sort_temp_bytes = 0; unsigned sort_cap = 0;
     unsigned *trace_qc = nullptr;
 };
 #define RT_PIPE_QN 4096          // ring of per-iteration queue counters
@@ -421,6 +426,9 @@ static int ensure(RtScene *s, T **buf, size_t *cap, size_t need) {
 // iterations launched after the last productive one find every slot in ST_EXIT and return at once.
 static int render_pipeline(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, int vol_levels, int vol_nmax, size_t vol_samp_words) {
     const int integ = rd->integrator;
+    // PathIntegrator without a medium: one shade pass per path vertex, all of a vertex's rays in one trace launch (rt_pipe_vertex.h)
+    bool by_vertex = integ == RT_INTEGRATOR_PATH && !s->volume.present;
+    if (const char *e = std::getenv("PBRT_HIP_PIPE_VERTEX")) by_vertex = by_vertex && std::atoi(e) != 0;
     unsigned want = 1u << 23;
     if (const char *e = std::getenv("PBRT_HIP_PIPE_SLOTS")) want = unsigned(std::max(256, std::atoi(e)));
     unsigned long long tw = fr.total_work ? fr.total_work : 1;
@@ -434,16 +442,34 @@ static int render_pipeline(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, int
         s->pool_cap = 0;
         HIPCHK(hipMalloc((void **)&s->pool.state, size_t(vec) * n_slots * sizeof(float4)));
         HIPCHK(hipMalloc((void **)&s->pool.ray_o, size_t(2) * n_slots * sizeof(float4)));
-        HIPCHK(hipMalloc((void **)&s->pool.hit, size_t(n_slots) * sizeof(float4)));
+        HIPCHK(hipMalloc((void **)&s->pool.hit, size_t(3) * n_slots * sizeof(float4)));              // [kind][slot] in the by-vertex form
         HIPCHK(hipMalloc((void **)&s->pool.q_o, size_t(4) * n_slots * sizeof(float4)));
-        HIPCHK(hipMalloc((void **)&s->pool.q_slot, size_t(2) * n_slots * sizeof(unsigned)));
+        HIPCHK(hipMalloc((void **)&s->pool.q_slot, size_t(3) * n_slots * sizeof(unsigned)));
         HIPWARN(hipFree(s->pool.wave_work)); s->pool.wave_work = nullptr;
         HIPCHK(hipMalloc((void **)&s->pool.wave_work, size_t(n_slots / 64 + 1) * 2 * sizeof(unsigned long long)));
         s->pool_cap = n_slots;
     }
     if (!s->pool.q_count) HIPCHK(hipMalloc((void **)&s->pool.q_count, size_t(RT_PIPE_QN) * RT_QC_STRIDE * sizeof(unsigned)));
+    int sort_mode = 0; unsigned sort_begin_bit = 9;
+    if (const char *e = std::getenv("PBRT_HIP_SORT")) sort_mode = std::atoi(e);
+    if (const char *e = std::getenv("PBRT_HIP_SORT_BEGIN_BIT")) sort_begin_bit = unsigned(std::max(0, std::min(30, std::atoi(e))));
+    if (sort_mode && s->sort_cap < n_slots) {
+        HIPCHK(hipStreamSynchronize(s->stream));
+        HIPWARN(hipFree(s->sort_keys)); HIPWARN(hipFree(s->sort_keys_out)); HIPWARN(hipFree(s->sort_iota)); HIPWARN(hipFree(s->sort_perm)); HIPWARN(hipFree(s->sort_temp));
+        s->sort_keys = s->sort_keys_out = s->sort_iota = s->sort_perm = nullptr; s->sort_temp = nullptr; s->sort_cap = 0;
+        const size_t n2 = size_t(2) * n_slots;
+        HIPCHK(hipMalloc((void **)&s->sort_keys, n2 * sizeof(unsigned))); HIPCHK(hipMalloc((void **)&s->sort_keys_out, n2 * sizeof(unsigned)));
+        HIPCHK(hipMalloc((void **)&s->sort_iota, n2 * sizeof(unsigned))); HIPCHK(hipMalloc((void **)&s->sort_perm, n2 * sizeof(unsigned)));
+        s->sort_temp_bytes = sort_pairs_temp_bytes(n2);
+        HIPCHK(hipMalloc(&s->sort_temp, s->sort_temp_bytes ? s->sort_temp_bytes : 16));
+        std::vector<unsigned> iota(n2); for (size_t i = 0; i < n2; ++i) iota[i] = unsigned(i);
+        HIPCHK(hipMemcpy(s->sort_iota, iota.data(), n2 * sizeof(unsigned), hipMemcpyHostToDevice));
+        s->sort_cap = n_slots;
+    }
     PipePool pl = s->pool;
+    pl.q_key = (sort_mode && !by_vertex) ? s->sort_keys : nullptr;
     pl.n_slots = n_slots; pl.ray_d = pl.ray_o + n_slots; pl.q_d = pl.q_o + size_t(2) * n_slots;
+    if (by_vertex) pl.ray_d = pl.q_o;                                       // directions [3][n_slots] (the compacted ray copies are not used)
     // per-slot scratch of the state machine: recursion frames (whitted / directlighting), volume march state
     if (integ != RT_INTEGRATOR_PATH) {
         int rc = ensure(s, &s->frames, &s->frames_floats, size_t(rd->max_depth + 2) * RT_FRAME_WORDS * n_slots); if (rc) return rc;
@@ -461,7 +487,7 @@ static int render_pipeline(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, int
     }
     const int f = s->counting ? 1 : (s->has_ext ? 2 : 0);
     const PipeShadeFn *st = integ == RT_INTEGRATOR_WHITTED ? g_pipe_shade_whitted : integ == RT_INTEGRATOR_DIRECT ? g_pipe_shade_direct : g_pipe_shade_path;
-    const PipeShadeFn shade = st[(s->volume.present ? 3 : 0) + f];
+    const PipeShadeFn shade = by_vertex ? g_pipe_vertex[f] : st[(s->volume.present ? 3 : 0) + f];
     const int tk = (s->accel_kind == RT_ACCEL_GRID ? 4 : 0) + (s->counting ? (s->has_ext ? 1 : 3) : (s->has_ext ? 2 : 0));
     const PipeTraceFn trace = g_pipe_trace[tk];
     HIPCHK(hipMemcpyAsync(s->dev_frame, &fr, sizeof(DevFrame), hipMemcpyHostToDevice, s->stream));
@@ -477,11 +503,17 @@ static int render_pipeline(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, int
         for (int k = 0; k < RT_PIPE_BATCH; ++k, ++iter) {
             const unsigned qi = unsigned(iter % RT_PIPE_QN);
             HIPCHK(hipMemsetAsync(pl.q_count + size_t(RT_QC_STRIDE) * qi, 0, RT_QC_STRIDE * sizeof(unsigned), s->stream));
+            if (sort_mode) HIPCHK(hipMemsetAsync(s->sort_keys, 0xff, size_t(2) * n_slots * sizeof(unsigned), s->stream));
             hipLaunchKernelGGL(shade, dim3(n_slots / RT_BLOCK), dim3(RT_BLOCK), 0, s->stream, (const DevScene *)s->dev_scene,
                                (const DevFrame *)s->dev_frame, (const PipePool *)s->dev_pool, qi);
             TraceJob job{};
             job.q_o = pl.q_o; job.q_d = pl.q_d; job.q_slot = pl.q_slot; job.q_count = pl.q_count + size_t(RT_QC_STRIDE) * qi; job.hit = pl.hit;
             job.n_slots = n_slots; job.spill = s->spill; job.n_threads = s->n_threads; job.counters = s->counters;
+            if (by_vertex) { job.by_slot = 1; job.q_o = pl.ray_o; job.q_d = pl.ray_d; }
+            if (sort_mode && !by_vertex) {
+                HIPCHK(sort_pairs(s->sort_temp, s->sort_temp_bytes, s->sort_keys, s->sort_keys_out, s->sort_iota, s->sort_perm, size_t(2) * n_slots, sort_begin_bit, 32u, s->stream));
+                job.perm = s->sort_perm;
+            }
             if (iter < RT_PIPE_TIMED) HIPCHK(hipEventRecord(s->pipe_ev[2 * iter], s->stream));
             hipLaunchKernelGGL(trace, dim3(s->trace_grids[tk]), dim3(RT_BLOCK), 0, s->stream, (const DevScene *)s->dev_scene, job);
             if (iter < RT_PIPE_TIMED) HIPCHK(hipEventRecord(s->pipe_ev[2 * iter + 1], s->stream));
@@ -793,6 +825,7 @@ int rt_scene_destroy(RtScene *s) {
     HIPWARN(hipFree(s->pool.state)); HIPWARN(hipFree(s->pool.ray_o)); HIPWARN(hipFree(s->pool.hit)); HIPWARN(hipFree(s->pool.q_o));
     HIPWARN(hipFree(s->pool.q_slot)); HIPWARN(hipFree(s->pool.q_count)); HIPWARN(hipFree(s->pool.wave_work)); HIPWARN(hipFree(s->dev_pool));
     HIPWARN(hipFree(s->trace_buf)); HIPWARN(hipFree(s->trace_qc));
+    HIPWARN(hipFree(s->sort_keys)); HIPWARN(hipFree(s->sort_keys_out)); HIPWARN(hipFree(s->sort_iota)); HIPWARN(hipFree(s->sort_perm)); HIPWARN(hipFree(s->sort_temp));
     if (s->h_qcount) HIPWARN(hipHostFree(s->h_qcount));
     for (hipEvent_t e : s->pipe_ev) HIPWARN(hipEventDestroy(e));
     for (hipEvent_t e : s->pipe_fence) HIPWARN(hipEventDestroy(e));

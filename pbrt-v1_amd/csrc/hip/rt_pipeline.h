@@ -51,11 +51,41 @@ struct PipePool {
     unsigned *q_count;            // [iterations][RT_QC_STRIDE]: n closest at +0, consumer head at +RT_QC_HEAD, n any at +RT_QC_ANY
                                   // (three different 64-byte lines: each is the target of one kernel's atomics)
     unsigned long long *wave_work; // [n_slots / 64][2] {next, end}: the chunk of camera samples a wave of the shade kernel owns
+    unsigned *q_key;              // [2][n_slots] sort key of each queued ray (ray_sort_key), 0xFFFFFFFF where the queue is empty; null = unsorted queue
 };
 #define RT_QC_STRIDE 64
 #define RT_QC_HEAD 16
 #define RT_QC_ANY 32
 #define RT_WORK_CHUNK 128         // camera samples a shade wave takes from the global work counter at a time
+
+// ---- sort key of a queued ray: kind << 31 | 30-bit Morton code of the point where the ray enters the tree's bounds ----------------------
+// Rays that start close to each other walk the same path down the tree (at 1 M triangles ~30 of a ray's ~80 node visits are that first
+// descent), so a trace wave whose 64 rays are neighbours asks for one line per step instead of 64 (rt_sort.hip).
+RT_DEV unsigned morton_spread10(unsigned x) {
+    x &= 0x3ffu;
+    x = (x | (x << 16)) & 0x030000FFu;
+    x = (x | (x << 8)) & 0x0300F00Fu;
+    x = (x | (x << 4)) & 0x030C30C3u;
+    x = (x | (x << 2)) & 0x09249249u;
+    return x;
+}
+RT_DEV unsigned ray_sort_key(const DevScene &sc, V3 o, V3 d, float mint, bool any) {
+    float t0 = mint;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float inv = 1.f / comp(d, i);
+        const float ta = (sc.bounds[i] - comp(o, i)) * inv, tb = (sc.bounds[3 + i] - comp(o, i)) * inv;
+        t0 = fmaxf(t0, fminf(ta, tb));
+    }
+    unsigned key = any ? 0x80000000u : 0u;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float lo = sc.bounds[i], hi = sc.bounds[3 + i];
+        const float q = ((comp(o, i) + comp(d, i) * t0) - lo) * (1024.f / (hi - lo));
+        key |= morton_spread10(unsigned(fminf(fmaxf(q, 0.f), 1023.f))) << i;
+    }
+    return key;
+}
 
 // ---- slot state <-> Lane ----------------------------------------------------------------------------------------
 // ctl word: stage (4 bits) | has_ray << 4 | specular << 5 | any << 6 | depth << 8 | fsp << 16
@@ -201,6 +231,7 @@ __global__ __launch_bounds__(RT_BLOCK) void pipe_shade_kernel(const DevScene *__
             const size_t q = ln.tv.any ? size_t(pl.n_slots) + wa + __popcll(ma & below) : size_t(wc) + __popcll(mc & below);
             const float4 ro = make_float4(ln.tv.o.x, ln.tv.o.y, ln.tv.o.z, ln.tv.mint), rd = make_float4(ln.tv.d.x, ln.tv.d.y, ln.tv.d.z, ln.tv.maxt);
             RT_GPTR(float4, pl.q_o)[q] = ro; RT_GPTR(float4, pl.q_d)[q] = rd; RT_GPTR(unsigned, pl.q_slot)[q] = slot;
+            if (pl.q_key) RT_GPTR(unsigned, pl.q_key)[q] = ray_sort_key(sc, ln.tv.o, ln.tv.d, ln.tv.mint, ln.tv.any);
             RT_GPTR(float4, pl.ray_o)[slot] = ro; RT_GPTR(float4, pl.ray_d)[slot] = rd;
         }
     }
@@ -221,6 +252,9 @@ __global__ __launch_bounds__(RT_BLOCK) void pipe_shade_kernel(const DevScene *__
 struct TraceJob {
     const float4 *q_o, *q_d;       // queue rays: closest in [0, n_slots), any in [n_slots, 2 n_slots)
     const unsigned *q_slot;
+    int by_slot;                   // rt_pipe_vertex.h: q_slot holds slot | kind << 30; q_o = ray origins [slot], q_d = directions [kind][slot],
+                                   // hit = [kind][slot]; kind 0 is an any-hit ray
+    const unsigned *perm;          // sorted queue (rt_sort.hip): entry i of the trace order -> position in q_o / q_d / q_slot; null = identity
     unsigned *q_count;             // this iteration's counters: n closest at +0, head at +RT_QC_HEAD, n any at +RT_QC_ANY
     float4 *hit;                   // [slot]; for rt_trace_* (q_slot == nullptr) indexed by queue position
     unsigned n_slots;
@@ -283,10 +317,15 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) void pipe_trace_kernel(co
             w_next = __builtin_amdgcn_readfirstlane(w_next); w_end = __builtin_amdgcn_readfirstlane(w_end);      // wave-uniform: scalar registers
             exhausted = head_done && w_next >= w_end;
             if (!busy && i < total) {
-                const bool any = i >= n_closest;
-                const size_t q = any ? size_t(job.n_slots) + (i - n_closest) : size_t(i);
-                const float4 ro = RT_GPTR(const float4, job.q_o)[q], rd = RT_GPTR(const float4, job.q_d)[q];
-                slot = job.q_slot ? RT_GPTR(const unsigned, job.q_slot)[q] : unsigned(q);
+                bool any = i >= n_closest;
+                size_t q = job.perm ? size_t(RT_GPTR(const unsigned, job.perm)[i]) : (any ? size_t(job.n_slots) + (i - n_closest) : size_t(i));
+                size_t qo = q;
+                if (job.by_slot) {                                      // wave-uniform
+                    const unsigned e = RT_GPTR(const unsigned, job.q_slot)[i];
+                    qo = e & 0x3fffffffu; q = size_t(e >> 30) * job.n_slots + qo; any = (e >> 30) == 0u;
+                }
+                const float4 ro = RT_GPTR(const float4, job.q_o)[qo], rd = RT_GPTR(const float4, job.q_d)[q];
+                slot = job.by_slot ? unsigned(q) : (job.q_slot ? RT_GPTR(const unsigned, job.q_slot)[q] : unsigned(q));
                 Ray r; r.o = mk3(ro.x, ro.y, ro.z); r.mint = ro.w; r.d = mk3(rd.x, rd.y, rd.z); r.maxt = rd.w;
                 accel_begin<ACCEL>(tv, sc, r, any);
                 busy = true;

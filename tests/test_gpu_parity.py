@@ -298,6 +298,22 @@ def test_timed_kernels_produce_the_same_film_as_the_counting_twins(pkg, name, mo
         ds.clear_film(); ds.render()
         got = ds.film_accum()
         assert np.array_equal(got, ref), (name, occ, float(np.abs(got - ref).max()))
+    monkeypatch.delenv("PBRT_HIP_HIGH_OCC")
+    # the queue pipeline: by vertex (rt_pipe_vertex.h: path integrator without a medium; every other frame takes the per-ray form), per
+    # ray, and with so few slots that every slot is refilled many times; its counting twin must also reproduce the ray counts
+    cnt_ref = ds.counters()
+    for env in (dict(PBRT_HIP_PIPELINE="1"), dict(PBRT_HIP_PIPELINE="1", PBRT_HIP_PIPE_VERTEX="0"), dict(PBRT_HIP_PIPELINE="1", PBRT_HIP_PIPE_SLOTS="512")):
+        with pytest.MonkeyPatch.context() as mp:
+            for k, v in env.items():
+                mp.setenv(k, v)
+            for counting in (False, True):
+                ds.set_counting(counting); ds.reset_counters(); ds.clear_film(); ds.render()
+                got = ds.film_accum()
+                assert np.array_equal(got, ref), (name, env, counting, float(np.abs(got - ref).max()))
+                if counting:
+                    c = ds.counters()
+                    for k in ("camera_rays", "closest_rays", "any_rays", "nodes_visited", "leaf_refs", "tri_tests", "bad_samples"):
+                        assert c[k] == cnt_ref[k], (name, env, k, c[k], cnt_ref[k])
     ds.close()
 
 
