@@ -400,6 +400,58 @@ static void build_pairs(const std::vector<Node> &tn, std::vector<uint4> &pairs, 
     root_y = pos[0];
 }
 
+// The same sibling pairs laid out in BLOCKS for the two-level step (kdp_step, rt_traverse.h): an "owner" node P is followed by the pairs of
+// its interior children -- {pair(P), pair(below(P)), pair(above(P))}, 16 / 32 / 48 bytes, never across a 64-byte boundary (next-fit
+// padding) -- and bits 30 / 31 of every word 1 that points at P say which of the two follow.  The owners are the root and, recursively,
+// the interior grandchildren of an owner; the nodes in between are "members" of their parent's block (flags 0: when a member is reached
+// through a pop it takes a one-level step).  Blocks are emitted depth-first, the below side first, so a subtree stays contiguous.
+static void build_pair_blocks(const std::vector<Node> &tn, std::vector<uint4> &pairs, uint32_t &root_x, uint32_t &root_y) {
+    pairs.clear();
+    if (tn.empty()) { root_x = 3u; root_y = 0u; pairs.push_back(make_uint4(3u, 0u, 3u, 0u)); return; }
+    root_x = tn[0].x;
+    if ((tn[0].x & 3u) == 3u) { root_y = tn[0].y; pairs.push_back(make_uint4(3u, 0u, 3u, 0u)); return; }
+    auto interior = [&](uint32_t n) { return (tn[n].x & 3u) != 3u; };
+    std::vector<uint32_t> order; order.reserve(tn.size() / 2 + tn.size() / 8 + 4);   // parent node of each emitted pair (~0u = padding)
+    std::vector<uint32_t> pos(tn.size(), ~0u);                                // node -> index of its children's pair
+    std::vector<uint8_t> owner(tn.size(), 0);
+    std::vector<uint32_t> todo{0u};
+    while (!todo.empty()) {
+        const uint32_t P = todo.back(); todo.pop_back();
+        const uint32_t b = P + 1u, a = tn[P].y;
+        const bool bI = interior(b), aI = interior(a);
+        const size_t size = 1u + (bI ? 1u : 0u) + (aI ? 1u : 0u);
+        if ((order.size() % 4) + size > 4) while (order.size() % 4) order.push_back(~0u);
+        owner[P] = 1;
+        pos[P] = uint32_t(order.size()); order.push_back(P);
+        if (bI) { pos[b] = uint32_t(order.size()); order.push_back(b); }
+        if (aI) { pos[a] = uint32_t(order.size()); order.push_back(a); }
+        // the owners below: interior children of the members; pushed so that below(below(P)) is placed next
+        const uint32_t mem[2] = {a, b};
+        const bool memI[2] = {aI, bI};
+        for (int k = 0; k < 2; ++k) {
+            if (!memI[k]) continue;
+            const uint32_t m = mem[k], mb = m + 1u, ma = tn[m].y;
+            if (interior(ma)) todo.push_back(ma);
+            if (interior(mb)) todo.push_back(mb);
+        }
+    }
+    if (order.size() >= (size_t(1) << 30)) { pairs.clear(); return; }
+    auto word1 = [&](uint32_t n) -> uint32_t {
+        if (!interior(n)) return tn[n].y;                                     // leaf: position of its primitives in ltris
+        uint32_t y = pos[n];
+        if (owner[n]) y |= (interior(n + 1u) ? 1u << 30 : 0u) | (interior(tn[n].y) ? 1u << 31 : 0u);
+        return y;
+    };
+    pairs.resize(order.size());
+    for (size_t i = 0; i < order.size(); ++i) {
+        const uint32_t P = order[i];
+        if (P == ~0u) { pairs[i] = make_uint4(3u, 0u, 3u, 0u); continue; }
+        const uint32_t b = P + 1u, a = tn[P].y;
+        pairs[i] = make_uint4(tn[b].x, word1(b), tn[a].x, word1(a));
+    }
+    root_y = word1(0u);
+}
+
 template <class T>
 static int upload(RtScene *s, const T *host, size_t n, const T **dev) {
     void *p = nullptr;
@@ -693,9 +745,12 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
         if (const char *e = std::getenv("PBRT_HIP_TREELET_PAIRS")) treelet = std::max(1, std::atoi(e));                  // layout experiments
         bool align = RT_TREELET_ALIGN != 0;
         if (const char *e = std::getenv("PBRT_HIP_TREELET_ALIGN")) align = std::atoi(e) != 0;
-        build_pairs(tn, pairs, s->dev.root_x, s->dev.root_y, treelet, align);
-        if (pairs.empty()) return fail(RT_EINVAL, "rt_scene_create: pair records beyond 2^32");
-        if (std::getenv("PBRT_HIP_TREELET_LOG")) std::fprintf(stderr, "TREELET pairs=%d align=%d interior_nodes=%zu records=%zu\n", treelet, int(align), tn.size() / 2, pairs.size());
+        bool blocks = true;
+        if (const char *e = std::getenv("PBRT_HIP_PAIR_BLOCKS")) blocks = std::atoi(e) != 0;                             // layout experiments
+        if (blocks) build_pair_blocks(tn, pairs, s->dev.root_x, s->dev.root_y);
+        else build_pairs(tn, pairs, s->dev.root_x, s->dev.root_y, treelet, align);
+        if (pairs.empty() || pairs.size() >= (size_t(1) << 30)) return fail(RT_EINVAL, "rt_scene_create: pair records beyond 2^30");
+        if (std::getenv("PBRT_HIP_TREELET_LOG")) std::fprintf(stderr, "TREELET blocks=%d pairs=%d align=%d interior_nodes=%zu records=%zu\n", int(blocks), treelet, int(align), tn.size() / 2, pairs.size());
         if ((rc = upload(s, pairs.data(), pairs.size(), &s->dev.tpairs))) return rc;
     }
     if ((rc = upload(s, s->tree.leaf_refs.data(), s->tree.leaf_refs.size(), &s->dev.leaf_refs))) return rc;

@@ -746,6 +746,28 @@ RT_DEV void kd_pop_flat(Trav &tv, bool done, const uint2 RT_L *lds_stack, const 
 // Stack entry = {far child's node words, tmax}: 8 + 4 bytes in two LDS planes [NS][RT_BLOCK]; the oldest entries spill to HBM as
 // uint4.  Visit order, tie rules and counters are those of kd_step_flat (kdtree.cpp:313-488); what changes is what is fetched.
 struct PairStack { uint2 RT_L *xy; float RT_L *tm; uint4 RT_G *spill; };
+// push {far child's words, tmax}; when the ring is full its oldest entry moves to HBM
+template <bool COUNT, int NS>
+RT_DEV void kdp_push(Trav &tv, PairStack st, unsigned sx, unsigned sy, float tmax, unsigned n_threads, unsigned gtid, TravCounters &cnt) {
+    if (tv.sp - tv.sbase == NS) {
+        const unsigned o = (unsigned(tv.sbase) % NS) * RT_BLOCK + threadIdx.x;
+        const volatile uint2 RT_L *ox = (const volatile uint2 RT_L *)st.xy + o;
+        const volatile float RT_L *ot = (const volatile float RT_L *)st.tm + o;
+        st.spill[size_t(tv.sbase) * n_threads + gtid] = make_uint4(ox->x, ox->y, __float_as_uint(*ot), 0u);
+        ++tv.sbase;
+        if (COUNT) ++cnt.spills;
+    }
+    const unsigned w = (unsigned(tv.sp) % NS) * RT_BLOCK + threadIdx.x;
+    st.xy[w] = make_uint2(sx, sy); st.tm[w] = tmax;
+    ++tv.sp;
+}
+// One step = one gather round trip = up to TWO levels of the tree.  Everything that decides which child of the current node P the
+// traversal continues in -- P's split (in hand), the ray, [tmin, tmax] -- is known BEFORE P's children arrive, and the pair layout
+// (build_pair_blocks, rt_kernels.hip) puts the pairs of an "owner" node's interior children right behind the owner's own pair
+// ({P, below(P), above(P)}: at most 48 bytes, never across a 64-byte boundary; bits 30 / 31 of the owner's word 1 say which of them
+// exist).  So the step asks for pair(P) and pair(chosen child) together, and when they arrive takes the reference's decisions for P
+// and for that child back to back (kdtree.cpp:340-365, same comparisons, same push order).  A node that is not an owner (flags 0: a
+// member of its parent's block, reached through a pop) takes the one-level form of the same code.
 template <bool COUNT, int NS>
 RT_DEV void kdp_step(Trav &tv, bool desc, const DevScene &sc, PairStack st, unsigned n_threads, unsigned gtid, TravCounters &cnt) {
     const bool dead = desc && !tv.any && tv.maxt < tv.tmin;                    // kdtree.cpp:330
@@ -758,33 +780,46 @@ RT_DEV void kdp_step(Trav &tv, bool desc, const DevScene &sc, PairStack st, unsi
     const unsigned axis = tv.cx & 3u;
     const bool leaf = axis == 3u;
     const bool interior = go && !leaf;
-    uint4 pr = make_uint4(3u, 0u, 3u, 0u);
-    if (interior) pr = RT_GPTR(const uint4, sc.tpairs)[tv.cy];
+    // ---- level 1: decided from the words in hand
     const float split = __uint_as_float(tv.cx);                                // perturbed split, B10
     const float oa = comp(tv.o, int(axis)), da = comp(tv.d, int(axis)), ia = comp(tv.inv, int(axis));
     const float tplane = (split - oa) * ia;
     const bool belowFirst = (oa < split) || (oa == split && da >= 0.f);
-    const unsigned fx = belowFirst ? pr.x : pr.z, fy = belowFirst ? pr.y : pr.w;
-    const unsigned sx = belowFirst ? pr.z : pr.x, sy = belowFirst ? pr.w : pr.y;
     const bool only_first = tplane > tv.tmax || tplane <= 0.f;
     const bool only_second = !only_first && tplane < tv.tmin;
     const bool both = interior && !only_first && !only_second;
-    if (both) {
-        if (tv.sp - tv.sbase == NS) {                                          // ring full: the oldest entry moves to HBM
-            const unsigned o = (unsigned(tv.sbase) % NS) * RT_BLOCK + threadIdx.x;
-            const volatile uint2 RT_L *ox = (const volatile uint2 RT_L *)st.xy + o;
-            const volatile float RT_L *ot = (const volatile float RT_L *)st.tm + o;
-            st.spill[size_t(tv.sbase) * n_threads + gtid] = make_uint4(ox->x, ox->y, __float_as_uint(*ot), 0u);
-            ++tv.sbase;
-            if (COUNT) ++cnt.spills;
-        }
-        const unsigned w = (unsigned(tv.sp) % NS) * RT_BLOCK + threadIdx.x;
-        st.xy[w] = make_uint2(sx, sy); st.tm[w] = tv.tmax;
-        ++tv.sp;
+    const bool c_above = belowFirst ? only_second : !only_second;             // the child the traversal continues in
+    const unsigned idx = tv.cy & 0x3fffffffu, fb = (tv.cy >> 30) & 1u, fa = tv.cy >> 31;
+    const bool two = interior && (c_above ? fa : fb) != 0u;                    // that child's pair sits in this node's block
+    uint4 A = make_uint4(3u, 0u, 3u, 0u), B = A;
+    if (interior) {
+        const uint4 RT_G *p = RT_GPTR(const uint4, sc.tpairs) + idx;
+        A = p[0];
+        if (two) B = p[1u + (c_above ? fb : 0u)];
     }
-    tv.cx = interior ? (only_second ? sx : fx) : tv.cx;
-    tv.cy = interior ? (only_second ? sy : fy) : tv.cy;
-    tv.tmax = both ? tplane : tv.tmax;
+    const unsigned c_x = c_above ? A.z : A.x, c_y = c_above ? A.w : A.y;
+    const unsigned f_x = c_above ? A.x : A.z, f_y = c_above ? A.y : A.w;
+    if (both) kdp_push<COUNT, NS>(tv, st, f_x, f_y, tv.tmax, n_threads, gtid, cnt);
+    const float tmax1 = both ? tplane : tv.tmax;
+    // ---- level 2: the chosen child (interior, its pair is B)
+    const unsigned axis2 = c_x & 3u;
+    const float split2 = __uint_as_float(c_x);
+    const float oa2 = comp(tv.o, int(axis2)), da2 = comp(tv.d, int(axis2)), ia2 = comp(tv.inv, int(axis2));
+    const float tplane2 = (split2 - oa2) * ia2;
+    const bool belowFirst2 = (oa2 < split2) || (oa2 == split2 && da2 >= 0.f);
+    const bool only_first2 = tplane2 > tmax1 || tplane2 <= 0.f;
+    const bool only_second2 = !only_first2 && tplane2 < tv.tmin;
+    const bool both2 = two && !only_first2 && !only_second2;
+    const bool g_above = belowFirst2 ? only_second2 : !only_second2;
+    const unsigned g_x = g_above ? B.z : B.x, g_y = g_above ? B.w : B.y;
+    const unsigned h_x = g_above ? B.x : B.z, h_y = g_above ? B.y : B.w;
+    if (both2) kdp_push<COUNT, NS>(tv, st, h_x, h_y, tmax1, n_threads, gtid, cnt);
+#ifndef RT_PROBE_UTIL
+    if (COUNT) cnt.nodes += two ? 1u : 0u;
+#endif
+    tv.cx = interior ? (two ? g_x : c_x) : tv.cx;
+    tv.cy = interior ? (two ? g_y : c_y) : tv.cy;
+    tv.tmax = interior ? (both2 ? tplane2 : tmax1) : tv.tmax;
     // The chosen child's words are in hand, so a leaf child is entered in this very step (the reference's next iteration re-checks
     // maxt < tmin with unchanged values, kdtree.cpp:330, and then is in the leaf); `leaf` itself is only ever a root that is a leaf.
     const bool enter = RT_TRACE_FOLD ? go && (tv.cx & 3u) == 3u : go && leaf;
