@@ -1047,7 +1047,8 @@ static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool nee
         // large trees (traversal bound by memory latency): the queue pipeline of rt_pipeline.h; tiny cache-resident ones: the megakernel
         // (measured on the 1 M-triangle frames, 1x MI355X: the pipeline's trace kernel is faster than the megakernel's traversal, but its
         // state traffic and sparse last iterations cost more than that gains, except where shading suspends often: volume marching)
-        fr.pipeline = (!tiny && s->volume.present) ? 1 : 0;
+        // round 3: a path without a medium takes the by-vertex form (rt_pipe_vertex.h): 1 M-triangle frame 72 ms against the megakernel's 79
+        fr.pipeline = (!tiny && (s->volume.present || rd->integrator == RT_INTEGRATOR_PATH)) ? 1 : 0;
         if (const char *e = std::getenv("PBRT_HIP_PIPELINE")) fr.pipeline = std::atoi(e) != 0;
         if (fr.max_depth > 250 || fr.max_depth < 0) fr.pipeline = 0;     // the slot's control word holds depth in 8 bits
         if (fr.trav_mode == 3 && fr.high_occupancy) fr.trav_mode = 1;   // the high-occupancy kernels carry no pooled-leaf scratch

@@ -61,29 +61,28 @@ __global__ __launch_bounds__(RT_BLOCK) void pipe_vertex_kernel(const DevScene *_
 
     // ---- resume: the rays of this slot's previous vertex have been traced
     if (mode == PV_RESUME) {
-        const float4 a2 = st[2 * n], a3 = st[3 * n];
+        // every load of the resume is issued before the first use (a streaming kernel at 3 waves per SIMD lives on loads in flight; the
+        // planes a slot does not need this time cost bandwidth, not latency)
+        const float4 a2 = st[2 * n], a3 = st[3 * n], a4 = st[4 * n], a5 = st[5 * n], a6 = st[6 * n];
+        const float4 ro = RT_GPTR(const float4, pl.ray_o)[slot];
+        const float4 hS = RT_GPTR(const float4, pl.hit)[size_t(PV_RAY_S) * n + slot], hM = RT_GPTR(const float4, pl.hit)[size_t(PV_RAY_M) * n + slot],
+                     hB = RT_GPTR(const float4, pl.hit)[size_t(PV_RAY_B) * n + slot];
+        const float4 rdM = RT_GPTR(const float4, pl.ray_d)[size_t(PV_RAY_M) * n + slot], rdB = RT_GPTR(const float4, pl.ray_d)[size_t(PV_RAY_B) * n + slot];
         ln.L = mk3(a2.x, a2.y, a2.z); ln.cur_light = __float_as_int(a2.w);
         ln.thr = mk3(a3.x, a3.y, a3.z);
-        const float4 ro = RT_GPTR(const float4, pl.ray_o)[slot];
         if (ctl & PV_ED) {                                              // the two halves of EstimateDirect, then path.cpp:99-110
-            const float4 a4 = st[4 * n];
             const V3 thr_old = mk3(a4.x, a4.y, a4.z);
             V3 Ld = mk3(0.f);                                           // transport.cpp:127
             if (ctl & PV_S) {
                 if (COUNT) ++c_any;
-                const float4 a5 = st[5 * n];
-                const float4 h = RT_GPTR(const float4, pl.hit)[size_t(PV_RAY_S) * n + slot];
-                if (__float_as_int(h.x) < 0) Ld = Ld + mk3(a5.x, a5.y, a5.z) * mk3(1.f);      // unoccluded; Transmittance = 1 (no medium)
+                if (__float_as_int(hS.x) < 0) Ld = Ld + mk3(a5.x, a5.y, a5.z) * mk3(1.f);     // unoccluded; Transmittance = 1 (no medium)
             }
             if (ctl & PV_M) {
                 if (COUNT) ++c_closest;
-                const float4 h = RT_GPTR(const float4, pl.hit)[size_t(PV_RAY_M) * n + slot];
-                const int prim = __float_as_int(h.x);
+                const int prim = __float_as_int(hM.x);
                 if (prim >= 0) {                                        // transport.cpp:180-190
-                    const float4 a6 = st[6 * n];
-                    const float4 rd = RT_GPTR(const float4, pl.ray_d)[size_t(PV_RAY_M) * n + slot];
-                    ln.tv.o = mk3(ro.x, ro.y, ro.z); ln.tv.d = mk3(rd.x, rd.y, rd.z); ln.tv.mint = ro.w; ln.tv.maxt = h.y;
-                    ln.tv.hit_prim = prim; ln.tv.b1 = h.z; ln.tv.b2 = h.w;
+                    ln.tv.o = mk3(ro.x, ro.y, ro.z); ln.tv.d = mk3(rdM.x, rdM.y, rdM.z); ln.tv.mint = ro.w; ln.tv.maxt = hM.y;
+                    ln.tv.hit_prim = prim; ln.tv.b1 = hM.z; ln.tv.b2 = hM.w;
                     V3 nh; int light;
                     prim_normal_light<EXT>(sc, ln.tv, nh, light);
                     if (light == ln.cur_light && dot3(nh, -ln.tv.d) > 0) Ld = Ld + mk3(a6.x, a6.y, a6.z) * mk3(1.f);
@@ -92,12 +91,10 @@ __global__ __launch_bounds__(RT_BLOCK) void pipe_vertex_kernel(const DevScene *_
             ln.L = ln.L + thr_old * (Ld * float(nLights));
         }
         if (ctl & PV_B) {                                               // the continuation (or camera) ray: next vertex
-            const float4 rd = RT_GPTR(const float4, pl.ray_d)[size_t(PV_RAY_B) * n + slot];
-            const float4 h = RT_GPTR(const float4, pl.hit)[size_t(PV_RAY_B) * n + slot];
-            ln.tv.o = mk3(ro.x, ro.y, ro.z); ln.tv.mint = ro.w; ln.tv.d = mk3(rd.x, rd.y, rd.z); ln.tv.maxt = rd.w; ln.tv.any = false;
-            ln.tv.hit_prim = __float_as_int(h.x);
-            if (ln.tv.hit_prim >= 0) ln.tv.maxt = h.y;                  // primitive.cpp:120
-            ln.tv.b1 = h.z; ln.tv.b2 = h.w;
+            ln.tv.o = mk3(ro.x, ro.y, ro.z); ln.tv.mint = ro.w; ln.tv.d = mk3(rdB.x, rdB.y, rdB.z); ln.tv.maxt = rdB.w; ln.tv.any = false;
+            ln.tv.hit_prim = __float_as_int(hB.x);
+            if (ln.tv.hit_prim >= 0) ln.tv.maxt = hB.y;                 // primitive.cpp:120
+            ln.tv.b1 = hB.z; ln.tv.b2 = hB.w;
             ln.stage = ST_VERTEX;
         } else ln.stage = ST_RETURN;                                    // the path ended at the previous vertex (PV_ENDED)
     }

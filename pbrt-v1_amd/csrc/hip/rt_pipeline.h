@@ -39,6 +39,10 @@
 
 namespace rt {
 
+static_assert(ST_EXIT < 16, "the slot's control word holds the stage in 4 bits");
+#ifndef RT_PIPE_VOL_SLIM
+#define RT_PIPE_VOL_SLIM 15        // a slot waiting inside a ray march loads / stores only what the march needs
+#endif
 #define RT_PIPE_VEC 12            // float4 planes of slot state (the 11th only for DirectLighting "all", the 12th for the EXT kernels)
 
 struct PipePool {
@@ -105,6 +109,14 @@ RT_DEV void pipe_load(const PipePool &pl, const DevFrame &fr, unsigned slot, Lan
         ln.L = mk3(0.f); ln.thr = mk3(1.f);
         return;
     }
+    if ((RT_PIPE_VOL_SLIM & 1) && ln.stage == ST_VOL_STEP) {   // a ray march waiting for a step's shadow ray: the surface vertex is dead (the march
+        const float4 a2 = st[2 * n], a8 = st[8 * n], a9 = st[9 * n];   // state lives in fr.vol_state); only L, the pending contribution and the ids are live
+        ln.L = mk3(a2.x, a2.y, a2.z);
+        { const unsigned ml = __float_as_uint(a2.w); ln.v.mat = int(ml & 0xffffu); ln.v.light = int(ml >> 16) - 1; }
+        ln.pend = mk3(a8.w, a9.x, a9.y);
+        ln.thr = mk3(1.f);
+        return;
+    }
     const float4 a2 = st[2 * n], a3 = st[3 * n], a4 = st[4 * n], a5 = st[5 * n], a6 = st[6 * n], a7 = st[7 * n], a8 = st[8 * n], a9 = st[9 * n];
     ln.L = mk3(a2.x, a2.y, a2.z);
     { const unsigned ml = __float_as_uint(a2.w); ln.v.mat = int(ml & 0xffffu); ln.v.light = int(ml >> 16) - 1; }
@@ -133,11 +145,14 @@ RT_DEV void pipe_store(const PipePool &pl, unsigned slot, const Lane &ln) {
     st[n] = make_float4(__uint_as_float(ln.dim_base), __uint_as_float(ln.rng.ctr), __uint_as_float(ctl), ln.alpha);
     if (ln.stage == ST_EXIT) return;
     st[2 * n] = make_float4(ln.L.x, ln.L.y, ln.L.z, __uint_as_float(unsigned(ln.v.mat) | (unsigned(ln.v.light + 1) << 16)));
-    st[3 * n] = make_float4(ln.thr.x, ln.thr.y, ln.thr.z, __uint_as_float(unsigned(ln.li) | (unsigned(ln.lj) << 16)));
+    const bool slim = (RT_PIPE_VOL_SLIM & 2) && ln.stage == ST_VOL_STEP;      // see pipe_load
+    if (!(slim && (RT_PIPE_VOL_SLIM & 4))) st[3 * n] = make_float4(ln.thr.x, ln.thr.y, ln.thr.z, __uint_as_float(unsigned(ln.li) | (unsigned(ln.lj) << 16)));
+    if (!(slim && (RT_PIPE_VOL_SLIM & 8))) {
     st[4 * n] = make_float4(ln.v.p.x, ln.v.p.y, ln.v.p.z, __int_as_float(ln.cur_light));
     st[5 * n] = make_float4(ln.v.nn.x, ln.v.nn.y, ln.v.nn.z, ln.bs1);
     st[6 * n] = make_float4(ln.v.sn.x, ln.v.sn.y, ln.v.sn.z, ln.bs2);
     st[7 * n] = make_float4(ln.v.wo.x, ln.v.wo.y, ln.v.wo.z, ln.bcs);
+    }
     st[8 * n] = make_float4(ln.Ld.x, ln.Ld.y, ln.Ld.z, ln.pend.x);
     if (INTEG == RT_INTEGRATOR_DIRECT) {
         st[9 * n] = make_float4(ln.pend.y, ln.pend.z, ln.Ld_light.x, ln.Ld_light.y);
