@@ -223,7 +223,7 @@ def run_workload(name, args, pkg, torch, dist, world, rank, device_index, steps,
                          # launches), and over the whole step (film gather, resolve, host hand-over included)
                          "frac_frame_kernels": round(alg_bytes / (render_ms_local * 1e-3) / 1e9 / 8000.0, 5),
                          "frac_step": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / 8000.0, 5),
-                         "frame_kernels_ms": {"render": round(render_ms_local, 3),
+                         "frame_kernels_ms": {"render": round(render_ms_local, 3), "shade_launches": round(float(np.mean([st.get("shade_ms", 0.0) for st in stats])), 3),
                                               "film_gather": round(float(np.mean([st["gather_ms"] for st in stats])), 3)},
                          "pipeline_iterations": int(stats[-1]["iterations"]), "pipeline_slots": int(stats[-1]["slots"]),
                          "algorithmic_bytes_per_launch": int(alg_bytes),

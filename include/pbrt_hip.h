@@ -273,6 +273,7 @@ typedef struct RtRenderStats {
     float total_ms, render_ms, trace_ms, gather_ms;
     int32_t pipeline, iterations, timed_iterations;
     uint32_t slots;
+    float shade_ms;            /* queue pipeline: the shade launches summed (they overlap the trace launches when the pool runs as two halves) */
 } RtRenderStats;
 int rt_last_render_stats(RtScene *s, RtRenderStats *out);
 

@@ -26,7 +26,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-msse2", "-mfpmath=sse", "-fvisibility=hidden", "-fvisibility-inlines-hidden"]
 
 
-HIP_UNITS = ("rt_kernels.hip", "rt_sort.hip", "rt_trace.hip", "rt_mega_w.hip", "rt_mega_d.hip", "rt_mega_p.hip", "rt_pipe_w.hip", "rt_pipe_d.hip",
+HIP_UNITS = ("rt_kernels.hip", "rt_trace.hip", "rt_mega_w.hip", "rt_mega_d.hip", "rt_mega_p.hip", "rt_pipe_w.hip", "rt_pipe_d.hip",
              "rt_pipe_p.hip", "rt_pipe_v.hip", "kd_build.cpp", "grid_build.cpp")
 
 
@@ -115,7 +115,7 @@ class RtAccelInfo(C.Structure):
 
 class RtRenderStats(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("render_ms", C.c_float), ("trace_ms", C.c_float), ("gather_ms", C.c_float),
-                ("pipeline", C.c_int32), ("iterations", C.c_int32), ("timed_iterations", C.c_int32), ("slots", C.c_uint32)]
+                ("pipeline", C.c_int32), ("iterations", C.c_int32), ("timed_iterations", C.c_int32), ("slots", C.c_uint32), ("shade_ms", C.c_float)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -226,6 +226,9 @@ def write_exr(path, rgb, alpha, total_res=None, offset=(0, 0)):
 
 
 def read_exr(path):
+    """ReadImage for the files write_exr / WriteRGBAImage produce: uncompressed half RGBA scanline EXR.  LIMIT: compressed files are
+    refused (a message on stderr names the compression) -- in particular the PIZ files a stock pbrt-v1 linked against OpenEXR writes
+    (RgbaOutputFile's default); nothing in this image can produce one to validate a decoder against."""
     info = (C.c_int * 6)()
     if host_lib().pbrt_host_read_exr_info(path.encode(), C.byref(info)) != 0:
         raise IOError("cannot read " + path)
@@ -272,7 +275,8 @@ def format_iota(first: int, count: int, per_line: int = 3) -> str:
 
 
 def assemble_exr(paths, out) -> float:
-    """tools/exrassemble.cpp: merge crop-window EXRs into the display-window image; returns the covered fraction."""
+    """tools/exrassemble.cpp: merge crop-window EXRs into the display-window image; returns the covered fraction.  LIMIT: the inputs
+    must be uncompressed half RGBA scanline files (this library's own output); PIZ tiles written by a stock pbrt are refused, see read_exr."""
     H = host_lib()
     H.pbrt_host_assemble_exr.restype = C.c_float
     H.pbrt_host_assemble_exr.argtypes = [C.c_char_p, C.c_char_p]

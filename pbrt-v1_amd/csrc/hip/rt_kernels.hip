@@ -15,7 +15,6 @@
 #include "rt_pipeline.h"
 #include "rt_pipe_vertex.h"
 #include "rt_internal.h"
-#include "rt_sort.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -251,6 +250,7 @@ struct RtScene {
     unsigned grids[48] = {0};          // resident grid per render_kernel<COUNT, INTEG> instantiation
     DevScene *dev_scene = nullptr; DevFrame *dev_frame = nullptr;   // descriptors in HBM (read with scalar loads)
     float4 *samples = nullptr; size_t samples_cap = 0;          // per-shard sample buffer
+    unsigned long long samples_last = 0;                       // camera samples the LAST rt_render wrote (rt_samples_read's range)
     float ms_render = 0.f, ms_gather = 0.f; hipEvent_t ev2 = nullptr;
     float *resolve_buf = nullptr; size_t resolve_cap = 0;
     float *vol_buf = nullptr; size_t vol_cap = 0;          // volume scratch: rays | state | samp
@@ -269,9 +269,9 @@ struct RtScene {
     std::vector<hipEvent_t> pipe_fence;
     bool last_pipeline = false; int pipe_iters = 0, pipe_timed = 0; unsigned pipe_slots = 0;
     float4 *trace_buf = nullptr; size_t trace_cap = 0;   // rt_trace_*: rays (2 x float4) and hits, reused across calls
-    // sorted queue (rt_sort.hip): keys written by the shade kernel, sorted with their queue positions before every trace launch
-    unsigned *sort_keys = nullptr, *sort_keys_out = nullptr, *sort_iota = nullptr, *sort_perm = nullptr; void *sort_temp = nullptr;
-    size_t sort_temp_bytes = 0; unsigned sort_cap = 0;
+    // overlapped pipeline: two CU-masked streams (trace kernel | shade passes) and the events that hand a half of the pool from one to the other
+    hipStream_t st_trace = nullptr, st_shade = nullptr; int trace_cus = 0, n_cus = 0;
+    std::vector<hipEvent_t> pipe_hand;
     unsigned *trace_qc = nullptr;
 };
 #define RT_PIPE_QN 4096          // ring of per-iteration queue counters
@@ -476,16 +476,59 @@ static int ensure(RtScene *s, T **buf, size_t *cap, size_t need) {
 // The queue pipeline: alternate pipe_shade_kernel / pipe_trace_kernel until a shade pass enqueues no ray.  The host learns the
 // queue sizes RT_PIPE_BATCH iterations late (page-locked copy + fence event per batch), so the GPU never waits for it; the
 // iterations launched after the last productive one find every slot in ST_EXIT and return at once.
+// (re)create the two CU-masked streams of the overlapped pipeline: the trace kernel's persistent waves own CUs [0, trace_cus), the shade
+// passes the rest.  On this part a mask bit is one CU and consecutive bits fall on different XCDs (tools/cumask_probe.hip: N bits = N CUs spread
+// over all 8 XCDs, two disjoint masks run side by side), so each side keeps all eight L2s.
+static int ensure_masked_streams(RtScene *s, int trace_cus) {
+    if (s->st_trace && s->trace_cus == trace_cus) return RT_OK;
+    if (s->st_trace) { HIPWARN(hipStreamSynchronize(s->st_trace)); HIPWARN(hipStreamDestroy(s->st_trace)); s->st_trace = nullptr; }
+    if (s->st_shade) { HIPWARN(hipStreamSynchronize(s->st_shade)); HIPWARN(hipStreamDestroy(s->st_shade)); s->st_shade = nullptr; }
+    const int ncu = s->n_cus;
+    std::vector<uint32_t> mt((ncu + 31) / 32, 0u), ms((ncu + 31) / 32, 0u);
+    for (int i = 0; i < ncu; ++i) (i < trace_cus ? mt : ms)[i / 32] |= 1u << (i % 32);
+    HIPCHK(hipExtStreamCreateWithCUMask(&s->st_trace, uint32_t(mt.size()), mt.data()));
+    HIPCHK(hipExtStreamCreateWithCUMask(&s->st_shade, uint32_t(ms.size()), ms.data()));
+    s->trace_cus = trace_cus;
+    return RT_OK;
+}
+
+// The queue pipeline: alternate a shade kernel (pipe_shade_kernel, or pipe_vertex_kernel for a path without a medium) and pipe_trace_kernel
+// until a shade pass enqueues no ray.  The host learns the queue sizes RT_PIPE_BATCH iterations late (page-locked copy + fence event per
+// batch), so the GPU never waits for it; the iterations launched after the last productive one find every slot in ST_EXIT and return at once.
+// Overlapped form (round 3): the pool is run as two halves that take turns -- while one half's rays are traced on most of the CUs, the other
+// half is shaded on the CUs the trace kernel does not own (two CU-masked streams, one event per hand-over).  The shade passes are streaming
+// kernels bound by HBM bandwidth, the trace kernel by the latency of dependent gathers: side by side they cost little more than the slower.
 static int render_pipeline(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, int vol_levels, int vol_nmax, size_t vol_samp_words) {
     const int integ = rd->integrator;
     // PathIntegrator without a medium: one shade pass per path vertex, all of a vertex's rays in one trace launch (rt_pipe_vertex.h)
     bool by_vertex = integ == RT_INTEGRATOR_PATH && !s->volume.present;
     if (const char *e = std::getenv("PBRT_HIP_PIPE_VERTEX")) by_vertex = by_vertex && std::atoi(e) != 0;
+    // ---- pool size: 8 M slots unless the frame is smaller or the per-slot scratch would not fit (a fine ray march: 3 floats per step)
+    const size_t frame_words = integ != RT_INTEGRATOR_PATH ? size_t(rd->max_depth + 2) * RT_FRAME_WORDS : 0;
+    const size_t vol_words = s->volume.present ? size_t(vol_levels) * 8 + 13 + vol_samp_words : 0;
+    const size_t slot_bytes = size_t(RT_PIPE_VEC) * 16 + 2 * 16 + 3 * 16 + 4 * 16 + 3 * 4 + (frame_words + vol_words) * 4;
     unsigned want = 1u << 23;
+    {
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        const size_t held = size_t(s->pool_cap) * (size_t(RT_PIPE_VEC) * 16 + 9 * 16 + 12) + (s->frames_floats + s->vol_cap) * 4;   // what this scene's pool already holds
+        size_t budget = (free_b + held) / 2;                                      // leave half of what is free to the caller (film, other scenes)
+        if (const char *e = std::getenv("PBRT_HIP_PIPE_MEM_MB")) budget = size_t(std::max(1, std::atoi(e))) << 20;      // tests: a small budget
+        if (slot_bytes * want > budget) want = unsigned(std::max<size_t>(budget / slot_bytes, 2 * RT_BLOCK));
+    }
     if (const char *e = std::getenv("PBRT_HIP_PIPE_SLOTS")) want = unsigned(std::max(256, std::atoi(e)));
     unsigned long long tw = fr.total_work ? fr.total_work : 1;
     unsigned n_slots = unsigned(std::min<unsigned long long>(want, tw));
-    n_slots = (n_slots + RT_BLOCK - 1) / RT_BLOCK * RT_BLOCK;
+    // ---- one pool or two halves taking turns
+    // Measured (tools/r03_overlap_probe.sh, profiles/r03_overlap_scan.txt): both kernels scale with the CUs they own -- the trace kernel on 192 of
+    // 256 CUs takes 78 ms instead of 57, the shade passes on the other 64 take 42 ms instead of 12 -- so side by side is slower than one
+    // after the other (1 M-triangle path frame 83 vs 71 ms, C5 440 vs 395 ms).  Off unless asked for.
+    bool overlap = false;
+    if (const char *e = std::getenv("PBRT_HIP_OVERLAP")) overlap = std::atoi(e) != 0 && n_slots >= 4 * RT_BLOCK;
+    const int H = overlap ? 2 : 1;
+    n_slots = (n_slots + H * RT_BLOCK - 1) / (H * RT_BLOCK) * (H * RT_BLOCK);
+    const unsigned half = n_slots / H;
+    if (n_slots >= (1u << 30)) return fail(RT_EINVAL, "rt_render: more than 2^30 pipeline slots");
     const int vec = RT_PIPE_VEC;
     if (n_slots > s->pool_cap) {
         HIPCHK(hipStreamSynchronize(s->stream));
@@ -502,96 +545,104 @@ static int render_pipeline(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, int
         s->pool_cap = n_slots;
     }
     if (!s->pool.q_count) HIPCHK(hipMalloc((void **)&s->pool.q_count, size_t(RT_PIPE_QN) * RT_QC_STRIDE * sizeof(unsigned)));
-    int sort_mode = 0; unsigned sort_begin_bit = 9;
-    if (const char *e = std::getenv("PBRT_HIP_SORT")) sort_mode = std::atoi(e);
-    if (const char *e = std::getenv("PBRT_HIP_SORT_BEGIN_BIT")) sort_begin_bit = unsigned(std::max(0, std::min(30, std::atoi(e))));
-    if (sort_mode && s->sort_cap < n_slots) {
-        HIPCHK(hipStreamSynchronize(s->stream));
-        HIPWARN(hipFree(s->sort_keys)); HIPWARN(hipFree(s->sort_keys_out)); HIPWARN(hipFree(s->sort_iota)); HIPWARN(hipFree(s->sort_perm)); HIPWARN(hipFree(s->sort_temp));
-        s->sort_keys = s->sort_keys_out = s->sort_iota = s->sort_perm = nullptr; s->sort_temp = nullptr; s->sort_cap = 0;
-        const size_t n2 = size_t(2) * n_slots;
-        HIPCHK(hipMalloc((void **)&s->sort_keys, n2 * sizeof(unsigned))); HIPCHK(hipMalloc((void **)&s->sort_keys_out, n2 * sizeof(unsigned)));
-        HIPCHK(hipMalloc((void **)&s->sort_iota, n2 * sizeof(unsigned))); HIPCHK(hipMalloc((void **)&s->sort_perm, n2 * sizeof(unsigned)));
-        s->sort_temp_bytes = sort_pairs_temp_bytes(n2);
-        HIPCHK(hipMalloc(&s->sort_temp, s->sort_temp_bytes ? s->sort_temp_bytes : 16));
-        std::vector<unsigned> iota(n2); for (size_t i = 0; i < n2; ++i) iota[i] = unsigned(i);
-        HIPCHK(hipMemcpy(s->sort_iota, iota.data(), n2 * sizeof(unsigned), hipMemcpyHostToDevice));
-        s->sort_cap = n_slots;
-    }
     PipePool pl = s->pool;
-    pl.q_key = (sort_mode && !by_vertex) ? s->sort_keys : nullptr;
     pl.n_slots = n_slots; pl.ray_d = pl.ray_o + n_slots; pl.q_d = pl.q_o + size_t(2) * n_slots;
     if (by_vertex) pl.ray_d = pl.q_o;                                       // directions [3][n_slots] (the compacted ray copies are not used)
     // per-slot scratch of the state machine: recursion frames (whitted / directlighting), volume march state
     if (integ != RT_INTEGRATOR_PATH) {
-        int rc = ensure(s, &s->frames, &s->frames_floats, size_t(rd->max_depth + 2) * RT_FRAME_WORDS * n_slots); if (rc) return rc;
+        int rc = ensure(s, &s->frames, &s->frames_floats, frame_words * n_slots); if (rc) return rc;
     }
     if (s->volume.present) {
-        int rc = ensure(s, &s->vol_buf, &s->vol_cap, (size_t(vol_levels) * 8 + 13 + vol_samp_words) * n_slots); if (rc) return rc;
+        int rc = ensure(s, &s->vol_buf, &s->vol_cap, vol_words * n_slots); if (rc) return rc;
         fr.vol_rays = s->vol_buf; fr.vol_state = s->vol_buf + size_t(vol_levels) * 8 * n_slots;
         fr.vol_samp = fr.vol_state + size_t(13) * n_slots; fr.vol_nmax = vol_nmax;
     }
     fr.frames = s->frames; fr.n_threads = n_slots;
     if (s->pipe_ev.empty()) {
-        s->pipe_ev.resize(2 * RT_PIPE_TIMED); s->pipe_fence.resize(RT_PIPE_QN / RT_PIPE_BATCH);
+        s->pipe_ev.resize(4 * RT_PIPE_TIMED); s->pipe_fence.resize(RT_PIPE_QN / RT_PIPE_BATCH); s->pipe_hand.resize(6);
         for (auto &e : s->pipe_ev) HIPCHK(hipEventCreate(&e));
         for (auto &e : s->pipe_fence) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto &e : s->pipe_hand) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     const int f = s->counting ? 1 : (s->has_ext ? 2 : 0);
     const PipeShadeFn *st = integ == RT_INTEGRATOR_WHITTED ? g_pipe_shade_whitted : integ == RT_INTEGRATOR_DIRECT ? g_pipe_shade_direct : g_pipe_shade_path;
     const PipeShadeFn shade = by_vertex ? g_pipe_vertex[f] : st[(s->volume.present ? 3 : 0) + f];
     const int tk = (s->accel_kind == RT_ACCEL_GRID ? 4 : 0) + (s->counting ? (s->has_ext ? 1 : 3) : (s->has_ext ? 2 : 0));
     const PipeTraceFn trace = g_pipe_trace[tk];
+    hipStream_t st_shade = s->stream, st_trace = s->stream;
+    unsigned trace_grid = s->trace_grids[tk];
+    if (overlap) {
+        // CUs of the trace kernel: a path's shade passes are light (13 ms of 70 on the whole chip), a ray march's are not (150 of 390)
+        int tc = s->volume.present ? s->n_cus * 5 / 8 : s->n_cus * 3 / 4;
+        if (const char *e = std::getenv("PBRT_HIP_TRACE_CUS")) tc = std::atoi(e);
+        tc = std::max(8, std::min(s->n_cus - 8, tc));
+        int rc = ensure_masked_streams(s, tc); if (rc) return rc;
+        st_shade = s->st_shade; st_trace = s->st_trace;
+        trace_grid = unsigned((unsigned long long)trace_grid * unsigned(tc) / unsigned(s->n_cus));
+        if (trace_grid < 1) trace_grid = 1;
+    }
     HIPCHK(hipMemcpyAsync(s->dev_frame, &fr, sizeof(DevFrame), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemcpyAsync(s->dev_pool, &pl, sizeof(PipePool), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemsetAsync(s->work_counter, 0, sizeof(unsigned long long), s->stream));
     HIPCHK(hipMemsetAsync(pl.state + n_slots, 0, size_t(n_slots) * sizeof(float4), s->stream));      // control words: every slot in ST_FETCH
     HIPCHK(hipMemsetAsync(pl.wave_work, 0, size_t(n_slots / 64 + 1) * 2 * sizeof(unsigned long long), s->stream));
     HIPCHK(hipEventRecord(s->ev0, s->stream));
-    int iter = 0, checked = 0, batch = 0;
+    if (overlap) { HIPCHK(hipStreamWaitEvent(st_shade, s->ev0, 0)); HIPCHK(hipStreamWaitEvent(st_trace, s->ev0, 0)); }
+    hipEvent_t *shaded = &s->pipe_hand[0], *traced = &s->pipe_hand[2];      // [half]: the half's rays are queued / its hits are written
+    int iter = 0, checked = 0, batch = 0, launches = 0;
     bool done = false;
     const int max_iters = 1 << 20;
     while (!done) {
         for (int k = 0; k < RT_PIPE_BATCH; ++k, ++iter) {
-            const unsigned qi = unsigned(iter % RT_PIPE_QN);
-            HIPCHK(hipMemsetAsync(pl.q_count + size_t(RT_QC_STRIDE) * qi, 0, RT_QC_STRIDE * sizeof(unsigned), s->stream));
-            if (sort_mode) HIPCHK(hipMemsetAsync(s->sort_keys, 0xff, size_t(2) * n_slots * sizeof(unsigned), s->stream));
-            hipLaunchKernelGGL(shade, dim3(n_slots / RT_BLOCK), dim3(RT_BLOCK), 0, s->stream, (const DevScene *)s->dev_scene,
-                               (const DevFrame *)s->dev_frame, (const PipePool *)s->dev_pool, qi);
-            TraceJob job{};
-            job.q_o = pl.q_o; job.q_d = pl.q_d; job.q_slot = pl.q_slot; job.q_count = pl.q_count + size_t(RT_QC_STRIDE) * qi; job.hit = pl.hit;
-            job.n_slots = n_slots; job.spill = s->spill; job.n_threads = s->n_threads; job.counters = s->counters;
-            if (by_vertex) { job.by_slot = 1; job.q_o = pl.ray_o; job.q_d = pl.ray_d; }
-            if (sort_mode && !by_vertex) {
-                HIPCHK(sort_pairs(s->sort_temp, s->sort_temp_bytes, s->sort_keys, s->sort_keys_out, s->sort_iota, s->sort_perm, size_t(2) * n_slots, sort_begin_bit, 32u, s->stream));
-                job.perm = s->sort_perm;
+            for (int h = 0; h < H; ++h, ++launches) {
+                const unsigned qi = unsigned(launches % RT_PIPE_QN);
+                PipeLaunch pk{}; pk.qi = qi; pk.slot_base = unsigned(h) * half; pk.q_base = by_vertex ? 3u * pk.slot_base : pk.slot_base;
+                if (overlap && iter > 0) HIPCHK(hipStreamWaitEvent(st_shade, traced[h], 0));
+                HIPCHK(hipMemsetAsync(pl.q_count + size_t(RT_QC_STRIDE) * qi, 0, RT_QC_STRIDE * sizeof(unsigned), st_shade));
+                if (launches < RT_PIPE_TIMED) HIPCHK(hipEventRecord(s->pipe_ev[4 * launches + 2], st_shade));
+                hipLaunchKernelGGL(shade, dim3(half / RT_BLOCK), dim3(RT_BLOCK), 0, st_shade, (const DevScene *)s->dev_scene,
+                                   (const DevFrame *)s->dev_frame, (const PipePool *)s->dev_pool, pk);
+                if (launches < RT_PIPE_TIMED) HIPCHK(hipEventRecord(s->pipe_ev[4 * launches + 3], st_shade));
+                if (overlap) { HIPCHK(hipEventRecord(shaded[h], st_shade)); HIPCHK(hipStreamWaitEvent(st_trace, shaded[h], 0)); }
+                TraceJob job{};
+                job.q_o = pl.q_o; job.q_d = pl.q_d; job.q_slot = pl.q_slot; job.q_count = pl.q_count + size_t(RT_QC_STRIDE) * qi; job.hit = pl.hit;
+                job.n_slots = n_slots; job.q_base = pk.q_base; job.spill = s->spill; job.n_threads = s->n_threads; job.counters = s->counters;
+                if (by_vertex) { job.by_slot = 1; job.q_o = pl.ray_o; job.q_d = pl.ray_d; }
+                if (launches < RT_PIPE_TIMED) HIPCHK(hipEventRecord(s->pipe_ev[4 * launches], st_trace));
+                hipLaunchKernelGGL(trace, dim3(trace_grid), dim3(RT_BLOCK), 0, st_trace, (const DevScene *)s->dev_scene, job);
+                if (launches < RT_PIPE_TIMED) HIPCHK(hipEventRecord(s->pipe_ev[4 * launches + 1], st_trace));
+                if (overlap) HIPCHK(hipEventRecord(traced[h], st_trace));
+                HIPCHK(hipMemcpyAsync(s->h_qcount + size_t(RT_QC_STRIDE) * qi, pl.q_count + size_t(RT_QC_STRIDE) * qi, (RT_QC_ANY + 1) * sizeof(unsigned), hipMemcpyDeviceToHost, st_trace));
             }
-            if (iter < RT_PIPE_TIMED) HIPCHK(hipEventRecord(s->pipe_ev[2 * iter], s->stream));
-            hipLaunchKernelGGL(trace, dim3(s->trace_grids[tk]), dim3(RT_BLOCK), 0, s->stream, (const DevScene *)s->dev_scene, job);
-            if (iter < RT_PIPE_TIMED) HIPCHK(hipEventRecord(s->pipe_ev[2 * iter + 1], s->stream));
-            HIPCHK(hipMemcpyAsync(s->h_qcount + size_t(RT_QC_STRIDE) * qi, pl.q_count + size_t(RT_QC_STRIDE) * qi, (RT_QC_ANY + 1) * sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
         }
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(s->pipe_fence[batch % (RT_PIPE_QN / RT_PIPE_BATCH)], s->stream));
+        HIPCHK(hipEventRecord(s->pipe_fence[batch % (RT_PIPE_QN / RT_PIPE_BATCH)], st_trace));
         if (batch >= 1) {                                                   // look at the batch before the one just launched
             HIPCHK(hipEventSynchronize(s->pipe_fence[(batch - 1) % (RT_PIPE_QN / RT_PIPE_BATCH)]));
             for (int k = 0; k < RT_PIPE_BATCH; ++k, ++checked) {
-                const unsigned *q = s->h_qcount + size_t(RT_QC_STRIDE) * (checked % RT_PIPE_QN);
-                if (q[0] + q[RT_QC_ANY] == 0) { done = true; break; }
+                unsigned rays = 0;
+                for (int h = 0; h < H; ++h) { const unsigned *q = s->h_qcount + size_t(RT_QC_STRIDE) * ((checked * H + h) % RT_PIPE_QN); rays += q[0] + q[RT_QC_ANY]; }
+                if (rays == 0) { done = true; break; }
             }
         }
         ++batch;
         if (iter > max_iters) return fail(RT_ESTATE, "rt_render: the queue pipeline did not terminate");
     }
-    if (std::getenv("PBRT_HIP_PIPE_TRACE_LOG")) {               // per-iteration queue sizes and trace-kernel times (experiments)
+    if (overlap) {                                                          // join: whatever follows on the scene's stream sees the finished frame
+        HIPCHK(hipEventRecord(s->pipe_hand[4], st_shade)); HIPCHK(hipEventRecord(s->pipe_hand[5], st_trace));
+        HIPCHK(hipStreamWaitEvent(s->stream, s->pipe_hand[4], 0)); HIPCHK(hipStreamWaitEvent(s->stream, s->pipe_hand[5], 0));
+    }
+#ifdef RT_PIPE_LOG
+    if (std::getenv("PBRT_HIP_PIPE_TRACE_LOG")) {               // per-launch queue sizes and kernel times (experiments)
         HIPCHK(hipStreamSynchronize(s->stream));
-        for (int i = 0; i <= checked && i < RT_PIPE_TIMED; ++i) {
-            float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, s->pipe_ev[2 * i], s->pipe_ev[2 * i + 1]));
+        for (int i = 0; i < (checked + 1) * H && i < RT_PIPE_TIMED; ++i) {
+            float ms = 0.f, ms2 = 0.f; HIPCHK(hipEventElapsedTime(&ms, s->pipe_ev[4 * i], s->pipe_ev[4 * i + 1])); HIPCHK(hipEventElapsedTime(&ms2, s->pipe_ev[4 * i + 2], s->pipe_ev[4 * i + 3]));
             const unsigned *q = s->h_qcount + size_t(RT_QC_STRIDE) * (i % RT_PIPE_QN);
-            std::fprintf(stderr, "PIPE iter %d closest %u any %u trace_ms %.3f Mrays/s %.0f\n", i, q[0], q[RT_QC_ANY], ms, (q[0] + q[RT_QC_ANY]) / (ms * 1e3 + 1e-9));
+            std::fprintf(stderr, "PIPE launch %d closest %u any %u trace_ms %.3f Mrays/s %.0f shade_ms %.3f\n", i, q[0], q[RT_QC_ANY], ms, (q[0] + q[RT_QC_ANY]) / (ms * 1e3 + 1e-9), ms2);
         }
     }
-    s->pipe_slots = n_slots; s->pipe_iters = checked + 1; s->pipe_timed = std::min(s->pipe_iters, RT_PIPE_TIMED);
+#endif
+    s->pipe_slots = n_slots; s->pipe_iters = checked + 1; s->pipe_timed = std::min(s->pipe_iters * H, RT_PIPE_TIMED);
     HIPCHK(hipEventRecord(s->ev1, s->stream));
     s->last_pipeline = true;
     return RT_OK;
@@ -827,6 +878,7 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
     // persistent launch geometry: as many resident blocks as the kernel's registers/LDS admit
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, s->device));
+    s->n_cus = prop.multiProcessorCount;
     {
         unsigned mx = 0;
         for (int k = 0; k < 48; ++k) {
@@ -880,7 +932,9 @@ int rt_scene_destroy(RtScene *s) {
     HIPWARN(hipFree(s->pool.state)); HIPWARN(hipFree(s->pool.ray_o)); HIPWARN(hipFree(s->pool.hit)); HIPWARN(hipFree(s->pool.q_o));
     HIPWARN(hipFree(s->pool.q_slot)); HIPWARN(hipFree(s->pool.q_count)); HIPWARN(hipFree(s->pool.wave_work)); HIPWARN(hipFree(s->dev_pool));
     HIPWARN(hipFree(s->trace_buf)); HIPWARN(hipFree(s->trace_qc));
-    HIPWARN(hipFree(s->sort_keys)); HIPWARN(hipFree(s->sort_keys_out)); HIPWARN(hipFree(s->sort_iota)); HIPWARN(hipFree(s->sort_perm)); HIPWARN(hipFree(s->sort_temp));
+    if (s->st_trace) { HIPWARN(hipStreamSynchronize(s->st_trace)); HIPWARN(hipStreamDestroy(s->st_trace)); }
+    if (s->st_shade) { HIPWARN(hipStreamSynchronize(s->st_shade)); HIPWARN(hipStreamDestroy(s->st_shade)); }
+    for (hipEvent_t e : s->pipe_hand) HIPWARN(hipEventDestroy(e));
     if (s->h_qcount) HIPWARN(hipHostFree(s->h_qcount));
     for (hipEvent_t e : s->pipe_ev) HIPWARN(hipEventDestroy(e));
     for (hipEvent_t e : s->pipe_fence) HIPWARN(hipEventDestroy(e));
@@ -995,6 +1049,7 @@ static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool nee
         std::vector<DevLight> lights(nl);
         if (nl) HIPCHK(hipMemcpy(lights.data(), s->dev.lights, nl * sizeof(DevLight), hipMemcpyDeviceToHost));
         for (int i = 0; i < nl; ++i) { int ns = lights[i].n_samples; if (rd->sampler == RT_SAMPLER_LOWDISCREPANCY) ns = int(round_up_pow2(unsigned(ns)));   // Sampler::RoundSize
+            if (ns > 65535) return fail(RT_EINVAL, "rt_render: more than 65535 samples per light (the sample table holds counts in 16 bits)");
             n2.push_back(ns); n2.push_back(ns); n1.push_back(ns); }
     } else if (rd->integrator == RT_INTEGRATOR_DIRECT) { n2 = {1, 1}; n1 = {1, 1}; }
     else if (rd->integrator == RT_INTEGRATOR_PATH) { n1.assign(9, 1); n2.assign(9, 1); }
@@ -1051,6 +1106,8 @@ static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool nee
         fr.pipeline = (!tiny && (s->volume.present || rd->integrator == RT_INTEGRATOR_PATH)) ? 1 : 0;
         if (const char *e = std::getenv("PBRT_HIP_PIPELINE")) fr.pipeline = std::atoi(e) != 0;
         if (fr.max_depth > 250 || fr.max_depth < 0) fr.pipeline = 0;     // the slot's control word holds depth in 8 bits
+        for (int i = 0; i < fr.n2d; ++i) if (fr.two_d[i].n >= 65535) fr.pipeline = 0;         // ... and the light / sample cursors in 16 bits each
+        if (s->dev.n_lights >= 65535u) fr.pipeline = 0;
         if (fr.trav_mode == 3 && fr.high_occupancy) fr.trav_mode = 1;   // the high-occupancy kernels carry no pooled-leaf scratch
         if (fr.trav_mode < 0 || fr.trav_mode > 4) fr.trav_mode = 1;
     }
@@ -1200,7 +1257,7 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
         rc = ensure(s, &s->samples, &cap, size_t(fr.total_work ? fr.total_work : 1) * 2); if (rc) return rc;
         s->samples_cap = cap;
     }
-    fr.samples = s->samples;
+    fr.samples = s->samples; s->samples_last = fr.total_work;
     HIPCHK(hipMemcpyAsync(s->filter_dev, rd->filter_table, 256 * sizeof(float), hipMemcpyHostToDevice, s->stream));
     { hipError_t pre = hipGetLastError(); if (pre != hipSuccess) return fail(RT_EDEVICE, std::string("pending HIP error before launch: ") + hipGetErrorString(pre)); }
     if (fr.pipeline) {
@@ -1253,7 +1310,7 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
 // Film::AddSample (scene.cpp:76), in the sampler's order (shard-local work order).  8 floats per sample.
 int rt_samples_read(RtScene *s, uint64_t first, uint64_t count, float *out) {
     if (!s || !out) return fail(RT_EINVAL, "null argument");
-    if (!s->samples || 2 * (first + count) > s->samples_cap) return fail(RT_ESTATE, "rt_samples_read: no frame rendered / range beyond the last frame");
+    if (!s->samples || first > s->samples_last || count > s->samples_last - first) return fail(RT_ESTATE, "rt_samples_read: no frame rendered / range beyond the last frame");
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipStreamSynchronize(s->stream));
     HIPCHK(hipMemcpy(out, s->samples + 2 * first, size_t(count) * 2 * sizeof(float4), hipMemcpyDeviceToHost));
@@ -1314,8 +1371,12 @@ int rt_last_render_stats(RtScene *s, RtRenderStats *out) {
     if (s->last_pipeline) {
         out->iterations = s->pipe_iters; out->timed_iterations = s->pipe_timed;
         float sum = 0.f;
-        for (int i = 0; i < s->pipe_timed; ++i) { float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, s->pipe_ev[2 * i], s->pipe_ev[2 * i + 1])); sum += ms; }
-        out->trace_ms = sum;
+        float sum2 = 0.f;
+        for (int i = 0; i < s->pipe_timed; ++i) {
+            float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, s->pipe_ev[4 * i], s->pipe_ev[4 * i + 1])); sum += ms;
+            HIPCHK(hipEventElapsedTime(&ms, s->pipe_ev[4 * i + 2], s->pipe_ev[4 * i + 3])); sum2 += ms;
+        }
+        out->trace_ms = sum; out->shade_ms = sum2;
         out->slots = s->pipe_slots;
     } else out->trace_ms = out->render_ms;
     return RT_OK;

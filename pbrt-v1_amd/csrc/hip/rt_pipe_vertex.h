@@ -29,12 +29,12 @@ enum { PV_RAY_S = 0, PV_RAY_M = 1, PV_RAY_B = 2 };
 
 template <bool COUNT, bool EXT>
 __global__ __launch_bounds__(RT_BLOCK) void pipe_vertex_kernel(const DevScene *__restrict__ scp, const DevFrame *__restrict__ frp,
-                                                                const PipePool *__restrict__ plp, unsigned iter) {
+                                                                const PipePool *__restrict__ plp, PipeLaunch pk) {
     constexpr int INTEG = RT_INTEGRATOR_PATH;
     const DevScene &sc = *scp;
     const DevFrame &fr = *frp;
     const PipePool &pl = *plp;
-    const unsigned slot = blockIdx.x * RT_BLOCK + threadIdx.x;          // n_slots is a multiple of RT_BLOCK
+    const unsigned slot = pk.slot_base + blockIdx.x * RT_BLOCK + threadIdx.x;   // slot_base and n_slots are multiples of RT_BLOCK
     const int lane = threadIdx.x & 63;
     const size_t n = pl.n_slots;
     const int nLights = int(sc.n_lights);
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(RT_BLOCK) void pipe_vertex_kernel(const DevScene *_
 
     // ---- enqueue: the rays of a slot are neighbours in the queue (wave scan of the per-lane counts, one LDS atomic per wave, one global per workgroup)
     {
-        unsigned RT_G *qc = RT_GPTR(unsigned, pl.q_count) + size_t(iter) * RT_QC_STRIDE;
+        unsigned RT_G *qc = RT_GPTR(unsigned, pl.q_count) + size_t(pk.qi) * RT_QC_STRIDE;
         const unsigned cnt = ((flags & PV_S) ? 1u : 0u) + ((flags & PV_M) ? 1u : 0u) + ((flags & PV_B) ? 1u : 0u);
         const unsigned incl = wave_scan_add(cnt);
         const unsigned wave_total = unsigned(__builtin_amdgcn_readlane(int(incl), 63));
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(RT_BLOCK) void pipe_vertex_kernel(const DevScene *_
         __syncthreads();
         if (threadIdx.x == 0 && blk_cnt) blk_base = atomicAdd((unsigned *)qc, blk_cnt);
         __syncthreads();
-        unsigned q = __shfl(wbase, 0) + blk_base + (incl - cnt);
+        unsigned q = pk.q_base + __shfl(wbase, 0) + blk_base + (incl - cnt);
         if (cnt) {
             unsigned RT_G *qe = RT_GPTR(unsigned, pl.q_slot);
             RT_GPTR(float4, pl.ray_o)[slot] = make_float4(ray_o.x, ray_o.y, ray_o.z, ray_mint);

@@ -36,6 +36,10 @@
 #ifndef RT_TRACE_CHUNK_MIN
 #define RT_TRACE_CHUNK_MIN 32
 #endif
+#ifndef RT_TRACE_RANGES
+#define RT_TRACE_RANGES 1         // contiguous ranges of the ray queue with their own heads (8 = one per XCD: measured WORSE, 1 M path trace 57 -> 60 ms, C5 235 -> 254: the single guided head balances better than range affinity saves misses)
+#endif
+static_assert(RT_TRACE_RANGES >= 1 && RT_TRACE_RANGES <= 8, "the heads sit at q_count[RT_QC_HEAD .. RT_QC_HEAD + 7]");
 
 namespace rt {
 
@@ -55,41 +59,18 @@ struct PipePool {
     unsigned *q_count;            // [iterations][RT_QC_STRIDE]: n closest at +0, consumer head at +RT_QC_HEAD, n any at +RT_QC_ANY
                                   // (three different 64-byte lines: each is the target of one kernel's atomics)
     unsigned long long *wave_work; // [n_slots / 64][2] {next, end}: the chunk of camera samples a wave of the shade kernel owns
-    unsigned *q_key;              // [2][n_slots] sort key of each queued ray (ray_sort_key), 0xFFFFFFFF where the queue is empty; null = unsorted queue
+};
+// one launch of a shade kernel: which part of the pool it covers and where its rays go.  The pool can be run as two halves that take turns
+// (one half is shaded on its own set of CUs while the other's rays are traced, rt_kernels.hip render_pipeline)
+struct PipeLaunch {
+    unsigned qi;                  // index of this launch's counters in q_count
+    unsigned slot_base;           // first slot of the launch
+    unsigned q_base;              // first entry of its region of the queue arrays
 };
 #define RT_QC_STRIDE 64
 #define RT_QC_HEAD 16
 #define RT_QC_ANY 32
 #define RT_WORK_CHUNK 128         // camera samples a shade wave takes from the global work counter at a time
-
-// ---- sort key of a queued ray: kind << 31 | 30-bit Morton code of the point where the ray enters the tree's bounds ----------------------
-// Rays that start close to each other walk the same path down the tree (at 1 M triangles ~30 of a ray's ~80 node visits are that first
-// descent), so a trace wave whose 64 rays are neighbours asks for one line per step instead of 64 (rt_sort.hip).
-RT_DEV unsigned morton_spread10(unsigned x) {
-    x &= 0x3ffu;
-    x = (x | (x << 16)) & 0x030000FFu;
-    x = (x | (x << 8)) & 0x0300F00Fu;
-    x = (x | (x << 4)) & 0x030C30C3u;
-    x = (x | (x << 2)) & 0x09249249u;
-    return x;
-}
-RT_DEV unsigned ray_sort_key(const DevScene &sc, V3 o, V3 d, float mint, bool any) {
-    float t0 = mint;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const float inv = 1.f / comp(d, i);
-        const float ta = (sc.bounds[i] - comp(o, i)) * inv, tb = (sc.bounds[3 + i] - comp(o, i)) * inv;
-        t0 = fmaxf(t0, fminf(ta, tb));
-    }
-    unsigned key = any ? 0x80000000u : 0u;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const float lo = sc.bounds[i], hi = sc.bounds[3 + i];
-        const float q = ((comp(o, i) + comp(d, i) * t0) - lo) * (1024.f / (hi - lo));
-        key |= morton_spread10(unsigned(fminf(fmaxf(q, 0.f), 1023.f))) << i;
-    }
-    return key;
-}
 
 // ---- slot state <-> Lane ----------------------------------------------------------------------------------------
 // ctl word: stage (4 bits) | has_ray << 4 | specular << 5 | any << 6 | depth << 8 | fsp << 16
@@ -164,11 +145,11 @@ RT_DEV void pipe_store(const PipePool &pl, unsigned slot, const Lane &ln) {
 // ---- shade: everything between two rays of a path, for every slot ---------------------------------------------------
 template <bool COUNT, int INTEG, bool VOL, bool EXT>
 __global__ __launch_bounds__(RT_BLOCK) void pipe_shade_kernel(const DevScene *__restrict__ scp, const DevFrame *__restrict__ frp,
-                                                               const PipePool *__restrict__ plp, unsigned iter) {
+                                                               const PipePool *__restrict__ plp, PipeLaunch pk) {
     const DevScene &sc = *scp;
     const DevFrame &fr = *frp;
     const PipePool &pl = *plp;
-    const unsigned slot = blockIdx.x * RT_BLOCK + threadIdx.x;          // n_slots is a multiple of RT_BLOCK
+    const unsigned slot = pk.slot_base + blockIdx.x * RT_BLOCK + threadIdx.x;   // slot_base and n_slots are multiples of RT_BLOCK
     const int lane = threadIdx.x & 63;
     Lane ln;
     ln.v.p = ln.v.nn = ln.v.ng = ln.v.sn = ln.v.tn = ln.v.wo = mk3(0.f); ln.v.mat = 0; ln.v.light = -1;
@@ -228,7 +209,7 @@ __global__ __launch_bounds__(RT_BLOCK) void pipe_shade_kernel(const DevScene *__
     // ---- enqueue: ballot compaction per ray kind inside the wave, LDS atomics inside the workgroup, ONE global atomic per
     // workgroup and kind (the two counters sit on different cache lines)
     {
-        unsigned RT_G *qc = RT_GPTR(unsigned, pl.q_count) + size_t(iter) * RT_QC_STRIDE;
+        unsigned RT_G *qc = RT_GPTR(unsigned, pl.q_count) + size_t(pk.qi) * RT_QC_STRIDE;
         const unsigned long long mc = __ballot(ln.has_ray && !ln.tv.any), ma = __ballot(ln.has_ray && ln.tv.any);
         unsigned wc = 0, wa = 0;
         __syncthreads();                                                // blk_cnt zeroed
@@ -243,10 +224,9 @@ __global__ __launch_bounds__(RT_BLOCK) void pipe_shade_kernel(const DevScene *__
         wc = __shfl(wc, 0) + blk_base[0]; wa = __shfl(wa, 0) + blk_base[1];
         if (ln.has_ray) {
             const unsigned long long below = (1ull << lane) - 1ull;
-            const size_t q = ln.tv.any ? size_t(pl.n_slots) + wa + __popcll(ma & below) : size_t(wc) + __popcll(mc & below);
+            const size_t q = size_t(pk.q_base) + (ln.tv.any ? size_t(pl.n_slots) + wa + __popcll(ma & below) : size_t(wc) + __popcll(mc & below));
             const float4 ro = make_float4(ln.tv.o.x, ln.tv.o.y, ln.tv.o.z, ln.tv.mint), rd = make_float4(ln.tv.d.x, ln.tv.d.y, ln.tv.d.z, ln.tv.maxt);
             RT_GPTR(float4, pl.q_o)[q] = ro; RT_GPTR(float4, pl.q_d)[q] = rd; RT_GPTR(unsigned, pl.q_slot)[q] = slot;
-            if (pl.q_key) RT_GPTR(unsigned, pl.q_key)[q] = ray_sort_key(sc, ln.tv.o, ln.tv.d, ln.tv.mint, ln.tv.any);
             RT_GPTR(float4, pl.ray_o)[slot] = ro; RT_GPTR(float4, pl.ray_d)[slot] = rd;
         }
     }
@@ -269,7 +249,7 @@ struct TraceJob {
     const unsigned *q_slot;
     int by_slot;                   // rt_pipe_vertex.h: q_slot holds slot | kind << 30; q_o = ray origins [slot], q_d = directions [kind][slot],
                                    // hit = [kind][slot]; kind 0 is an any-hit ray
-    const unsigned *perm;          // sorted queue (rt_sort.hip): entry i of the trace order -> position in q_o / q_d / q_slot; null = identity
+    unsigned q_base;               // where this launch's part of the queue arrays starts (the pool's halves have their own queue regions)
     unsigned *q_count;             // this iteration's counters: n closest at +0, head at +RT_QC_HEAD, n any at +RT_QC_ANY
     float4 *hit;                   // [slot]; for rt_trace_* (q_slot == nullptr) indexed by queue position
     unsigned n_slots;
@@ -292,6 +272,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) void pipe_trace_kernel(co
     unsigned w_next = 0, w_end = 0;                                     // this wave's chunk of the queue (wave-uniform)
     bool head_done = false;                                             // the global head has passed the end of the queue
     const unsigned n_waves = gridDim.x * (RT_BLOCK / 64);
+    const unsigned home = blockIdx.x % RT_TRACE_RANGES;                 // the queue range this wave draws from first: its XCD's
+    unsigned r_shift = 0, r_seen = 0;                                   // ranges given up so far; the current range's head as last seen
     // Outer loop: report finished rays, refill the idle lanes from the queue (one wave-aggregated atomic).  Inner loop: rounds of
     // traversal with nothing else in it, until enough lanes have finished for a refill to pay (or, once the queue is exhausted,
     // until the wave's last ray ends).
@@ -311,16 +293,26 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) void pipe_trace_kernel(co
             const unsigned have = w_end - w_next;                       // w_end never exceeds total
             unsigned f_lo = 0, f_hi = 0;                                 // the fresh chunk, clipped to the queue
             if (have < n_idle && !head_done) {                          // wave-uniform branch
-                const unsigned left = total - w_end;                    // w_end: the head as this wave last saw it
-                unsigned want = left / (2u * n_waves);
-                want = want < RT_TRACE_CHUNK_MIN ? RT_TRACE_CHUNK_MIN : (want > RT_TRACE_CHUNK_MAX ? RT_TRACE_CHUNK_MAX : want);
-                want = want < n_idle - have ? n_idle - have : want;
+                // The queue is cut into RT_TRACE_RANGES contiguous ranges, each with its own head; a wave draws from the range of ITS XCD
+                // (workgroup i runs on XCD i mod 8) and moves on to the next range when that one is empty.  Neighbours in the queue are
+                // neighbours on the film and, for the first bounces, in the scene: kept on one XCD they share that XCD's L2 instead of
+                // being fetched into all eight (the L2s are private; a line two XCDs need is two misses).
                 const int leader = __ffsll((long long)idle) - 1;
-                unsigned base = 0;
-                if (lane == leader) base = atomicAdd(job.q_count + RT_QC_HEAD, want);
-                base = __builtin_amdgcn_readfirstlane(__shfl(base, leader));
-                head_done = base + want >= total;
-                f_lo = base < total ? base : total; f_hi = base + want < total ? base + want : total;
+#pragma unroll 1
+                while (!head_done) {
+                    const unsigned r = (home + r_shift) % RT_TRACE_RANGES;
+                    const unsigned lo = unsigned((unsigned long long)total * r / RT_TRACE_RANGES), hi = unsigned((unsigned long long)total * (r + 1u) / RT_TRACE_RANGES);
+                    const unsigned left = hi - lo > r_seen ? hi - lo - r_seen : 0u;     // r_seen: this range's head as this wave last saw it
+                    unsigned want = left / (2u * n_waves / RT_TRACE_RANGES + 1u);
+                    want = want < RT_TRACE_CHUNK_MIN ? RT_TRACE_CHUNK_MIN : (want > RT_TRACE_CHUNK_MAX ? RT_TRACE_CHUNK_MAX : want);
+                    want = want < n_idle - have ? n_idle - have : want;
+                    unsigned base = 0;
+                    if (lane == leader) base = atomicAdd(job.q_count + RT_QC_HEAD + r, want);
+                    base = __builtin_amdgcn_readfirstlane(__shfl(base, leader));
+                    if (base < hi - lo) { f_lo = lo + base; f_hi = lo + base + want < hi ? lo + base + want : hi; r_seen = base + want; break; }
+                    ++r_shift; r_seen = 0u;
+                    head_done = r_shift >= RT_TRACE_RANGES;
+                }
             }
             const unsigned rk = unsigned(__popcll(idle & ((1ull << lane) - 1ull)));
             const unsigned fi = f_lo + (rk - have);
@@ -333,10 +325,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) void pipe_trace_kernel(co
             exhausted = head_done && w_next >= w_end;
             if (!busy && i < total) {
                 bool any = i >= n_closest;
-                size_t q = job.perm ? size_t(RT_GPTR(const unsigned, job.perm)[i]) : (any ? size_t(job.n_slots) + (i - n_closest) : size_t(i));
+                size_t q = any ? size_t(job.n_slots) + job.q_base + (i - n_closest) : size_t(job.q_base) + i;
                 size_t qo = q;
                 if (job.by_slot) {                                      // wave-uniform
-                    const unsigned e = RT_GPTR(const unsigned, job.q_slot)[i];
+                    const unsigned e = RT_GPTR(const unsigned, job.q_slot)[size_t(job.q_base) + i];
                     qo = e & 0x3fffffffu; q = size_t(e >> 30) * job.n_slots + qo; any = (e >> 30) == 0u;
                 }
                 const float4 ro = RT_GPTR(const float4, job.q_o)[qo], rd = RT_GPTR(const float4, job.q_d)[q];
@@ -367,7 +359,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) void pipe_trace_kernel(co
     }
 }
 
-typedef void (*PipeShadeFn)(const DevScene *, const DevFrame *, const PipePool *, unsigned);
+typedef void (*PipeShadeFn)(const DevScene *, const DevFrame *, const PipePool *, PipeLaunch);
 typedef void (*PipeTraceFn)(const DevScene *, TraceJob);
 
 }  // namespace rt

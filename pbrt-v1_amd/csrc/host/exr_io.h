@@ -138,7 +138,14 @@ inline bool ReadRGBAImage(const std::string &name, ExrImage &img) {
         }
         p += size_t(sz);
     }
-    if (compression != 0 || chans != "ABGR" || !have_dw || !have_disp) return false;
+    if (compression != 0) {                                   // said out loud: this is the one foreign-file case a pbrt user will actually meet
+        static const char *const names[] = {"NO", "RLE", "ZIPS", "ZIP", "PIZ", "PXR24", "B44", "B44A", "DWAA", "DWAB"};
+        std::fprintf(stderr, "exr file \"%s\" uses %s compression: only uncompressed half RGBA scanline files (what this library's WriteRGBAImage "
+                             "produces) can be read; a file written by OpenEXR's RgbaOutputFile defaults to PIZ\n",
+                     name.c_str(), compression > 0 && compression < 10 ? names[compression] : "an unknown");
+        return false;
+    }
+    if (chans != "ABGR" || !have_dw || !have_disp) return false;
     const long long xr = (long long)dw[2] - dw[0] + 1, yr = (long long)dw[3] - dw[1] + 1;
     if (xr < 1 || yr < 1 || xr > 65536 || yr > 65536 || disp[2] < 0 || disp[3] < 0 || disp[2] >= 65536 || disp[3] >= 65536) return false;
     img.xRes = int(xr); img.yRes = int(yr); img.xOffset = dw[0]; img.yOffset = dw[1];

@@ -79,8 +79,12 @@ def test_timed_kernels_stay_inside_their_occupancy_step(pkg):
     the trace kernel of the queue pipeline runs 6 waves per SIMD (its 24 KB of LDS stack planes per workgroup set that), i.e. <= 80 VGPRs.  The compiler's own resource report is kept at build time
     (pbrt-v1_amd/lib/obj/*.resources.txt)."""
     import re
+    pkg.build()                                   # incremental: a no-op when the objects are current, and then the reports are the ones of THESE objects
     def vgprs(unit, mangled_fragment):
-        text = open(os.path.join(pkg.LIB_DIR, "obj", unit + ".resources.txt")).read()
+        rep, obj = os.path.join(pkg.LIB_DIR, "obj", unit + ".resources.txt"), os.path.join(pkg.LIB_DIR, "obj", unit + ".o")
+        # the report is written by the very compiler invocation that writes the object (pkg.build), after it: never older than the object
+        assert os.path.exists(rep) and os.path.exists(obj) and os.path.getmtime(rep) >= os.path.getmtime(obj) - 1.0, "stale resource report for " + unit
+        text = open(rep).read()
         blocks = re.split(r"remark: Function Name: ", text)[1:]
         for b in blocks:
             if mangled_fragment in b.splitlines()[0]:
@@ -88,7 +92,13 @@ def test_timed_kernels_stay_inside_their_occupancy_step(pkg):
         raise AssertionError("kernel %s not in %s report" % (mangled_fragment, unit))
     v, spill = vgprs("rt_mega_p", "render_kernelILb0ELi2ELi0ELb0ELi1ELb0EE")      # path, kd-tree, no volume, natural allocation, no EXT
     assert v <= 168 and spill == 0, (v, spill)
+    v, spill = vgprs("rt_mega_d", "render_kernelILb0ELi1ELi0ELb0ELi3ELb0EE")      # directlighting, kd-tree: held to the 3-wave step (170 on its own)
+    assert v <= 168 and spill <= 8, (v, spill)
+    v, spill = vgprs("rt_mega_w", "render_kernelILb0ELi0ELi0ELb0ELi1ELb0EE")      # whitted
+    assert v <= 168 and spill == 0, (v, spill)
     v, spill = vgprs("rt_trace", "pipe_trace_kernelILb0ELi0ELb0EE")
     assert v <= 80 and spill == 0, (v, spill)
     v, spill = vgprs("rt_mega_p", "render_kernelILb0ELi2ELi0ELb0ELi4ELb0EE")      # the 4-waves flavour is capped at 128
     assert v <= 128, v
+    v, spill = vgprs("rt_pipe_v", "pipe_vertex_kernelILb0ELb0EE")                 # the by-vertex shade pass of the path pipeline: 3 waves
+    assert v <= 168 and spill == 0, (v, spill)

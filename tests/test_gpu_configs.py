@@ -121,13 +121,13 @@ def test_1m_trace_bit_exact_with_identical_work_counters(pkg, oracle, soup1m):
     assert np.array_equal(occ, refo)
     for k in ("nodes_visited", "leaf_refs", "tri_tests"):
         assert dc[k] == oc[k], (k, dc[k], oc[k])
-    # a depth-34 tree overflows the LDS ring: the spill path is exercised in earnest here
-    assert dc["stack_overflows"] > 0 or ds.counters()["nodes_visited"] > 0
+    # a depth-34 tree overflows the trace kernel's 8-entry LDS ring: the spill path to HBM is exercised in earnest here
+    assert dc["stack_overflows"] > 0, dc
 
 
 def test_pair_record_order_never_changes_a_result(pkg, scenes, monkeypatch):
     """The sibling-pair records of the kd-tree are addressed by absolute index, so their order in HBM (depth-first, breadth-first
-    treelets of 4 / 8 / 32 records, with or without line-aligned padding) is a pure layout choice: hits, barycentrics and the work
+    treelets of 4 / 8 / 32 records, with or without line-aligned padding, or the owner blocks {P, below(P), above(P)} of the two-level step) is a pure layout choice: hits, barycentrics and the work
     counters of closest-hit and any-hit rays must be bit-identical for every order (and the default order is pinned against the
     oracle by the tests above)."""
     need_gpu(pkg)
@@ -140,7 +140,8 @@ def test_pair_record_order_never_changes_a_result(pkg, scenes, monkeypatch):
     rays["d"] = d.astype(np.float32); rays["mint"] = 1e-3; rays["maxt"] = np.inf
     seg = rays.copy(); seg["maxt"] = rng.uniform(50, 600, n).astype(np.float32)
     results = []
-    for pairs, align in ((1, 0), (4, 0), (8, 1), (8, 0), (32, 1)):
+    for blocks, pairs, align in ((0, 1, 0), (1, 8, 1), (0, 4, 0), (0, 8, 1), (0, 8, 0), (0, 32, 1)):       # blocks = 1: the owner-block layout of the two-level step (the default)
+        monkeypatch.setenv("PBRT_HIP_PAIR_BLOCKS", str(blocks))
         monkeypatch.setenv("PBRT_HIP_TREELET_PAIRS", str(pairs)); monkeypatch.setenv("PBRT_HIP_TREELET_ALIGN", str(align))
         ps = pkg.ParsedScene(text=text)
         ds = pkg.DeviceScene(ps)
@@ -180,6 +181,85 @@ def test_1m_direct_lighting_frame_against_the_oracle(pkg, oracle, soup1m, monkey
         for k in env:
             monkeypatch.delenv(k)
     ds.set_counting(True)
+
+
+def test_1m_path_frame_against_the_oracle(pkg, scenes, oracle):
+    """The north star's case at a frame the oracle finishes in seconds: PathIntegrator depth 5 on the full 36 M-node tree (64x36 @ 4).
+    Counting twin against the oracle (the path bar: >= 99.5 % of pixels with L2 < 1e-4; ray counts within 5e-4), then every timed
+    flavour -- the queue pipeline by vertex (the default at this size) and per ray, the megakernel at 3 and 4 waves per SIMD --
+    bit-identical to the twin."""
+    need_gpu(pkg)
+    ps = pkg.ParsedScene(text=scenes.cornell_scene(xres=64, yres=36, integrator="path", maxdepth=5, xsamples=2, ysamples=2, jitter=True,
+                                                   pixel_filter="mitchell", soup_tris=1_000_000, keyed=True))
+    assert ps.valid and ps.errors == 0 and ps.n_tris == 1_000_012
+    ds = pkg.DeviceScene(ps)
+    ds.render()
+    assert ds.last_stats()["pipeline"] == 1                      # the counting twin of the by-vertex pipeline
+    rgb, alpha = ds.film(); acc = ds.film_accum(); cnt = ds.counters()
+    nodes, refs, bounds, info = accel_of(ds)
+    orgb, oalpha, _, ocnt = oracle.render(ps, nodes, refs, bounds, info=info)
+    m = check_film("p1m_path", rgb, alpha, orgb, oalpha, ps.integrator)
+    record_case("p1m:path", m)
+    assert m["frac"] >= 0.995, m
+    assert cnt["camera_rays"] == ocnt["camera_rays"] and cnt["bad_samples"] == 0
+    for k in ("closest_rays", "any_rays", "nodes_visited", "tri_tests"):
+        assert abs(cnt[k] - ocnt[k]) <= 5e-4 * ocnt[k] + 8, (k, cnt[k], ocnt[k])
+    for env in (dict(PBRT_HIP_PIPELINE="1"), dict(PBRT_HIP_PIPELINE="1", PBRT_HIP_PIPE_VERTEX="0"), dict(PBRT_HIP_PIPELINE="1", PBRT_HIP_PIPE_SLOTS="1024"),
+                dict(PBRT_HIP_PIPELINE="0", PBRT_HIP_HIGH_OCC="0"), dict(PBRT_HIP_PIPELINE="0", PBRT_HIP_HIGH_OCC="1")):
+        with pytest.MonkeyPatch.context() as mp:
+            for k, v in env.items():
+                mp.setenv(k, v)
+            ds.set_counting(False); ds.clear_film(); ds.render()
+            assert np.array_equal(ds.film_accum(), acc), env
+    # the counting twin of the megakernel sees the same rays and does the same traversal work
+    with pytest.MonkeyPatch.context() as mp:
+        mp.setenv("PBRT_HIP_PIPELINE", "0")
+        ds.set_counting(True); ds.reset_counters(); ds.clear_film(); ds.render()
+        c2 = ds.counters()
+        assert np.array_equal(ds.film_accum(), acc)
+        for k in ("camera_rays", "closest_rays", "any_rays", "nodes_visited", "leaf_refs", "tri_tests", "bad_samples"):
+            assert c2[k] == cnt[k], (k, c2[k], cnt[k])
+    ds.close()
+
+
+@pytest.mark.parametrize("name", ["p1m", "c4", "c5"])
+def test_pipeline_workloads_full_size_properties(pkg, scenes, name):
+    """The three pipeline workloads bench.py times, at the size it times them (1 M-triangle soup in the Cornell box, 1024x1024):
+    the path frame (depth 5, 16 spp), C4's material mix (path depth 8, 16 spp), C5's medium (single scattering, stepsize 20, g 0 +
+    DirectLighting; 16 of its 64 spp here).  No oracle at this size:
+      coverage     every camera sample rendered exactly once: box filter, unjittered strata -> weight spp on every interior pixel;
+      determinism  two renders of the counting twin give the bit-identical film and counters;
+      flavours     the timed pipeline (what bench.py times) and the timed megakernel give that same film;
+      sanity       no NaN / negative / infinite sample, alpha <= weight;
+      linearity    (path frame) doubling the emitter's L doubles every radiance accumulator and changes no ray count."""
+    need_gpu(pkg)
+    kw = dict(xres=1024, yres=1024, xsamples=4, ysamples=4, jitter=False, pixel_filter="box", soup_tris=1_000_000, keyed=True)
+    if name == "p1m": kw.update(integrator="path", maxdepth=5)
+    elif name == "c4": kw.update(integrator="path", maxdepth=8, soup_materials=True)
+    else: kw.update(integrator="directlighting", volume_integrator='"single" "float stepsize" [20]', world_kwargs=dict(volume='"float g" [0]'))
+    ps = pkg.ParsedScene(text=scenes.cornell_scene(**kw))
+    assert ps.valid and ps.errors == 0
+    ds = pkg.DeviceScene(ps); ds.render(); a = ds.film_accum(); ca = ds.counters(); st = ds.last_stats()
+    assert st["pipeline"] == 1
+    ds.reset_counters(); ds.clear_film(); ds.render(); a2 = ds.film_accum(); ca2 = ds.counters()
+    ds.set_counting(False); ds.clear_film(); ds.render(); a3 = ds.film_accum()       # the timed flavour the bench uses
+    with pytest.MonkeyPatch.context() as mp:
+        mp.setenv("PBRT_HIP_PIPELINE", "0")
+        ds.clear_film(); ds.render(); a4 = ds.film_accum()
+        assert ds.last_stats()["pipeline"] == 0
+    ds.close()
+    assert ca["camera_rays"] == 1025 * 1025 * 16 and ca["bad_samples"] == 0 and ca == ca2
+    assert np.array_equal(a, a2) and np.array_equal(a, a3) and np.array_equal(a, a4)
+    assert np.all(a[4][1:-1, 1:-1] == 16.0)
+    assert np.isfinite(a).all() and a[:3].min() >= 0 and np.all(a[3] <= a[4] + 1e-3)
+    assert ca["closest_rays"] >= ca["camera_rays"] and ca["any_rays"] > 0.2 * ca["camera_rays"]
+    if name == "p1m":
+        kw["world_kwargs"] = dict(light_L=(34, 24, 8))
+        ps2 = pkg.ParsedScene(text=scenes.cornell_scene(**kw))
+        ds2 = pkg.DeviceScene(ps2); ds2.render(); b = ds2.film_accum(); cb = ds2.counters(); ds2.close()
+        for k in COUNTERS:
+            assert cb[k] == ca[k], k
+        assert np.allclose(b[:3], 2 * a[:3], rtol=1e-5, atol=1e-5) and np.array_equal(b[4], a[4]) and np.array_equal(b[3], a[3])
 
 
 def test_c3_full_size_properties(pkg, scenes):
@@ -274,3 +354,27 @@ def test_crop_window_tiles_to_exr_and_assembled(pkg, scenes, tmp_path):
     assert np.array_equal(a_rgb, f_rgb) and np.array_equal(a_alpha, f_alpha)
     with np.errstate(over="ignore"):
         assert np.array_equal(f_rgb, rgb.astype(np.float16).astype(np.float32))
+
+
+def test_pipeline_pool_is_sized_by_a_memory_budget(pkg, scenes):
+    """The queue pipeline keeps its per-slot scratch (state planes, recursion frames, the ray march's LatinHypercube table: 3 floats per
+    march step) for every slot of the pool; a fine stepsize times 8 M slots would ask for ~100 GB.  The pool is cut to a memory budget
+    instead (rt_kernels.hip render_pipeline): same film, more iterations."""
+    need_gpu(pkg)
+    cfg = dict(xres=64, yres=64, integrator="directlighting", xsamples=2, ysamples=2, jitter=True, soup_tris=5000,
+               volume_integrator='"single" "float stepsize" [3]', world_kwargs=dict(volume='"float g" [.1]'))
+    ps = pkg.ParsedScene(text=scenes.cornell_scene(keyed=True, **cfg))
+    assert ps.valid and ps.errors == 0
+    ds = pkg.DeviceScene(ps)
+    with pytest.MonkeyPatch.context() as mp:
+        mp.setenv("PBRT_HIP_PIPELINE", "0")
+        ds.set_counting(False); ds.render(); ref = ds.film_accum()
+    with pytest.MonkeyPatch.context() as mp:
+        mp.setenv("PBRT_HIP_PIPELINE", "1")
+        ds.clear_film(); ds.render(); full = ds.film_accum(); st_full = ds.last_stats()
+        mp.setenv("PBRT_HIP_PIPE_MEM_MB", "4")          # ~4.5 KB per slot at ~340 march steps -> a pool of a few hundred slots
+        ds.clear_film(); ds.render(); small = ds.film_accum(); st_small = ds.last_stats()
+    ds.close()
+    assert st_full["pipeline"] == 1 and st_small["pipeline"] == 1
+    assert st_small["slots"] < st_full["slots"] and st_small["slots"] <= 2048 and st_small["iterations"] > st_full["iterations"]
+    assert np.array_equal(full, ref) and np.array_equal(small, ref)

@@ -177,3 +177,29 @@ def test_parallel_kd_build_equals_serial_and_the_reference_at_60k(pkg, scenes):
     ref_refs, ref_leaves = (stat_int(x)[0] for x in table["Avg. number of primitives in leaf nodes"].split(":"))
     assert abs(int(nprims.sum()) - ref_refs) <= 0.0006 * ref_refs + 50 and abs(int(leaf.sum()) - ref_leaves) <= 0.0006 * ref_leaves + 50
     assert int(nprims.max()) == int(table["Maximum number of primitives in leaf node"])
+
+
+def test_kd_build_equals_the_reference_at_1m(pkg, scenes):
+    """The tree the 1 M-triangle workloads are traced through is the reference's: KdTreeAccel's own StatsPrint on the Cornell box +
+    1 M-triangle soup (tests/golden/chain/kd_soup1m.npz, printed by the unmodified reference after its 90 s build; generator
+    tests/golden/make_kd_stats.py) against the parallel build of this library on the same primitives.  StatsPrint rounds to three
+    decimals of a million ('18.224M'), so counts are compared to +-600."""
+    import json, os
+    from conftest import ROOT
+    table = json.loads(str(np.load(os.path.join(ROOT, "tests", "golden", "chain", "kd_soup1m.npz"))["stats"]))
+    ps = pkg.ParsedScene(text=scenes.cornell_scene(xres=4, yres=4, integrator="whitted", soup_tris=1_000_000, world_kwargs=dict(point_light=True, area_light=False)))
+    assert ps.valid and ps.errors == 0
+    tv = np.ascontiguousarray(ps.tri_verts(), np.float32).reshape(-1, 9)
+    assert abs(len(tv) - stat_int(table["Triangles created"])[0]) <= 600
+    nodes, refs, bounds, info = pkg.build_kdtree(tv)
+    leaf = (nodes[:, 0] & 3) == 3
+    n_int, n_leaf = int((~leaf).sum()), int(leaf.sum())
+    assert n_leaf == n_int + 1
+    for key, mine in (("Interior kd-tree nodes made", n_int), ("Leaf kd-tree nodes made", n_leaf)):
+        ref, exact = stat_int(table[key])
+        assert not exact and abs(mine - ref) <= 600, (key, mine, table[key])
+    nprims = nodes[leaf, 0] >> 2
+    ref_refs, ref_leaves = (stat_int(x)[0] for x in table["Avg. number of primitives in leaf nodes"].split(":"))
+    assert abs(int(nprims.sum()) - ref_refs) <= 600 and abs(n_leaf - ref_leaves) <= 600, (int(nprims.sum()), n_leaf, table["Avg. number of primitives in leaf nodes"])
+    assert int(nprims.max()) == int(table["Maximum number of primitives in leaf node"])
+    assert info.max_depth >= 33

@@ -8,13 +8,9 @@ run() {  # tag, env...
 import json
 try:
     j = json.loads(open("$OUT/$tag.json").read().strip().splitlines()[-1]); r = j["roofline"]
-    print("$tag", j["value"], "Mrays/s", j["ms_per_step"], "ms/frame trace_ms", r["kernel_ms"], "render_ms", r["frame_kernels_ms"]["render"], "iters", r.get("pipeline_iterations"), "frac", r["frac"], "frac_frame", r["frac_frame_kernels"])
+    print("$tag", j["value"], "Mrays/s", j["ms_per_step"], "ms/frame trace_ms", r["kernel_ms"], "render_ms", r["frame_kernels_ms"]["render"], "gather", r["frame_kernels_ms"]["film_gather"], "iters", r.get("pipeline_iterations"), "frac", r["frac"], "frac_frame", r["frac_frame_kernels"])
 except Exception as e:
     print("$tag FAILED", e); print(open("$OUT/$tag.err").read()[-1500:])
 PY
 }
-run p1m
-WL=c4 run c4
-WL=c5 run c5
-WL=c5 run c5_mega PBRT_HIP_PIPELINE=0
-timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py -x -q -m gpu 2>&1 | tail -5
+for w in "$@"; do WL=$w run $w; done

@@ -1,4 +1,4 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r03
-timeout 2400 python -m pytest tests -q -m gpu -x 2>&1 | tail -8 | tee gpurun_out/r03/gputests.log
+timeout 3000 python -m pytest tests -q -m gpu -x --durations=12 "$@" 2>&1 | tail -40 | tee gpurun_out/r03/gputests.log
