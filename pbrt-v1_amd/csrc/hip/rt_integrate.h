@@ -664,6 +664,10 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
             if (COUNT) ++*c_any;
             i = __float_as_int(vs[0]); N = __float_as_int(vs[st]); t0 = vs[2 * st]; step = vs[3 * st];
             Tr = mk3(vs[4 * st], vs[5 * st], vs[6 * st]); p = mk3(vs[7 * st], vs[8 * st], vs[9 * st]); Lv = mk3(vs[10 * st], vs[11 * st], vs[12 * st]);
+#ifdef RT_DEBUG_PIXEL
+            if (int(floorf(ln.image_x)) == fr.dbg_x && int(floorf(ln.image_y)) == fr.dbg_y)
+                printf("VOL resume w %u i %d N %d hit %d pend %g %g %g Lv %g %g %g Tr %g %g %g L %g %g %g fsp %d\n", ln.work, i, N, ln.tv.hit_prim, ln.pend.x, ln.pend.y, ln.pend.z, Lv.x, Lv.y, Lv.z, Tr.x, Tr.y, Tr.z, ln.L.x, ln.L.y, ln.L.z, ln.fsp);
+#endif
             if (ln.tv.hit_prim < 0)                                                // vis.Unoccluded: Ld = L * vis.Transmittance(scene)
                 Lv = Lv + ln.pend * scene_transmittance<VOL>(sc, ln, ln.tv.o, ln.tv.d, ln.tv.mint, ln.tv.maxt);
             ++i; t0 += step;
@@ -709,6 +713,10 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
         }
         Lv = Lv * step;
         const V3 T = vol_transmittance(vol, ray.o, ray.d, ray.mint, ray.maxt);      // sample != NULL: no draw
+#ifdef RT_DEBUG_PIXEL
+        if (int(floorf(ln.image_x)) == fr.dbg_x && int(floorf(ln.image_y)) == fr.dbg_y)
+            printf("VOL end w %u N %d Lv %g %g %g T %g %g %g L %g %g %g fsp %d\n", ln.work, N, Lv.x, Lv.y, Lv.z, T.x, T.y, T.z, ln.L.x, ln.L.y, ln.L.z, ln.fsp);
+#endif
         ln.L = T * ln.L + Lv;
         ln.stage = ST_POP;
         return;

@@ -1102,8 +1102,10 @@ static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool nee
         // large trees (traversal bound by memory latency): the queue pipeline of rt_pipeline.h; tiny cache-resident ones: the megakernel
         // (measured on the 1 M-triangle frames, 1x MI355X: the pipeline's trace kernel is faster than the megakernel's traversal, but its
         // state traffic and sparse last iterations cost more than that gains, except where shading suspends often: volume marching)
-        // round 3: a path without a medium takes the by-vertex form (rt_pipe_vertex.h): 1 M-triangle frame 72 ms against the megakernel's 79
-        fr.pipeline = (!tiny && (s->volume.present || rd->integrator == RT_INTEGRATOR_PATH)) ? 1 : 0;
+        // round 3: a path without a medium can take the by-vertex form (rt_pipe_vertex.h: 1 M-triangle frame 69.9 ms); since the kernels are
+        // built without the SLP vectorizer the 4-wave megakernel no longer spills and is as fast there (69.3 ms) and faster on C4's
+        // material mix (71.3 vs 76.3 ms), so it stays the default for frames without a medium
+        fr.pipeline = (!tiny && s->volume.present) ? 1 : 0;
         if (const char *e = std::getenv("PBRT_HIP_PIPELINE")) fr.pipeline = std::atoi(e) != 0;
         if (fr.max_depth > 250 || fr.max_depth < 0) fr.pipeline = 0;     // the slot's control word holds depth in 8 bits
         for (int i = 0; i < fr.n2d; ++i) if (fr.two_d[i].n >= 65535) fr.pipeline = 0;         // ... and the light / sample cursors in 16 bits each

@@ -193,7 +193,9 @@ def test_1m_path_frame_against_the_oracle(pkg, scenes, oracle):
                                                    pixel_filter="mitchell", soup_tris=1_000_000, keyed=True))
     assert ps.valid and ps.errors == 0 and ps.n_tris == 1_000_012
     ds = pkg.DeviceScene(ps)
-    ds.render()
+    with pytest.MonkeyPatch.context() as mp:
+        mp.setenv("PBRT_HIP_PIPELINE", "1")
+        ds.render()
     assert ds.last_stats()["pipeline"] == 1                      # the counting twin of the by-vertex pipeline
     rgb, alpha = ds.film(); acc = ds.film_accum(); cnt = ds.counters()
     nodes, refs, bounds, info = accel_of(ds)
@@ -239,13 +241,16 @@ def test_pipeline_workloads_full_size_properties(pkg, scenes, name):
     else: kw.update(integrator="directlighting", volume_integrator='"single" "float stepsize" [20]', world_kwargs=dict(volume='"float g" [0]'))
     ps = pkg.ParsedScene(text=scenes.cornell_scene(**kw))
     assert ps.valid and ps.errors == 0
-    ds = pkg.DeviceScene(ps); ds.render(); a = ds.film_accum(); ca = ds.counters(); st = ds.last_stats()
-    assert st["pipeline"] == 1
-    ds.reset_counters(); ds.clear_film(); ds.render(); a2 = ds.film_accum(); ca2 = ds.counters()
-    ds.set_counting(False); ds.clear_film(); ds.render(); a3 = ds.film_accum()       # the timed flavour the bench uses
+    ds = pkg.DeviceScene(ps)
+    with pytest.MonkeyPatch.context() as mp:
+        mp.setenv("PBRT_HIP_PIPELINE", "1")
+        ds.render(); a = ds.film_accum(); ca = ds.counters(); st = ds.last_stats()
+        assert st["pipeline"] == 1
+        ds.reset_counters(); ds.clear_film(); ds.render(); a2 = ds.film_accum(); ca2 = ds.counters()
+        ds.set_counting(False); ds.clear_film(); ds.render(); a3 = ds.film_accum()       # the timed pipeline
     with pytest.MonkeyPatch.context() as mp:
         mp.setenv("PBRT_HIP_PIPELINE", "0")
-        ds.clear_film(); ds.render(); a4 = ds.film_accum()
+        ds.clear_film(); ds.render(); a4 = ds.film_accum()                               # the timed megakernel
         assert ds.last_stats()["pipeline"] == 0
     ds.close()
     assert ca["camera_rays"] == 1025 * 1025 * 16 and ca["bad_samples"] == 0 and ca == ca2

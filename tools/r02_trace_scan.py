@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 HIP = os.path.join(ROOT, "pbrt-v1_amd", "csrc", "hip")
 LIBD = os.path.join(ROOT, "pbrt-v1_amd", "lib")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-value"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-Wno-unused-value"]
 UNITS = ("rt_kernels", "rt_trace", "rt_mega_w", "rt_mega_d", "rt_mega_p", "rt_pipe_w", "rt_pipe_d", "rt_pipe_p", "kd_build", "grid_build")
 
 
