@@ -130,22 +130,81 @@ def run_workload(name, args, pkg, torch, dist, world, rank, device_index, steps,
     if not ps.valid or ps.errors:
         raise SystemExit("bench.py: the workload's scene description did not parse cleanly (%d errors): refusing to time a different scene" % ps.errors)
     emu = int(os.environ.get("PBRT_BENCH_EMULATE_WORLD", "0"))      # debugging aid: time rank 0's share of an N-rank job on one GPU
-    ps.set_shard(rank, emu if (emu > 1 and world == 1) else world, args.tile_pixels)
-    ds = pkg.DeviceScene(ps, device=device_index)
+    tiles = (args.tile_2d, args.tile_2d) if args.tile_2d > 0 else args.tile_pixels
+    ps.set_shard(rank, emu if (emu > 1 and world == 1) else world, tiles)
+    # One accelerator build per node, not per rank: local rank 0 builds (all host cores: 10 M triangles take 15 s) and publishes the
+    # flattened tree under /dev/shm; the other ranks map it (rt_scene_create_prebuilt).  Reference: every cropwindow process builds its own.
+    shared = None
+    if dist is not None and not os.environ.get("PBRT_BENCH_NO_SHARED_ACCEL"):
+        shm = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+        shared = os.path.join(shm, "pbrt_hip_accel_%s_%s.bin" % (os.environ.get("MASTER_PORT", "0"), name))
+    t_create = time.perf_counter()
+    if shared is None:
+        ds = pkg.DeviceScene(ps, device=device_index)
+    else:
+        local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+        if local_rank == 0:
+            ds = pkg.DeviceScene(ps, device=device_index)
+            pkg.publish_accel(ds, shared)
+        dist.barrier()
+        if local_rank != 0:
+            ds = pkg.DeviceScene(ps, device=device_index, prebuilt=pkg.attach_accel(shared))
+        dist.barrier()
+        if local_rank == 0:
+            os.remove(shared)
+    t_create = time.perf_counter() - t_create
     info = ds.accel_info()
     film = torch.zeros((5, ps.height, ps.width), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream()
     ds.set_stream(stream.cuda_stream)
     ds.bind_film(film.data_ptr())
     # the host side of the boundary: the resolved film lands in page-locked buffers that are reused every frame
-    host_rgb = torch.empty((ps.height, ps.width, 3), dtype=torch.float32, pin_memory=True).numpy() if rank == 0 else None
-    host_alpha = torch.empty((ps.height, ps.width), dtype=torch.float32, pin_memory=True).numpy() if rank == 0 else None
+    host_rgb_t = torch.empty((ps.height, ps.width, 3), dtype=torch.float32, pin_memory=True) if rank == 0 else None
+    host_alpha_t = torch.empty((ps.height, ps.width), dtype=torch.float32, pin_memory=True) if rank == 0 else None
+    host_rgb = host_rgb_t.numpy() if rank == 0 else None
+    host_alpha = host_alpha_t.numpy() if rank == 0 else None
+
+    # N > 1: how the partial films meet (film/image.cpp:220-228 + tools/exrassemble.cpp:42-133 in the reference).
+    #   allreduce       one all-reduce(sum) of the 5 planes, rank 0 resolves the whole film;
+    #   reduce_scatter  (default) row-wise reduce-scatter per plane, every rank resolves ITS rows (rt_film_resolve_device), one all-gather of
+    #                   the resolved rows (4 floats per pixel instead of 5, 1/N of the normalisation per rank).
+    merge = args.merge if dist is not None else "none"
+    H, W = ps.height, ps.width
+    if merge == "reduce_scatter":
+        rows = (H + world - 1) // world
+        pad = torch.zeros((5, rows * world, W), dtype=torch.float32, device="cuda")
+        part = torch.zeros((5, rows, W), dtype=torch.float32, device="cuda")
+        rgb_part = torch.zeros((rows, W, 3), dtype=torch.float32, device="cuda"); alpha_part = torch.zeros((rows, W), dtype=torch.float32, device="cuda")
+        rgb_all = torch.zeros((rows * world, W, 3), dtype=torch.float32, device="cuda"); alpha_all = torch.zeros((rows * world, W), dtype=torch.float32, device="cuda")
+    host_backend = dist is not None and dist.get_backend() != "nccl"      # the 2-ranks-on-one-GPU test harness: collectives through the host
 
     def step():
         film.zero_()
         ds.render(sync=False)
-        if dist is not None:
+        if merge == "allreduce":
             dist.all_reduce(film, op=dist.ReduceOp.SUM)
+        elif merge == "reduce_scatter":
+            pad[:, :H].copy_(film)
+            if host_backend:
+                hp, ho = pad.cpu(), torch.zeros((5, rows, W))
+                for k in range(5):
+                    dist.reduce_scatter_tensor(ho[k], hp[k])
+                part.copy_(ho)
+            else:
+                for k in range(5):
+                    dist.reduce_scatter_tensor(part[k], pad[k])
+            ds.resolve_device(part.data_ptr(), rows * W, rgb_part.data_ptr(), alpha_part.data_ptr())
+            if host_backend:
+                hr, ha = torch.zeros((rows * world, W, 3)), torch.zeros((rows * world, W))
+                dist.all_gather_into_tensor(hr, rgb_part.cpu()); dist.all_gather_into_tensor(ha, alpha_part.cpu())
+                rgb_all.copy_(hr); alpha_all.copy_(ha)
+            else:
+                dist.all_gather_into_tensor(rgb_all, rgb_part); dist.all_gather_into_tensor(alpha_all, alpha_part)
+            if rank == 0:
+                host_rgb_t.copy_(rgb_all[:H], non_blocking=True); host_alpha_t.copy_(alpha_all[:H], non_blocking=True)
+                torch.cuda.synchronize()
+                return host_rgb, host_alpha
+            return None
         if rank == 0:
             return ds.film(out=(host_rgb, host_alpha))          # ImageFilm::WriteImage normalisation (synchronises)
         return None
@@ -212,7 +271,10 @@ def run_workload(name, args, pkg, torch, dist, world, rank, device_index, steps,
             "config": {"workload": label, "camera_samples_per_frame": int(cam_total), "rays_per_frame": int(rays_total),
                        "rays_per_camera_sample": round(rays_total / max(cam_total, 1), 3),
                        "kd_nodes": int(info.n_nodes), "kd_build_s": round(info.build_seconds, 4),
-                       "parallelism": "tiles of %d pixels dealt round-robin to %d rank(s); RCCL all-reduce(sum) of the 5-plane film" % (args.tile_pixels, world),
+                       "parallelism": "%s dealt round-robin to %d rank(s); %s; accelerator built once per node (%.2f s scene create on rank 0)"
+                                      % ("2-D tiles of %dx%d pixels" % (args.tile_2d, args.tile_2d) if args.tile_2d > 0 else "tiles of %d consecutive pixels" % args.tile_pixels, world,
+                                         {"allreduce": "RCCL all-reduce(sum) of the 5-plane film, rank 0 resolves", "reduce_scatter": "RCCL reduce-scatter of film rows, per-rank resolve, all-gather of the resolved rows",
+                                          "none": "single rank"}[merge], t_create),
                        "rng": "counter-based keyed RNG, seed 0"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 5), "traffic": None,
@@ -296,6 +358,11 @@ def main():
     # same columns for ~16 consecutive rows and whole 16x16 film-gather blocks fall to a single rank (measured at 8 ranks:
     # rank share 10.06 ms with 64, 9.61 ms with 48)
     ap.add_argument("--tile-pixels", type=int, default=48)
+    # 2-D tiles of T x T pixels (multiples of the film gather's 16x16 blocks): a rank's samples fall on compact pieces of the film, so its
+    # gather touches the blocks around them only; 0 = the 1-D tiles above
+    ap.add_argument("--tile-2d", type=int, default=64)
+    ap.add_argument("--merge", choices=["allreduce", "reduce_scatter"], default="reduce_scatter")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even for one rank: exercises the N > 1 code path on a single GPU")
     args = ap.parse_args()
 
     import torch
@@ -315,13 +382,27 @@ def main():
     device_index = 0 if os.environ.get("PBRT_BENCH_SAME_GPU") else local_rank
     torch.cuda.set_device(device_index)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
+        import datetime
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        if torch.cuda.device_count() <= device_index:
+            raise SystemExit("bench.py: rank %d wants GPU %d but only %d are visible (one process per GPU: launch with --nproc-per-node <= #GPUs)"
+                             % (rank, device_index, torch.cuda.device_count()))
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index),
+                                        timeout=datetime.timedelta(seconds=300))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+            probe = torch.ones(8, device="cuda")                     # first collective: communicator set-up errors surface here, not mid-frame
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            if int(probe[0].item()) != world:
+                raise RuntimeError("all_reduce probe returned %r for world size %d" % (probe[0].item(), world))
+        except Exception as e:
+            raise SystemExit("bench.py: torch.distributed (%s) set-up failed on rank %d / %d, MASTER %s:%s: %s: %s" % (
+                backend, rank, world, os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"), type(e).__name__, e))
 
     out = run_workload(args.workload, args, pkg, torch, dist, world, rank, device_index, args.steps, args.warmup,
                        with_cpu=not args.no_cpu_baseline, dump_film=args.dump_film)

@@ -174,7 +174,10 @@ typedef struct RtRenderDesc {
     float filter_table[256];  /* 16x16, image.cpp:89-101                                   */
     /* Work partition (reference: cropwindow processes, image.cpp:220-228): pixels of the
      * sample extent, in scanline order, are grouped into tiles of tile_pixels consecutive
-     * pixels; this call renders tiles t with t % shard_count == shard_index. */
+     * pixels; this call renders tiles t with t % shard_count == shard_index.
+     * tile_pixels < 0 selects 2-D tiles: -tile_pixels = tile_w | tile_h << 16, blocks of tile_w x tile_h pixels of the sample extent
+     * numbered row by row (border blocks are clipped).  A rank then owns compact pieces of the film: its film gather touches only the
+     * blocks around them, and the partial films can be merged row-wise (bench.py: reduce-scatter + per-rank resolve). */
     int32_t shard_index, shard_count, tile_pixels;
 } RtRenderDesc;
 
@@ -207,6 +210,18 @@ int rt_device_count(int *count);
 /* Build accelerator (KdTreeAccel ctor kdtree.cpp:141-190 / GridAccel ctor grid.cpp:122-210),
  * upload everything.  device < 0 = current device. */
 int rt_scene_create(const RtSceneDesc *desc, int device, RtScene **out);
+/* The same with an accelerator built elsewhere -- by rt_accel_build, or copied out of another process' scene (rt_scene_accel_info /
+ * rt_scene_accel_copy): the ranks of one node build the tree once (reference: every cropwindow process of image.cpp:220-228 builds its
+ * own, kdtree.cpp:141-312).  Arrays as rt_accel_copy writes them; they are checked (every index in range) and copied. */
+typedef struct RtPrebuiltAccel {
+    int32_t kind;                       /* RT_ACCEL_KDTREE / RT_ACCEL_GRID, must equal desc->accel.kind */
+    uint32_t n_nodes, n_leaf_refs, max_depth;
+    const uint32_t *nodes;              /* [n_nodes][2] */
+    const uint32_t *leaf_refs;          /* [n_leaf_refs] */
+    float bounds[6];
+    int32_t grid_nvoxels[3]; float grid_width[3], grid_inv_width[3];   /* grid only (RtAccelInfo) */
+} RtPrebuiltAccel;
+int rt_scene_create_prebuilt(const RtSceneDesc *desc, int device, const RtPrebuiltAccel *accel, RtScene **out);
 int rt_scene_destroy(RtScene *s);
 int rt_scene_set_stream(RtScene *s, void *hip_stream);
 int rt_scene_accel_info(const RtScene *s, RtAccelInfo *info);
@@ -275,6 +290,9 @@ typedef struct RtRenderStats {
     uint32_t slots;
     float shade_ms;            /* queue pipeline: the shade launches summed (they overlap the trace launches when the pool runs as two halves) */
 } RtRenderStats;
+/* ImageFilm::WriteImage's normalisation (image.cpp:157-203) of ANY 5-plane accumulator in device memory (planes of n floats each), e.g. the
+ * rows of the film a rank owns after a reduce-scatter; rgb[n][3] and alpha[n] stay on the device.  Asynchronous on the scene's stream. */
+int rt_film_resolve_device(RtScene *s, const float *dev_accum, uint64_t n, int premultiply, float *dev_rgb, float *dev_alpha);
 int rt_last_render_stats(RtScene *s, RtRenderStats *out);
 
 #ifdef __cplusplus

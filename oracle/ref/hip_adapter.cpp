@@ -62,9 +62,42 @@
 #define CreateMaterial CreateMaterial_plastic_
 #include "materials/plastic.cpp"
 #undef CreateMaterial
+#define CreateMaterial CreateMaterial_uber_
+#include "materials/uber.cpp"
+#undef CreateMaterial
+#define CreateShape CreateShape_sphere_
+#include "shapes/sphere.cpp"
+#undef CreateShape
+#define CreateShape CreateShape_disk_
+#include "shapes/disk.cpp"
+#undef CreateShape
+#define CreateShape CreateShape_cylinder_
+#include "shapes/cylinder.cpp"
+#undef CreateShape
+#define CreateShape CreateShape_cone_
+#include "shapes/cone.cpp"
+#undef CreateShape
+#define CreateShape CreateShape_paraboloid_
+#include "shapes/paraboloid.cpp"
+#undef CreateShape
+#define CreateShape CreateShape_hyperboloid_
+#include "shapes/hyperboloid.cpp"
+#undef CreateShape
 #define CreateLight CreateLight_point_
 #include "lights/point.cpp"
 #undef CreateLight
+#define CreateLight CreateLight_spot_
+#include "lights/spot.cpp"
+#undef CreateLight
+#define CreateLight CreateLight_distant_
+#include "lights/distant.cpp"
+#undef CreateLight
+#define CreateCamera CreateCamera_orthographic_
+#include "cameras/orthographic.cpp"
+#undef CreateCamera
+#define CreateCamera CreateCamera_environment_
+#include "cameras/environment.cpp"
+#undef CreateCamera
 #define CreateCamera CreateCamera_perspective_
 #include "cameras/perspective.cpp"
 #undef CreateCamera
@@ -113,7 +146,7 @@ RtAccelParams g_accel;
 struct Flat {
     std::vector<float> tri_verts; std::vector<uint16_t> tri_material; std::vector<int32_t> tri_light; std::vector<uint8_t> tri_flags;
     std::vector<RtMaterial> materials; std::vector<RtLight> lights; std::vector<float> light_tris;
-    std::vector<int32_t> tri_shading; std::vector<RtTriShading> shading; std::vector<float> xforms;
+    std::vector<int32_t> tri_shading; std::vector<RtTriShading> shading; std::vector<float> xforms; std::vector<RtQuadric> quadrics;
     RtSceneDesc scene; RtRenderDesc render;
 };
 
@@ -136,15 +169,60 @@ RtMaterial flatten_material(const Material *m) {
     } else if (type_is(ti, "Glass")) {                                       // glass.cpp:46-63
         const Glass *x = static_cast<const Glass *>(m);
         spec3(x->Kr->Evaluate(dg).Clamp(), o.kd); spec3(x->Kt->Evaluate(dg).Clamp(), o.kt); o.ior = x->index->Evaluate(dg); o.type = RT_MAT_GLASS;
+    } else if (type_is(ti, "UberMaterial")) {                                // uber.cpp:52-89: op = opacity.Clamp(); T = -op + 1, D = op * Kd.Clamp(), G = op * Ks.Clamp(), R = op * Kr.Clamp()
+        const UberMaterial *x = static_cast<const UberMaterial *>(m);
+        const Spectrum op = x->opacity->Evaluate(dg).Clamp();
+        spec3(-op + Spectrum(1.), o.kt); spec3(op * x->Kd->Evaluate(dg).Clamp(), o.kd); spec3(op * x->Ks->Evaluate(dg).Clamp(), o.ks); spec3(op * x->Kr->Evaluate(dg).Clamp(), o.kr);
+        o.roughness = x->roughness->Evaluate(dg); o.type = RT_MAT_UBER; o.ior = 1.f;
     } else die(ti.name());
     return o;
+}
+
+void put_m(const Reference<Matrix4x4> &m, float *out);
+// a quadric (shapes/{sphere,disk,cylinder,cone,paraboloid,hyperboloid}.cpp) as the constructors left it; false for any other shape
+bool flatten_quadric(const Shape *sh, RtQuadric &q) {
+    memset(&q, 0, sizeof q);
+    const std::type_info &ti = typeid(*sh);
+    if (type_is(ti, "Sphere")) {
+        const Sphere *x = static_cast<const Sphere *>(sh);
+        q.type = RT_QUADRIC_SPHERE; q.radius = x->radius; q.zmin = x->zmin; q.zmax = x->zmax; q.theta_min = x->thetaMin; q.theta_max = x->thetaMax; q.phi_max = x->phiMax;
+    } else if (type_is(ti, "Disk")) {
+        const Disk *x = static_cast<const Disk *>(sh);
+        q.type = RT_QUADRIC_DISK; q.radius = x->radius; q.zmin = x->height; q.zmax = x->innerRadius; q.phi_max = x->phiMax;
+    } else if (type_is(ti, "Cylinder")) {
+        const Cylinder *x = static_cast<const Cylinder *>(sh);
+        q.type = RT_QUADRIC_CYLINDER; q.radius = x->radius; q.zmin = x->zmin; q.zmax = x->zmax; q.phi_max = x->phiMax;
+    } else if (type_is(ti, "Cone")) {
+        const Cone *x = static_cast<const Cone *>(sh);
+        q.type = RT_QUADRIC_CONE; q.radius = x->radius; q.zmin = 0.f; q.zmax = x->height; q.phi_max = x->phiMax;
+    } else if (type_is(ti, "Paraboloid")) {
+        const Paraboloid *x = static_cast<const Paraboloid *>(sh);
+        q.type = RT_QUADRIC_PARABOLOID; q.radius = x->radius; q.zmin = x->zmin; q.zmax = x->zmax; q.phi_max = x->phiMax;
+    } else if (type_is(ti, "Hyperboloid")) {
+        const Hyperboloid *x = static_cast<const Hyperboloid *>(sh);
+        q.type = RT_QUADRIC_HYPERBOLOID; q.radius = x->rmax; q.zmin = x->zmin; q.zmax = x->zmax; q.phi_max = x->phiMax;
+        q.p1[0] = x->p1.x; q.p1[1] = x->p1.y; q.p1[2] = x->p1.z; q.p2[0] = x->p2.x; q.p2[1] = x->p2.y; q.p2[2] = x->p2.z; q.a = x->a; q.c = x->c;
+    } else return false;
+    put_m(sh->ObjectToWorld.m, q.object_to_world); put_m(sh->ObjectToWorld.mInv, q.world_to_object);
+    return true;
 }
 
 void put_m(const Reference<Matrix4x4> &m, float *out) { for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) out[4 * r + c] = m->m[r][c]; }
 
 void flatten(const Scene *scene, const ParamSet &ips, Flat &F) {
     memset(&F.scene, 0, sizeof F.scene); memset(&F.render, 0, sizeof F.render);
-    // ---- lights first (their indices are what tri_light refers to): Scene::lights in creation order (api.cpp:339-352, :362-366)
+    // ---- primitives in the order KdTreeAccel refines them (kdtree.cpp:146-148: prims[i]->FullyRefine appends); the k-th quadric among
+    // them is quadrics[k] (an area light on a quadric refers to it by that index)
+    std::vector<Reference<Primitive> > refined;
+    for (size_t i = 0; i < g_prims.size(); ++i) g_prims[i]->FullyRefine(refined);
+    std::map<const Shape *, int> quadric_index;
+    for (size_t i = 0; i < refined.size(); ++i) {
+        if (!type_is(typeid(*refined[i].ptr), "GeometricPrimitive")) die("a primitive that is not a GeometricPrimitive");
+        const GeometricPrimitive *gp = static_cast<const GeometricPrimitive *>(refined[i].ptr);
+        RtQuadric q;
+        if (flatten_quadric(gp->shape.ptr, q)) { quadric_index[gp->shape.ptr] = int(F.quadrics.size()); F.quadrics.push_back(q); }
+    }
+    // ---- lights (their indices are what tri_light refers to): Scene::lights in creation order (api.cpp:339-352, :362-366)
     std::map<const Light *, int> light_index;
     for (size_t i = 0; i < scene->lights.size(); ++i) {
         const Light *l = scene->lights[i];
@@ -154,6 +232,22 @@ void flatten(const Scene *scene, const ParamSet &ips, Flat &F) {
         if (type_is(ti, "PointLight")) {                                    // point.cpp:49-54
             const PointLight *p = static_cast<const PointLight *>(l);
             L.type = RT_LIGHT_POINT; spec3(p->Intensity, L.color); L.pos[0] = p->lightPos.x; L.pos[1] = p->lightPos.y; L.pos[2] = p->lightPos.z;
+        } else if (type_is(ti, "SpotLight")) {                               // spot.cpp:54-60; Falloff uses WorldToLight (spot.cpp:68-79)
+            const SpotLight *p = static_cast<const SpotLight *>(l);
+            L.type = RT_LIGHT_SPOT; spec3(p->Intensity, L.color); L.pos[0] = p->lightPos.x; L.pos[1] = p->lightPos.y; L.pos[2] = p->lightPos.z;
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) L.world_to_light[3 * r + c] = p->WorldToLight.m->m[r][c];
+            L.cos_total_width = p->cosTotalWidth; L.cos_falloff_start = p->cosFalloffStart;
+        } else if (type_is(ti, "DistantLight")) {                            // distant.cpp:51-56
+            const DistantLight *p = static_cast<const DistantLight *>(l);
+            L.type = RT_LIGHT_DISTANT; spec3(p->L, L.color); L.dir[0] = p->lightDir.x; L.dir[1] = p->lightDir.y; L.dir[2] = p->lightDir.z;
+        } else if (type_is(ti, "AreaLight") && quadric_index.count(static_cast<const AreaLight *>(l)->shape.ptr)) {
+            // an emitter on a quadric: AreaLight keeps a shape that CanIntersect as it is (area.cpp:38-39)
+            const AreaLight *a = static_cast<const AreaLight *>(l);
+            L.type = RT_LIGHT_AREA; spec3(a->Lemit, L.color);
+            L.first_tri = 0; L.n_tris = 0; L.quadric_plus1 = quadric_index[a->shape.ptr] + 1;
+            if (F.quadrics[L.quadric_plus1 - 1].type > RT_QUADRIC_CYLINDER) die("an area light on a cone / paraboloid / hyperboloid (Shape::Sample unimplemented, shape.h:84-88)");
+            L.reverse_orientation = a->shape->reverseOrientation ? 1 : 0;
+            L.flip_normal = (a->shape->reverseOrientation ^ a->shape->transformSwapsHandedness) ? 1 : 0;
         } else if (type_is(ti, "AreaLight")) {                               // area.cpp:28-54
             const AreaLight *a = static_cast<const AreaLight *>(l);
             L.type = RT_LIGHT_AREA; spec3(a->Lemit, L.color);
@@ -172,21 +266,33 @@ void flatten(const Scene *scene, const ParamSet &ips, Flat &F) {
         light_index[l] = int(F.lights.size());
         F.lights.push_back(L);
     }
-    // ---- primitives in the order KdTreeAccel refines them (kdtree.cpp:146-148: prims[i]->FullyRefine appends)
-    std::vector<Reference<Primitive> > refined;
-    for (size_t i = 0; i < g_prims.size(); ++i) g_prims[i]->FullyRefine(refined);
     std::map<const Material *, int> mat_index;
     std::map<const TriangleMesh *, uint32_t> mesh_xform;
     bool any_shading = false;
     for (size_t i = 0; i < refined.size(); ++i) {
         if (!type_is(typeid(*refined[i].ptr), "GeometricPrimitive")) die("a primitive that is not a GeometricPrimitive");
         const GeometricPrimitive *gp = static_cast<const GeometricPrimitive *>(refined[i].ptr);
-        if (!type_is(typeid(*gp->shape.ptr), "Triangle")) die("a shape that is not a triangle");
+        if (quadric_index.count(gp->shape.ptr)) continue;
+        if (!type_is(typeid(*gp->shape.ptr), "Triangle")) die("a shape that is neither a triangle nor a quadric");
         const TriangleMesh *mesh = static_cast<const Triangle *>(gp->shape.ptr)->mesh.ptr;
         any_shading = any_shading || mesh->n || mesh->s || mesh->uvs;
     }
     for (size_t i = 0; i < refined.size(); ++i) {
         const GeometricPrimitive *gp = static_cast<const GeometricPrimitive *>(refined[i].ptr);
+        if (quadric_index.count(gp->shape.ptr)) {
+            // one primitive slot: the shape's world bound as a degenerate triangle {pMin, pMax, pMin} (pbrt_hip.h), flags bit 1
+            const Shape *sh = gp->shape.ptr;
+            const BBox wb = sh->WorldBound();
+            const float v[9] = {wb.pMin.x, wb.pMin.y, wb.pMin.z, wb.pMax.x, wb.pMax.y, wb.pMax.z, wb.pMin.x, wb.pMin.y, wb.pMin.z};
+            F.tri_verts.insert(F.tri_verts.end(), v, v + 9);
+            const Material *m = gp->material.ptr;
+            if (!mat_index.count(m)) { mat_index[m] = int(F.materials.size()); F.materials.push_back(flatten_material(m)); }
+            F.tri_material.push_back(uint16_t(mat_index[m]));
+            F.tri_light.push_back(gp->areaLight ? light_index[gp->areaLight] : -1);
+            F.tri_flags.push_back(uint8_t(((sh->reverseOrientation ^ sh->transformSwapsHandedness) ? 1 : 0) | 2));
+            if (any_shading) F.tri_shading.push_back(-1);
+            continue;
+        }
         const Triangle *t = static_cast<const Triangle *>(gp->shape.ptr);
         const TriangleMesh *mesh = t->mesh.ptr;
         for (int c = 0; c < 3; ++c) { const Point &p = mesh->p[t->v[c]]; F.tri_verts.push_back(p.x); F.tri_verts.push_back(p.y); F.tri_verts.push_back(p.z); }
@@ -217,15 +323,22 @@ void flatten(const Scene *scene, const ParamSet &ips, Flat &F) {
         }
     }
     // ---- camera (camera.cpp:50-70, perspective.cpp:37-50) and film (image.cpp:69-101)
-    if (!type_is(typeid(*scene->camera), "PerspectiveCamera")) die(typeid(*scene->camera).name());
-    const PerspectiveCamera *cam = static_cast<const PerspectiveCamera *>(scene->camera);
-    if (!type_is(typeid(*cam->film), "ImageFilm")) die(typeid(*cam->film).name());
-    const ImageFilm *film = static_cast<const ImageFilm *>(cam->film);
+    const Camera *anycam = scene->camera;
+    if (!type_is(typeid(*anycam->film), "ImageFilm")) die(typeid(*anycam->film).name());
+    const ImageFilm *film = static_cast<const ImageFilm *>(anycam->film);
     RtCamera &C = F.scene.camera;
-    C.type = RT_CAMERA_PERSPECTIVE; C.x_res = film->xResolution; C.y_res = film->yResolution;
-    put_m(cam->RasterToCamera.m, C.raster_to_camera); put_m(cam->CameraToWorld.m, C.camera_to_world);
-    C.lens_radius = cam->LensRadius; C.focal_distance = cam->FocalDistance; C.hither = cam->ClipHither; C.yon = cam->ClipYon;
-    C.shutter_open = cam->ShutterOpen; C.shutter_close = cam->ShutterClose;
+    C.x_res = film->xResolution; C.y_res = film->yResolution;
+    put_m(anycam->CameraToWorld.m, C.camera_to_world);
+    C.hither = anycam->ClipHither; C.yon = anycam->ClipYon; C.shutter_open = anycam->ShutterOpen; C.shutter_close = anycam->ShutterClose;
+    if (type_is(typeid(*anycam), "EnvironmentCamera")) C.type = RT_CAMERA_ENVIRONMENT;     // environment.cpp:37-61: no projection, no lens
+    else {
+        if (type_is(typeid(*anycam), "PerspectiveCamera")) C.type = RT_CAMERA_PERSPECTIVE;
+        else if (type_is(typeid(*anycam), "OrthoCamera")) C.type = RT_CAMERA_ORTHOGRAPHIC;   // orthographic.cpp:40-47
+        else die(typeid(*anycam).name());
+        const ProjectiveCamera *cam = static_cast<const ProjectiveCamera *>(anycam);
+        put_m(cam->RasterToCamera.m, C.raster_to_camera);
+        C.lens_radius = cam->LensRadius; C.focal_distance = cam->FocalDistance;
+    }
     RtRenderDesc &R = F.render;
     R.x_res = film->xResolution; R.y_res = film->yResolution;
     R.x_pixel_start = film->xPixelStart; R.y_pixel_start = film->yPixelStart; R.x_pixel_count = film->xPixelCount; R.y_pixel_count = film->yPixelCount;
@@ -278,6 +391,7 @@ void flatten(const Scene *scene, const ParamSet &ips, Flat &F) {
     F.scene.tri_shading = F.tri_shading.empty() ? NULL : F.tri_shading.data();
     F.scene.n_shading = uint32_t(F.shading.size()); F.scene.shading = F.shading.empty() ? NULL : F.shading.data();
     F.scene.n_xforms = uint32_t(F.xforms.size() / 32); F.scene.xforms = F.xforms.empty() ? NULL : F.xforms.data();
+    F.scene.n_quadrics = uint32_t(F.quadrics.size()); F.scene.quadrics = F.quadrics.empty() ? NULL : F.quadrics.data();
 }
 
 // ---- the C ABI of libpbrt_hip.so, bound at run time (include/pbrt_hip.h)

@@ -118,6 +118,12 @@ class RtAccelInfo(C.Structure):
                 ("grid_nvoxels", C.c_int32 * 3), ("grid_width", C.c_float * 3), ("grid_inv_width", C.c_float * 3)]
 
 
+class RtPrebuiltAccel(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("n_nodes", C.c_uint32), ("n_leaf_refs", C.c_uint32), ("max_depth", C.c_uint32),
+                ("nodes", C.c_void_p), ("leaf_refs", C.c_void_p), ("bounds", C.c_float * 6),
+                ("grid_nvoxels", C.c_int32 * 3), ("grid_width", C.c_float * 3), ("grid_inv_width", C.c_float * 3)]
+
+
 class RtRenderStats(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("render_ms", C.c_float), ("trace_ms", C.c_float), ("gather_ms", C.c_float),
                 ("pipeline", C.c_int32), ("iterations", C.c_int32), ("timed_iterations", C.c_int32), ("slots", C.c_uint32), ("shade_ms", C.c_float)]
@@ -145,9 +151,10 @@ def hip_lib():
                      "rt_film_clear", "rt_film_read", "rt_film_resolve", "rt_render", "rt_sync", "rt_counters",
                      "rt_counters_reset", "rt_last_render_ms", "rt_last_render_stats", "rt_samples_read", "rt_device_count", "rt_set_counting",
                      "rt_kdtree_build", "rt_kdtree_info", "rt_kdtree_copy", "rt_kdtree_destroy",
-                     "rt_accel_build", "rt_accel_info", "rt_accel_copy", "rt_accel_destroy"):
+                     "rt_accel_build", "rt_accel_info", "rt_accel_copy", "rt_accel_destroy", "rt_scene_create_prebuilt", "rt_film_resolve_device"):
             getattr(L, name).restype = C.c_int
         L.rt_scene_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.rt_scene_create_prebuilt.argtypes = [C.c_void_p, C.c_int, C.POINTER(RtPrebuiltAccel), C.POINTER(C.c_void_p)]
         L.rt_scene_destroy.argtypes = [C.c_void_p]
         L.rt_scene_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.rt_scene_accel_info.argtypes = [C.c_void_p, C.POINTER(RtAccelInfo)]
@@ -160,6 +167,7 @@ def hip_lib():
         L.rt_film_read.argtypes = [C.c_void_p, C.c_void_p]
         L.rt_film_resolve.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.rt_render.argtypes = [C.c_void_p, C.c_void_p]
+        L.rt_film_resolve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
         L.rt_sync.argtypes = [C.c_void_p]
         L.rt_counters.argtypes = [C.c_void_p, C.POINTER(RtCounters)]
         L.rt_counters_reset.argtypes = [C.c_void_p]
@@ -291,6 +299,27 @@ def assemble_exr(paths, out) -> float:
     return float(r)
 
 
+def publish_accel(ds: "DeviceScene", path: str) -> None:
+    """Rank 0 of a node: write the accelerator of `ds` where the other ranks can map it (e.g. under /dev/shm): one file, header
+    (RtAccelInfo bytes) + nodes + leaf refs, renamed into place when complete."""
+    info = ds.accel_info()
+    nodes, refs = ds.accel_arrays()
+    tmp = path + ".tmp%d" % os.getpid()
+    with open(tmp, "wb") as f:
+        f.write(bytes(info).ljust(256, b"\0"))
+        f.write(nodes.tobytes()); f.write(np.ascontiguousarray(refs, np.uint32).tobytes())
+    os.replace(tmp, path)
+
+
+def attach_accel(path: str):
+    """The other ranks: (nodes, leaf_refs, RtAccelInfo) mapped read-only from a file written by publish_accel."""
+    raw = np.memmap(path, dtype=np.uint8, mode="r")
+    info = RtAccelInfo.from_buffer_copy(bytes(raw[:C.sizeof(RtAccelInfo)]))
+    nodes = np.frombuffer(raw, np.uint32, count=2 * info.n_nodes, offset=256).reshape(-1, 2)
+    refs = np.frombuffer(raw, np.uint32, count=info.n_leaf_refs, offset=256 + 8 * info.n_nodes)
+    return nodes, refs, info
+
+
 class RtError(RuntimeError):
     pass
 
@@ -354,8 +383,12 @@ class ParsedScene:
         x0, x1, y0, y1 = self.sample_extent
         return (x1 - x0) * (y1 - y0) * self.spp
 
-    def set_shard(self, index: int, count: int, tile_pixels: int = 64):
-        host_lib().pbrt_host_set_shard(self.render_desc, index, count, tile_pixels)
+    def set_shard(self, index: int, count: int, tile_pixels=64):
+        """tile_pixels: an int = tiles of that many consecutive pixels of the sample extent (scanline order); a pair (w, h) = 2-D tiles of
+        w x h pixels (RtRenderDesc.tile_pixels = -(w | h << 16))."""
+        if isinstance(tile_pixels, (tuple, list)):
+            tile_pixels = -(int(tile_pixels[0]) | (int(tile_pixels[1]) << 16))
+        host_lib().pbrt_host_set_shard(self.render_desc, index, count, int(tile_pixels))
 
     def set_seed(self, seed: int):
         host_lib().pbrt_host_set_seed(self.render_desc, seed)
@@ -403,10 +436,22 @@ class ParsedScene:
 class DeviceScene:
     """rt_scene_create: kd-tree build + upload.  Holds the film unless one is bound externally."""
 
-    def __init__(self, parsed: ParsedScene, device: int = -1):
+    def __init__(self, parsed: ParsedScene, device: int = -1, prebuilt=None):
+        """prebuilt = (nodes[n][2] uint32, leaf_refs uint32, RtAccelInfo) of an accelerator built elsewhere (another rank's
+        DeviceScene.accel_arrays() / accel_info(), e.g. through publish_accel / attach_accel): rt_scene_create_prebuilt."""
         self.parsed = parsed
         self._s = C.c_void_p()
-        _chk(hip_lib().rt_scene_create(parsed.scene_desc, device, C.byref(self._s)))
+        if prebuilt is None:
+            _chk(hip_lib().rt_scene_create(parsed.scene_desc, device, C.byref(self._s)))
+        else:
+            nodes, refs, info = prebuilt
+            nodes = np.ascontiguousarray(nodes, np.uint32); refs = np.ascontiguousarray(refs if len(refs) else np.zeros(1, np.uint32), np.uint32)
+            pa = RtPrebuiltAccel(kind=info.kind, n_nodes=info.n_nodes, n_leaf_refs=info.n_leaf_refs, max_depth=info.max_depth,
+                                 nodes=nodes.ctypes.data, leaf_refs=refs.ctypes.data)
+            for i in range(6): pa.bounds[i] = info.bounds[i]
+            for i in range(3):
+                pa.grid_nvoxels[i] = info.grid_nvoxels[i]; pa.grid_width[i] = info.grid_width[i]; pa.grid_inv_width[i] = info.grid_inv_width[i]
+            _chk(hip_lib().rt_scene_create_prebuilt(parsed.scene_desc, device, C.byref(pa), C.byref(self._s)))
         self._film_bound = False
 
     def accel_info(self) -> RtAccelInfo:
@@ -441,6 +486,11 @@ class DeviceScene:
 
     def sync(self):
         _chk(hip_lib().rt_sync(self._s))
+
+    def resolve_device(self, accum_ptr: int, n: int, rgb_ptr: int, alpha_ptr: int, premultiply: bool | None = None):
+        """rt_film_resolve_device: WriteImage's normalisation of a 5-plane accumulator (planes of n floats) in device memory."""
+        pm = self.parsed.premultiply if premultiply is None else premultiply
+        _chk(hip_lib().rt_film_resolve_device(self._s, C.c_void_p(accum_ptr), n, int(pm), C.c_void_p(rgb_ptr), C.c_void_p(alpha_ptr)))
 
     def film_accum(self) -> np.ndarray:
         out = np.zeros((5, self.parsed.height, self.parsed.width), np.float32)

@@ -105,6 +105,8 @@ struct DevFrame {
     float *accum;                // 5 planes
     float4 *samples;             // per-shard sample buffer, 2 x float4 per work item
     int shard_index, shard_count, tile_pixels;
+    int tile_w, tile_h, tiles_x;   // 2-D tiles (RtRenderDesc.tile_pixels < 0): tile_w x tile_h pixel blocks of the sample extent, tiles_x of them per row;
+                                   // tile_pixels = tile_w * tile_h then.  tile_w == 0: tiles of tile_pixels consecutive pixels in scanline order
     int dbg_x, dbg_y;            // -DRT_DEBUG_PIXEL builds: print the vertices of the samples of this pixel
     int exit_thresh;             // leave the shared traversal loop when <= this many lanes still traverse (0 = never)
     int phase_sync;             // path integrator: alternate the two halves of the state machine between sweeps (rt_integrate.h)

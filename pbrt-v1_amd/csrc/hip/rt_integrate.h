@@ -207,6 +207,18 @@ RT_DEV bool work_to_sample(const DevFrame &fr, unsigned long long w, unsigned lo
     const unsigned long long per_tile = (unsigned long long)fr.tile_pixels * fr.spp;
     // every frame of practical size has fewer than 2^32 samples: 32-bit divisions (a 64-bit division is ~150 VALU instructions
     // on gfx950, and this runs in the sparsely populated fetch path)
+    if (fr.tile_w > 0) {                                    // 2-D tiles: a tile is a tile_w x tile_h block of the sample extent; the pixels of
+        const unsigned long long lt = w / per_tile, rem = w - lt * per_tile;           // the border tiles that fall off the extent are skipped
+        const unsigned long long tile = lt * unsigned(fr.shard_count) + unsigned(fr.shard_index);
+        const unsigned q = unsigned(rem / unsigned(fr.spp));
+        s = int(rem - (unsigned long long)q * unsigned(fr.spp));
+        const unsigned ty = unsigned(tile / unsigned(fr.tiles_x)), tx = unsigned(tile - (unsigned long long)ty * unsigned(fr.tiles_x));
+        const unsigned qy = q / unsigned(fr.tile_w), qx = q - qy * unsigned(fr.tile_w);
+        const unsigned px = tx * unsigned(fr.tile_w) + qx, py = ty * unsigned(fr.tile_h) + qy;
+        const unsigned ew = unsigned(fr.x_end - fr.x_start), eh = unsigned(fr.y_end - fr.y_start);
+        pixel = (unsigned long long)py * ew + px;
+        return px < ew && py < eh;
+    }
     if (fr.total_work <= 0xffffffffull && per_tile <= 0xffffffffull) {
         const unsigned w32 = unsigned(w), pt = unsigned(per_tile);
         const unsigned lt = w32 / pt, rem = w32 - lt * pt;

@@ -69,6 +69,14 @@ __global__ __launch_bounds__(256) void film_gather_kernel(const DevFrame *__rest
             if (int(threadIdx.x) < ncols) {
                 const unsigned long long pixel = (unsigned long long)(sy - fr.y_start) * ew + (cx + int(threadIdx.x) - fr.x_start);
                 bool mine; unsigned long long base;
+                if (fr.tile_w > 0) {                                // 2-D tiles (work_to_sample, rt_integrate.h)
+                    const unsigned px = unsigned(cx + int(threadIdx.x) - fr.x_start), py = unsigned(sy - fr.y_start);
+                    const unsigned tx = px / unsigned(fr.tile_w), ty = py / unsigned(fr.tile_h);
+                    const unsigned tile = ty * unsigned(fr.tiles_x) + tx, lt = tile / unsigned(fr.shard_count);
+                    const unsigned in_tile = (py - ty * unsigned(fr.tile_h)) * unsigned(fr.tile_w) + (px - tx * unsigned(fr.tile_w));
+                    mine = int(tile - lt * unsigned(fr.shard_count)) == fr.shard_index;
+                    base = ((unsigned long long)lt * per_tile + (unsigned long long)in_tile * fr.spp) * 2;
+                } else
                 if (fr.total_pixels <= 0xffffffffull) {             // 32-bit divisions (a 64-bit one is ~150 VALU instructions)
                     const unsigned p32 = unsigned(pixel), tile = p32 / unsigned(fr.tile_pixels), in_tile = p32 - tile * unsigned(fr.tile_pixels);
                     const unsigned lt = tile / unsigned(fr.shard_count);
@@ -649,6 +657,7 @@ static int render_pipeline(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, int
 }
 
 static void fill_info(const KdTree &tree, const GridAccelData &g, int kind, uint32_t n_tris, RtAccelInfo *info);
+extern "C" int rt_scene_destroy(RtScene *s);
 
 extern "C" {
 
@@ -662,8 +671,48 @@ int rt_device_count(int *count) {
     *count = n; return RT_OK;
 }
 
-int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
+// structural check of an accelerator handed in by the caller (rt_scene_create_prebuilt): every index the traversal follows stays in range
+static int check_prebuilt(const RtPrebuiltAccel *a, uint32_t n_tris) {
+    if (!a->nodes || (a->n_leaf_refs && !a->leaf_refs)) return fail(RT_EINVAL, "rt_scene_create_prebuilt: null accelerator arrays");
+    const uint32_t *nd = a->nodes;
+    for (uint32_t i = 0; i < a->n_leaf_refs; ++i) if (a->leaf_refs[i] >= n_tris) return fail(RT_EINVAL, "rt_scene_create_prebuilt: primitive index out of range");
+    if (a->kind == RT_ACCEL_KDTREE) {
+        if (a->n_nodes == 0 && n_tris != 0) return fail(RT_EINVAL, "rt_scene_create_prebuilt: empty tree");
+        for (uint32_t i = 0; i < a->n_nodes; ++i) {
+            const uint32_t x = nd[2 * size_t(i)], y = nd[2 * size_t(i) + 1];
+            if ((x & 3u) != 3u) { if (y <= i + 1u || y >= a->n_nodes || i + 1u >= a->n_nodes) return fail(RT_EINVAL, "rt_scene_create_prebuilt: child index out of range"); }
+            else {
+                const uint32_t np = x >> 2;
+                if (np == 1u ? y >= n_tris : (np > 1u && (y > a->n_leaf_refs || np > a->n_leaf_refs - y))) return fail(RT_EINVAL, "rt_scene_create_prebuilt: leaf list out of range");
+            }
+        }
+        if (a->max_depth > 64) return fail(RT_EINVAL, "rt_scene_create_prebuilt: max_depth beyond 64");
+    } else {
+        const unsigned long long nv = (unsigned long long)a->grid_nvoxels[0] * a->grid_nvoxels[1] * a->grid_nvoxels[2];
+        if (a->grid_nvoxels[0] < 1 || a->grid_nvoxels[1] < 1 || a->grid_nvoxels[2] < 1 || nv != a->n_nodes) return fail(RT_EINVAL, "rt_scene_create_prebuilt: voxel counts do not match");
+        for (uint32_t i = 0; i < a->n_nodes; ++i) {
+            const uint32_t off = nd[2 * size_t(i)], cnt = nd[2 * size_t(i) + 1];
+            if (off > a->n_leaf_refs || cnt > a->n_leaf_refs - off) return fail(RT_EINVAL, "rt_scene_create_prebuilt: voxel list out of range");
+        }
+    }
+    return RT_OK;
+}
+
+static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel *pre, RtScene **out);
+int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) { return scene_create(d, device, nullptr, out); }
+// The same scene with the accelerator somebody else built (rt_accel_build / rt_scene_accel_copy of another rank's scene): the ranks of one
+// node build the kd-tree ONCE (10 M triangles: 15 s on all host cores) instead of once per process.  The arrays are the canonical flattened
+// tree (pbrt_hip.h RtAccelInfo / rt_accel_copy); everything the device derives from them (leaf-ordered records, pair blocks) is rebuilt here.
+int rt_scene_create_prebuilt(const RtSceneDesc *d, int device, const RtPrebuiltAccel *pre, RtScene **out) {
+    if (!pre) return fail(RT_EINVAL, "rt_scene_create_prebuilt: null accelerator");
+    return scene_create(d, device, pre, out);
+}
+static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel *pre, RtScene **out) {
     if (!d || !out) return fail(RT_EINVAL, "rt_scene_create: null argument");
+    if (pre) {
+        if (pre->kind != d->accel.kind) return fail(RT_EINVAL, "rt_scene_create_prebuilt: accelerator kind differs from the scene's");
+        int rc = check_prebuilt(pre, d->n_tris); if (rc) return rc;
+    }
     if (d->n_tris && (!d->tri_verts || !d->tri_material || !d->tri_light || !d->tri_flags))
         return fail(RT_EINVAL, "rt_scene_create: missing triangle arrays");
     if (d->accel.kind != RT_ACCEL_KDTREE && d->accel.kind != RT_ACCEL_GRID) return fail(RT_EINVAL, "rt_scene_create: unknown accelerator kind");
@@ -687,7 +736,17 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
     s->n_tris = d->n_tris;
 
     s->accel_kind = d->accel.kind;
-    if (s->accel_kind == RT_ACCEL_GRID) {
+    if (pre) {
+        const Node *pn = reinterpret_cast<const Node *>(pre->nodes);
+        s->tree.nodes.assign(pn, pn + pre->n_nodes); s->tree.leaf_refs.assign(pre->leaf_refs, pre->leaf_refs + pre->n_leaf_refs);
+        s->tree.max_depth = int(pre->max_depth); s->tree.build_seconds = 0.0;
+        std::memcpy(s->tree.bounds, pre->bounds, sizeof s->tree.bounds);
+        if (s->accel_kind == RT_ACCEL_GRID) {
+            s->gridacc.voxels = s->tree.nodes; s->gridacc.refs = s->tree.leaf_refs; s->gridacc.build_seconds = 0.0;
+            std::memcpy(s->gridacc.bounds, pre->bounds, sizeof s->gridacc.bounds);
+            for (int a = 0; a < 3; ++a) { s->gridacc.nvox[a] = pre->grid_nvoxels[a]; s->gridacc.width[a] = pre->grid_width[a]; s->gridacc.inv_width[a] = pre->grid_inv_width[a]; }
+        }
+    } else if (s->accel_kind == RT_ACCEL_GRID) {
         build_grid(d->tri_verts, d->n_tris, s->gridacc);
         s->tree.nodes = s->gridacc.voxels; s->tree.leaf_refs = s->gridacc.refs; s->tree.max_depth = 0;
         std::memcpy(s->tree.bounds, s->gridacc.bounds, sizeof s->tree.bounds); s->tree.build_seconds = s->gridacc.build_seconds;
@@ -1037,7 +1096,15 @@ static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool nee
     if (fr.shard_index < 0 || fr.shard_index >= fr.shard_count) return fail(RT_EINVAL, "bad shard index");
     fr.total_pixels = (unsigned long long)(fr.x_end - fr.x_start) * (unsigned long long)(fr.y_end - fr.y_start);
     if (fr.total_pixels * fr.spp > 0xFFFFFFFFull) return fail(RT_EINVAL, "more than 2^32 camera samples per frame");
-    const unsigned long long n_tiles = (fr.total_pixels + fr.tile_pixels - 1) / fr.tile_pixels;
+    unsigned long long n_tiles = 0;
+    if (rd->tile_pixels < 0) {                               // 2-D tiles: width in the low 16 bits of -tile_pixels, height above (pbrt_hip.h)
+        const int tw = (-rd->tile_pixels) & 0xffff, th = (-rd->tile_pixels) >> 16;
+        if (tw < 1 || th < 1 || tw > 4096 || th > 4096) return fail(RT_EINVAL, "bad 2-D tile size");
+        fr.tile_w = tw; fr.tile_h = th; fr.tile_pixels = tw * th;
+        fr.tiles_x = (fr.x_end - fr.x_start + tw - 1) / tw;
+        n_tiles = (unsigned long long)fr.tiles_x * (unsigned long long)((fr.y_end - fr.y_start + th - 1) / th);
+        if (n_tiles * fr.tile_pixels * fr.spp > 0xFFFFFFFFull) return fail(RT_EINVAL, "more than 2^32 camera samples per frame (2-D tiles, border tiles included)");
+    } else n_tiles = (fr.total_pixels + fr.tile_pixels - 1) / fr.tile_pixels;
     const unsigned long long my_tiles = n_tiles > (unsigned long long)fr.shard_index
         ? (n_tiles - fr.shard_index + fr.shard_count - 1) / fr.shard_count : 0;
     fr.total_work = my_tiles * fr.tile_pixels * fr.spp;
@@ -1218,6 +1285,17 @@ int rt_film_resolve(RtScene *s, int premultiply, float *rgb_out, float *alpha_ou
     HIPCHK(hipMemcpyAsync(rgb_out, s->resolve_buf, 3 * n * sizeof(float), hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipMemcpyAsync(alpha_out, s->resolve_buf + 3 * n, n * sizeof(float), hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
+    return RT_OK;
+}
+
+// ImageFilm::WriteImage's per-pixel arithmetic (image.cpp:157-203) on the caller's DEVICE buffers: `dev_accum` = 5 planes of n floats (the
+// part of a film a rank holds after a row-wise reduce-scatter), results to dev_rgb[n][3] / dev_alpha[n]; asynchronous on the scene's stream.
+int rt_film_resolve_device(RtScene *s, const float *dev_accum, uint64_t n, int premultiply, float *dev_rgb, float *dev_alpha) {
+    if (!s || !dev_accum || !dev_rgb || !dev_alpha) return fail(RT_EINVAL, "null argument");
+    if (n == 0) return RT_OK;
+    HIPCHK(hipSetDevice(s->device));
+    hipLaunchKernelGGL(film_resolve_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s->stream, dev_accum, size_t(n), premultiply, dev_rgb, dev_alpha);
+    HIPCHK(hipGetLastError());
     return RT_OK;
 }
 

@@ -233,9 +233,13 @@ bool MakeCamera(const std::string &name, const ParamSet &ps, const Xform &world2
     Xform rasterToScreen = screenToRaster.inverse();
     Xform rasterToCamera = cameraToScreen.inverse() * rasterToScreen;
     Xform cameraToWorld = world2cam.inverse();
-    std::memcpy(out->raster_to_camera, rasterToCamera.m.m, 16 * sizeof(float));
+    // EnvironmentCamera is not a ProjectiveCamera (environment.cpp:29-38): it has no RasterToCamera, no lens; those fields stay zero
+    if (out->type != RT_CAMERA_ENVIRONMENT) {
+        std::memcpy(out->raster_to_camera, rasterToCamera.m.m, 16 * sizeof(float));
+        out->lens_radius = lensradius; out->focal_distance = focaldistance;
+    }
     std::memcpy(out->camera_to_world, cameraToWorld.m.m, 16 * sizeof(float));
-    out->lens_radius = lensradius; out->focal_distance = focaldistance; out->hither = hither; out->yon = yon;
+    out->hither = hither; out->yon = yon;
     out->shutter_open = shutteropen; out->shutter_close = shutterclose;
     return true;
 }

@@ -19,9 +19,28 @@ SMOOTH = ('AttributeBegin\nMaterial "plastic" "color Kd" [.2 .3 .7] "float rough
           'AttributeEnd\n')
 
 
+# quadrics (two of them emitters), spot + distant lights, uber / plastic materials
+F4_WORLD = ('AttributeBegin\nMaterial "uber" "color Kd" [.5 .4 .6] "color Ks" [.3 .3 .3] "color Kr" [.2 .2 .2] "color opacity" [1 1 .7] "float roughness" [.2]\n'
+            'Translate 420 100 380\nRotate 25 1 1 1\nShape "cylinder" "float radius" [48] "float zmin" [-50] "float zmax" [60] "float phimax" [300]\nAttributeEnd\n'
+            'AttributeBegin\nAreaLightSource "area" "color L" [6 5 4] "integer nsamples" [2]\nMaterial "matte" "color Kd" [0 0 0]\nTranslate 150 420 300\n'
+            'Shape "sphere" "float radius" [40] "float zmin" [-30] "float zmax" [35]\nAttributeEnd\n'
+            'AttributeBegin\nAreaLightSource "area" "color L" [3 3 5]\nTranslate 400 500 150\nRotate 90 1 0 0\nReverseOrientation\nShape "disk" "float radius" [50] "float innerradius" [10]\nAttributeEnd\n'
+            'AttributeBegin\nMaterial "plastic" "color Kd" [.2 .5 .3] "color Ks" [.4 .4 .4] "float roughness" [.05]\nTranslate 120 60 200\nRotate -90 1 0 0\n'
+            'Shape "cone" "float radius" [50] "float height" [120]\nTranslate 180 0 0\nShape "paraboloid" "float radius" [40] "float zmax" [90] "float zmin" [10]\n'
+            'Translate 0 140 0\nScale -1 1 1\nShape "hyperboloid" "point p1" [50 0 -40] "point p2" [30 30 50]\nAttributeEnd\n'
+            'AttributeBegin\nRotate 10 0 1 0\nLightSource "spot" "point from" [278 500 100] "point to" [300 0 330] "color I" [300000 250000 200000] "float coneangle" [35] "float conedeltaangle" [12]\n'
+            'LightSource "distant" "point from" [.3 1 -.2] "point to" [0 0 0] "color L" [.8 .8 1]\nAttributeEnd\n')
+
+
 def cases(scenes):
     blob = scenes.icosphere((200, 120, 250), 90, 1)
+    f4 = scenes.cornell_scene(xres=32, yres=28, integrator="path", maxdepth=4, xsamples=2, ysamples=2, jitter=True, soup_tris=200, world_kwargs=dict(extra=F4_WORLD))
     return {
+        "f4_quadrics_lights_uber": f4,
+        "f4_orthographic": scenes.cornell_scene(xres=24, yres=20, integrator="directlighting", xsamples=2, ysamples=1, lensradius=3.0, focaldistance=700.0,
+                                                world_kwargs=dict(extra=F4_WORLD)).replace('Camera "perspective" "float fov" [39.3]', 'Camera "orthographic" "float screenwindow" [-300 300 -290 290]'),
+        "f4_environment": scenes.cornell_scene(xres=32, yres=16, integrator="whitted", world_kwargs=dict(extra=F4_WORLD)).replace(
+            "LookAt 278 273 -800  278 273 0  0 1 0", "LookAt 278 273 200  278 273 600  0 1 0").replace('Camera "perspective" "float fov" [39.3]', 'Camera "environment" "float hither" [.5]'),
         "c1_cornell_whitted": scenes.cornell_scene(xres=64, yres=64, integrator="whitted"),
         "c2_cornell_path": scenes.cornell_scene(xres=48, yres=48, integrator="path", maxdepth=5, xsamples=2, ysamples=2, jitter=True, pixel_filter="mitchell"),
         "c3_soup_direct": scenes.cornell_scene(xres=40, yres=30, integrator="directlighting", xsamples=2, ysamples=1, jitter=True, soup_tris=600, pixel_filter="gaussian",
@@ -93,7 +112,7 @@ def test_host_library_exports_a_c_surface_only(pkg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["c1_cornell_whitted", "c3_soup_direct", "c2_cornell_path", "smooth_mesh_nuvs"])
+@pytest.mark.parametrize("name", ["c1_cornell_whitted", "c3_soup_direct", "c2_cornell_path", "smooth_mesh_nuvs", "f4_orthographic", "f4_environment"])
 def test_reference_render_loop_served_by_the_hip_library(pkg, scenes, name):
     """Scene::Render (scene.cpp:32-88) of the UNMODIFIED reference, with SurfaceIntegrator "hip" / Accelerator "hip": the adapter hands
     the flattened scene to libpbrt_hip.so through the C ABI and answers every Li() from rt_samples_read; the reference's sampler

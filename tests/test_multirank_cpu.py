@@ -35,7 +35,7 @@ def _worker(rank, world, port, scene_text, tile, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("tile", [7, 64])
+@pytest.mark.parametrize("tile", [7, 64, (8, 8), (16, 5)])
 def test_two_rank_tile_shards_sum_to_the_full_film(pkg, scenes, oracle, tmp_path, tile):
     import torch.multiprocessing as mp
     text = scenes.cornell_scene(xres=24, yres=20, integrator="path", xsamples=2, ysamples=2, jitter=True,
@@ -43,7 +43,7 @@ def test_two_rank_tile_shards_sum_to_the_full_film(pkg, scenes, oracle, tmp_path
     ps = pkg.ParsedScene(text=text)
     nodes, refs, bounds, _ = ps.kdtree()
     _, _, full, cnt = oracle.render(ps, nodes, refs, bounds)
-    port = 29500 + (os.getpid() + tile) % 2000
+    port = 29500 + (os.getpid() + (tile if isinstance(tile, int) else 100 + tile[0] + tile[1])) % 2000
     mp.spawn(_worker, args=(2, port, text, tile, str(tmp_path)), nprocs=2, join=True)
     merged = np.load(tmp_path / "film.npy")
     rays = np.load(tmp_path / "rays.npy")
@@ -64,3 +64,9 @@ def test_shard_partition_covers_every_sample_once(pkg, scenes, oracle):
             cams += oracle.render(ps)[3]["camera_rays"]
         total = cams if total is None else total
         assert cams == total == 18 * 10 * 2
+        for tile in ((4, 4), (5, 3), (32, 32)):                      # 2-D tiles, clipped at the border of the 18 x 10 sample extent
+            cams = 0
+            for r in range(world):
+                ps = pkg.ParsedScene(text=text); ps.set_shard(r, world, tile)
+                cams += oracle.render(ps)[3]["camera_rays"]
+            assert cams == total, (world, tile)

@@ -19,19 +19,29 @@ def free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def test_two_ranks_on_one_gpu_through_bench(pkg, tmp_path):
+def _bench(args, env, timeout=900, nproc=0):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args if not nproc else \
+          [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(ROOT, "bench.py")] + args
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    return json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+
+
+@pytest.mark.parametrize("mode", [["--tile-2d", "0", "--tile-pixels", "16", "--merge", "allreduce"],      # round 1 / 2: 1-D tiles, all-reduce, rank-0 resolve
+                                  ["--tile-2d", "16", "--merge", "reduce_scatter"],                         # round 3 default form: 2-D tiles, row-wise reduce-scatter,
+                                  ["--tile-2d", "32", "--merge", "allreduce"]])                             # per-rank resolve, all-gather of the resolved rows
+def test_two_ranks_on_one_gpu_through_bench(pkg, tmp_path, mode):
+    """Two ranks share GPU 0 (collectives over gloo, staged through the host); the second rank maps the accelerator the first one
+    built and published under /dev/shm (rt_scene_create_prebuilt).  Whatever the tile shape and the way the partial films are merged,
+    the frame is the single-rank frame (float sums in another order: <= 2e-5 relative)."""
     if pkg.device_count() < 1:
         pytest.fail("no HIP device visible")
     env = dict(os.environ, PBRT_BENCH_BACKEND="gloo", PBRT_BENCH_SAME_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
-    base = ["--steps", "2", "--warmup", "1", "--workload", "tsmall", "--no-cpu-baseline", "--no-extra", "--tile-pixels", "16"]
-    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dump-film", one] + base, env=env, capture_output=True, text=True, timeout=600)
-    assert r1.returncode == 0, r1.stderr[-2000:]
-    j1 = json.loads(r1.stdout.strip().splitlines()[-1])
-    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
-                         os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dump-film", two] + base, env=env, capture_output=True, text=True, timeout=900)
-    assert r2.returncode == 0, (r2.stdout[-1500:], r2.stderr[-3000:])
-    j2 = json.loads([ln for ln in r2.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    base = ["--steps", "2", "--warmup", "1", "--workload", "tsmall", "--no-cpu-baseline", "--no-extra"] + mode
+    j1 = _bench(["--gpus", "1", "--dump-film", one] + base, env)
+    j2 = _bench(["--gpus", "2", "--dump-film", two] + base, env, nproc=2)
     assert j2["n_gpus"] == 2 and len(j2["per_rank"]) == 2
     # every camera sample rendered exactly once across the two shards, same rays as the single-rank frame
     assert j2["config"]["camera_samples_per_frame"] == j1["config"]["camera_samples_per_frame"]
@@ -39,3 +49,48 @@ def test_two_ranks_on_one_gpu_through_bench(pkg, tmp_path):
     assert all(r["rays"] > 0.3 * j1["config"]["rays_per_frame"] for r in j2["per_rank"])          # interleaved tiles: balanced shards
     a, b = np.load(one), np.load(two)
     assert np.allclose(a["rgb"], b["rgb"], rtol=2e-5, atol=2e-6) and np.allclose(a["alpha"], b["alpha"], rtol=2e-5, atol=2e-6)
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("pbrt_hip_accel_")]            # the published tree is removed again
+
+
+def test_single_rank_rccl_process_group(pkg, tmp_path):
+    """bench.py --force-dist: world size 1 over the nccl (= RCCL) backend on the one GPU this box has -- process-group set-up with
+    device_id, the probe all-reduce, the shared-accelerator hand-shake, reduce-scatter / all-gather of device tensors through RCCL and
+    the per-rank resolve all execute; the frame is the plain single-process frame."""
+    if pkg.device_count() < 1:
+        pytest.fail("no HIP device visible")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
+    base = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--workload", "tsmall", "--no-cpu-baseline", "--no-extra"]
+    j1 = _bench(base + ["--dump-film", one], env)
+    for merge in ("reduce_scatter", "allreduce"):
+        j2 = _bench(base + ["--dump-film", two, "--force-dist", "--merge", merge], env)
+        assert j2["config"]["rays_per_frame"] == j1["config"]["rays_per_frame"]
+        a, b = np.load(one), np.load(two)
+        assert np.array_equal(a["rgb"], b["rgb"]) and np.array_equal(a["alpha"], b["alpha"]), merge
+
+
+def test_prebuilt_accelerator_gives_the_same_scene(pkg, scenes, tmp_path):
+    """rt_scene_create_prebuilt with the arrays of another scene's tree (through a file, as bench.py's ranks hand it over): same hits,
+    same film; a tree with an index out of range is refused."""
+    if pkg.device_count() < 1:
+        pytest.fail("no HIP device visible")
+    for accel in ("kdtree", "grid"):
+        ps = pkg.ParsedScene(text=scenes.cornell_scene(xres=48, yres=40, integrator="path", maxdepth=4, xsamples=2, ysamples=2, jitter=True, soup_tris=4000,
+                                                       accelerator=accel, keyed=True))
+        a = pkg.DeviceScene(ps); a.render(); fa = a.film_accum(); ca = a.counters()
+        path = str(tmp_path / ("accel_%s.bin" % accel))
+        pkg.publish_accel(a, path)
+        nodes, refs, info = pkg.attach_accel(path)
+        b = pkg.DeviceScene(ps, prebuilt=(nodes, refs, info)); b.render(); fb = b.film_accum(); cb = b.counters()
+        assert np.array_equal(fa, fb) and ca == cb, accel
+        n2, r2 = b.accel_arrays()
+        assert np.array_equal(n2, nodes) and np.array_equal(r2, refs) and b.accel_info().max_depth == info.max_depth
+        a.close(); b.close()
+        bad = np.array(nodes, copy=True)
+        if accel == "kdtree":
+            interior = np.nonzero((bad[:, 0] & 3) != 3)[0]
+            bad[interior[len(interior) // 2], 1] = len(bad) + 5            # an above-child beyond the array
+        else:
+            bad[3, 1] = len(refs) + 7                                         # a voxel list beyond the reference array
+        with pytest.raises(pkg.RtError):
+            pkg.DeviceScene(ps, prebuilt=(bad, refs, info))

@@ -1,0 +1,28 @@
+"""GPU box: rebuild single units with -D knobs and time workloads.  usage: python tools/r03_scan.py <group>"""
+import json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import r02_trace_scan as T
+T.UNITS = ("rt_kernels", "rt_trace", "rt_mega_w", "rt_mega_d", "rt_mega_p", "rt_pipe_w", "rt_pipe_d", "rt_pipe_p", "rt_pipe_v", "kd_build", "grid_build")
+
+def bench(tag, env=None, workload="p1000000", steps=3):
+    e = dict(env or {}); e.setdefault("PBRT_HIP_PIPELINE", "")
+    T.bench(tag, env=e, workload=workload, steps=steps)
+
+g = sys.argv[1]
+if g == "occ":
+    for w in (5, 6, 4):
+        for u in ("rt_mega_p", "rt_mega_d"):
+            T.rebuild(u, ["-DRT_HIGH_OCC_WAVES=%d" % w])
+        for wl in ("c3", "p1000000", "c4"):
+            bench("mega_waves%d_%s" % (w, wl), workload=wl)
+elif g == "exit":
+    for et in (16, 24, 32, 40, 48):
+        for wl in ("c3", "p1000000"):
+            bench("exit%d_%s" % (et, wl), env={"PBRT_HIP_EXIT_THRESH": str(et)}, workload=wl)
+elif g == "trace8":
+    # the trace kernel at 8 waves per SIMD (64 VGPRs) with a 6-entry LDS ring (18 KB per workgroup: 8 workgroups per CU)
+    for defs in (["-DRT_TRACE_WAVES=8", "-DRT_TRACE_STACK=6"], ["-DRT_TRACE_WAVES=7", "-DRT_TRACE_STACK=6"], []):
+        T.rebuild("rt_trace", defs)
+        for wl in ("c5", "p1000000"):
+            bench("trace:%s:%s" % (" ".join(defs), wl), env={"PBRT_HIP_PIPELINE": "1"}, workload=wl)
