@@ -416,7 +416,7 @@ def test_allow_listed_cases_converge_to_the_oracle(pkg, scenes, oracle, case):
     rendered at 32x its samples per pixel: the oracle twice (seeds A and B), the device once (seed A), and compared on 4x4-pixel block
     means.  d_ref = oracle_A - oracle_B is pure Monte-Carlo noise; d_dev = device_A - oracle_B must look like it:
       * rms(d_dev) <= 1.25 rms(d_ref)            (no extra error anywhere),
-      * |mean(d_dev)| <= 4 rms(d_ref) / sqrt(#blocks)   (no energy bias),
+      * |mean(device_A - oracle_A)| <= 4 rms(d_ref) / sqrt(#blocks)   (no energy bias),
       * every block within max(6 rms(d_ref), 1.5 max|d_ref|) + 3 % of its value (no local bias beyond the noise's own tail)."""
     need_gpu(pkg)
     if case.startswith("mix:"):
@@ -444,7 +444,9 @@ def test_allow_listed_cases_converge_to_the_oracle(pkg, scenes, oracle, case):
     m = dict(rms_ref=rms_ref, rms_dev=rms_dev, mean_dev=float(d_dev.mean()), mean_ref=float(d_ref.mean()), level=float(bo_b.mean()), blocks=nb)
     record_case("converged:" + case, dict(frac=1.0, mean_l2=rms_dev, maxabs=float(np.abs(d_dev).max())), False, m)
     assert rms_ref > 0 and rms_dev <= 1.25 * rms_ref + 1e-4, m
-    assert abs(m["mean_dev"]) <= 4 * rms_ref / np.sqrt(nb) + 1e-4, m
+    # energy: with the SAME seed the two differ only on the few paths a last bit flips, so their means agree far inside the noise of either
+    # (the oracle's own two seeds can differ by more than that: heavy tails)
+    assert abs(m["mean_dev"] - m["mean_ref"]) <= 4 * rms_ref / np.sqrt(nb) + 1e-4, m
     # Monte-Carlo noise of these scenes is heavy-tailed (a block that caught a caustic path): the oracle's own worst block sets the scale
     worst_ref = float(np.abs(d_ref).max())
     assert np.all(np.abs(d_dev) <= max(6 * rms_ref, 1.5 * worst_ref) + 0.03 * np.abs(bo_b) + 1e-3), (m, float(np.abs(d_dev).max()), worst_ref)
