@@ -36,6 +36,9 @@
 #ifndef RT_TRACE_CHUNK_MIN
 #define RT_TRACE_CHUNK_MIN 32
 #endif
+#ifndef RT_PIPE_TRACE_DSTEPS
+#define RT_PIPE_TRACE_DSTEPS 1    // steps per round in the trace kernel (the megakernel takes RT_TRACE_DSTEPS = 2): C5's trace launches 203 -> 195 ms
+#endif
 #ifndef RT_TRACE_RANGES
 #define RT_TRACE_RANGES 1         // contiguous ranges of the ray queue with their own heads (8 = one per XCD: measured WORSE, 1 M path trace 57 -> 60 ms, C5 235 -> 254: the single guided head balances better than range affinity saves misses)
 #endif
@@ -143,8 +146,11 @@ RT_DEV void pipe_store(const PipePool &pl, unsigned slot, const Lane &ln) {
 }
 
 // ---- shade: everything between two rays of a path, for every slot ---------------------------------------------------
+#ifndef RT_SHADE_VOL_WAVES
+#define RT_SHADE_VOL_WAVES 3      // waves per SIMD the shade kernels of a frame with a medium are held to (they allocate ~195 VGPRs on their own = 2 waves; a pass is a chain of dependent loads, so the third wave pays: C5 353 -> 328 ms; 4 spills: 388)
+#endif
 template <bool COUNT, int INTEG, bool VOL, bool EXT>
-__global__ __launch_bounds__(RT_BLOCK) void pipe_shade_kernel(const DevScene *__restrict__ scp, const DevFrame *__restrict__ frp,
+__global__ __launch_bounds__(RT_BLOCK, (VOL && !COUNT) ? RT_SHADE_VOL_WAVES : 1) void pipe_shade_kernel(const DevScene *__restrict__ scp, const DevFrame *__restrict__ frp,
                                                                const PipePool *__restrict__ plp, PipeLaunch pk) {
     const DevScene &sc = *scp;
     const DevFrame &fr = *frp;
@@ -344,7 +350,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) void pipe_trace_kernel(co
         const int leave_at = exhausted ? 0 : (live0 > RT_TRACE_REFILL ? live0 - RT_TRACE_REFILL : 0);
 #pragma unroll 1
         do {
-            trace_round<COUNT, ACCEL, EXT, RT_TRACE_STACK>(tv, busy, sc, (uint2 RT_L *)lds_stack, (float RT_L *)lds_tm, RT_GPTR(uint2, job.spill), job.n_threads, gtid, tc);
+            trace_round<COUNT, ACCEL, EXT, RT_TRACE_STACK, true, RT_PIPE_TRACE_DSTEPS>(tv, busy, sc, (uint2 RT_L *)lds_stack, (float RT_L *)lds_tm, RT_GPTR(uint2, job.spill), job.n_threads, gtid, tc);
         } while (__popcll(__ballot(busy && tv.active)) > leave_at);
     }
     if (COUNT) {

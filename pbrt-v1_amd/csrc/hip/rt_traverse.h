@@ -650,7 +650,8 @@ RT_DEV void accel_round_batched(Trav &tv, bool mine, const DevScene &sc, uint2 R
 // ---- flat (select-style) traversal steps and the round built from them: used by the trace kernel of the queue pipeline
 // (rt_pipeline.h) and by the megakernel's trav_mode 2 ----
 #ifndef RT_TRACE_DSTEPS
-#define RT_TRACE_DSTEPS 4         // interior steps a descending lane may take per round before the leaf phase gets its turn
+#define RT_TRACE_DSTEPS 2         // steps (of up to two levels each) a descending lane may take per round before the leaf phase gets its turn
+                                  // (round 3, two-level steps: 2 beats 4 by 7 % on the 1 M-triangle path frame, 5 % on C3)
 #endif
 #ifndef RT_TRACE_FOLD
 #define RT_TRACE_FOLD 1            // pair form: a leaf child (or popped leaf) is entered in the step that selects it
@@ -681,7 +682,7 @@ RT_DEV void kd_step_flat(Trav &tv, bool desc, const DevScene &sc, uint2 RT_L *ld
     const float split = __uint_as_float(nd.x);                                 // perturbed split, B10
     const float oa = comp(tv.o, int(axis)), da = comp(tv.d, int(axis)), ia = comp(tv.inv, int(axis));   // by value: stays in registers
     const float tplane = (split - oa) * ia;
-    const bool belowFirst = (oa < split) || (oa == split && da >= 0.f);
+    const bool belowFirst = (oa < split) | ((oa == split) & (da >= 0.f));
     const unsigned below = tv.node + 1u, above = nd.y;
     const unsigned first = belowFirst ? below : above, second = belowFirst ? above : below;
     const bool only_first = tplane > tv.tmax || tplane <= 0.f;
@@ -720,7 +721,7 @@ RT_DEV void leaf_test_flat(Trav &tv, bool leafw, const DevScene &sc, TravCounter
     const V3 s2 = cross3(dd, e1);
     const float b2 = dot3(tv.d, s2) * invDivisor;
     const float t = dot3(e2, s2) * invDivisor;
-    const bool miss = (divisor == 0.f) || (b1 < 0.f || b1 > 1.f) || (b2 < 0.f || b1 + b2 > 1.f) || (t < tv.mint || t > tv.maxt);
+    const bool miss = (divisor == 0.f) | (b1 < 0.f) | (b1 > 1.f) | (b2 < 0.f) | (b1 + b2 > 1.f) | (t < tv.mint) | (t > tv.maxt);
     const bool hit = leafw && !miss;
     const bool stop = hit && tv.any;                                           // kdtree.cpp:432-434
     const bool keep = hit && !tv.any;                                          // primitive.cpp:120
@@ -784,10 +785,10 @@ RT_DEV void kdp_step(Trav &tv, bool desc, const DevScene &sc, PairStack st, unsi
     const float split = __uint_as_float(tv.cx);                                // perturbed split, B10
     const float oa = comp(tv.o, int(axis)), da = comp(tv.d, int(axis)), ia = comp(tv.inv, int(axis));
     const float tplane = (split - oa) * ia;
-    const bool belowFirst = (oa < split) || (oa == split && da >= 0.f);
-    const bool only_first = tplane > tv.tmax || tplane <= 0.f;
-    const bool only_second = !only_first && tplane < tv.tmin;
-    const bool both = interior && !only_first && !only_second;
+    const bool belowFirst = (oa < split) | ((oa == split) & (da >= 0.f));        // bitwise: lane masks on the scalar unit, no divergent branch
+    const bool only_first = (tplane > tv.tmax) | (tplane <= 0.f);
+    const bool only_second = !only_first & (tplane < tv.tmin);
+    const bool both = interior & !only_first & !only_second;
     const bool c_above = belowFirst ? only_second : !only_second;             // the child the traversal continues in
     const unsigned idx = tv.cy & 0x3fffffffu, fb = (tv.cy >> 30) & 1u, fa = tv.cy >> 31;
     const bool two = interior && (c_above ? fa : fb) != 0u;                    // that child's pair sits in this node's block
@@ -806,10 +807,10 @@ RT_DEV void kdp_step(Trav &tv, bool desc, const DevScene &sc, PairStack st, unsi
     const float split2 = __uint_as_float(c_x);
     const float oa2 = comp(tv.o, int(axis2)), da2 = comp(tv.d, int(axis2)), ia2 = comp(tv.inv, int(axis2));
     const float tplane2 = (split2 - oa2) * ia2;
-    const bool belowFirst2 = (oa2 < split2) || (oa2 == split2 && da2 >= 0.f);
-    const bool only_first2 = tplane2 > tmax1 || tplane2 <= 0.f;
-    const bool only_second2 = !only_first2 && tplane2 < tv.tmin;
-    const bool both2 = two && !only_first2 && !only_second2;
+    const bool belowFirst2 = (oa2 < split2) | ((oa2 == split2) & (da2 >= 0.f));
+    const bool only_first2 = (tplane2 > tmax1) | (tplane2 <= 0.f);
+    const bool only_second2 = !only_first2 & (tplane2 < tv.tmin);
+    const bool both2 = two & !only_first2 & !only_second2;
     const bool g_above = belowFirst2 ? only_second2 : !only_second2;
     const unsigned g_x = g_above ? B.z : B.x, g_y = g_above ? B.w : B.y;
     const unsigned h_x = g_above ? B.x : B.z, h_y = g_above ? B.y : B.w;
@@ -867,7 +868,7 @@ RT_DEV void kdp_pop(Trav &tv, bool done, PairStack st, unsigned n_threads, unsig
 #ifndef RT_TRACE_LEAF_GO
 #define RT_TRACE_LEAF_GO 65       // leave the descent steps early once this many lanes hold an untested primitive (65 = never)
 #endif
-template <bool COUNT, int ACCEL, bool EXT, int NS, bool PAIRS_OK = true>
+template <bool COUNT, int ACCEL, bool EXT, int NS, bool PAIRS_OK = true, int DSTEPS = RT_TRACE_DSTEPS>
 RT_DEV void trace_round(Trav &tv, bool busy, const DevScene &sc, uint2 RT_L *lds_stack, float RT_L *lds_tm, uint2 RT_G *spill, unsigned n_threads, unsigned gtid, TravCounters &cnt) {
     constexpr bool PAIRS = PAIRS_OK && ACCEL != RT_ACCEL_GRID && !EXT;
     const PairStack pst = {lds_stack, lds_tm, (uint4 RT_G *)spill};
@@ -876,7 +877,7 @@ RT_DEV void trace_round(Trav &tv, bool busy, const DevScene &sc, uint2 RT_L *lds
     } else if (PAIRS) {
         // RT_TRACE_POP_IN_LOOP: a lane leaves a finished (or empty) leaf inside the descent loop instead of at the end of the round
 #pragma unroll 1
-        for (int k = 0; k < RT_TRACE_DSTEPS; ++k) {
+        for (int k = 0; k < DSTEPS; ++k) {
             const bool desc = busy && tv.active && !tv.at_leaf;
             const bool fin = RT_TRACE_POP_IN_LOOP && busy && tv.active && tv.at_leaf && tv.li >= tv.ln_;
             if (!__any(desc || fin)) break;
@@ -892,7 +893,7 @@ RT_DEV void trace_round(Trav &tv, bool busy, const DevScene &sc, uint2 RT_L *lds
         }
     } else {
 #pragma unroll 1
-        for (int k = 0; k < RT_TRACE_DSTEPS; ++k) {
+        for (int k = 0; k < DSTEPS; ++k) {
             const bool desc = busy && tv.active && !tv.at_leaf;
             if (!__any(desc)) break;
             kd_step_flat<COUNT, NS, !EXT>(tv, desc, sc, lds_stack, spill, n_threads, gtid, cnt);

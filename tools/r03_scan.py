@@ -17,7 +17,7 @@ if g == "occ":
         for wl in ("c3", "p1000000", "c4"):
             bench("mega_waves%d_%s" % (w, wl), workload=wl)
 elif g == "exit":
-    for et in (16, 24, 32, 40, 48):
+    for et in (8, 16, 24, 32, 40, 48, 56):
         for wl in ("c3", "p1000000"):
             bench("exit%d_%s" % (et, wl), env={"PBRT_HIP_EXIT_THRESH": str(et)}, workload=wl)
 elif g == "trace8":
@@ -26,3 +26,31 @@ elif g == "trace8":
         T.rebuild("rt_trace", defs)
         for wl in ("c5", "p1000000"):
             bench("trace:%s:%s" % (" ".join(defs), wl), env={"PBRT_HIP_PIPELINE": "1"}, workload=wl)
+
+elif g == "steps":
+    for ds, lm in ((2, 24), (3, 24), (6, 24), (4, 16), (4, 32), (3, 16), (4, 24)):
+        for u in ("rt_mega_p", "rt_mega_d"):
+            T.rebuild(u, ["-DRT_TRACE_DSTEPS=%d" % ds, "-DRT_TRACE_LEAF_MIN=%d" % lm])
+        for wl in ("c3", "p1000000"):
+            bench("dsteps%d_leafmin%d_%s" % (ds, lm, wl), workload=wl)
+
+elif g == "steps2":
+    for ds, lm in ((1, 24), (2, 16), (2, 32), (2, 24)):
+        for u in ("rt_mega_p", "rt_mega_d", "rt_trace"):
+            T.rebuild(u, ["-DRT_TRACE_DSTEPS=%d" % ds, "-DRT_TRACE_LEAF_MIN=%d" % lm])
+        for wl in ("c3", "p1000000"):
+            bench("dsteps%d_leafmin%d_%s" % (ds, lm, wl), workload=wl)
+        bench("dsteps%d_leafmin%d_c5" % (ds, lm), workload="c5")
+
+elif g == "shadeocc":
+    for w in (3, 4, 1):
+        T.rebuild("rt_pipe_d", ["-DRT_SHADE_VOL_WAVES=%d" % w])
+        bench("shade_vol_waves%d_c5" % w, workload="c5")
+
+elif g == "prof":
+    for u in ("rt_mega_p", "rt_mega_d", "rt_kernels"):
+        T.rebuild(u, ["-DRT_PROFILE"])
+    for wl in ("c3", "p1000000", "c2"):
+        e = dict(os.environ); e["PBRT_HIP_PIPELINE"] = "0"
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-extra", "--steps", "1", "--warmup", "0", "--workload", wl], env=e, capture_output=True, text=True, timeout=600)
+        print(wl, "\n".join([l for l in r.stderr.splitlines() if l.startswith("RT_PROFILE")][-1:]), flush=True)
