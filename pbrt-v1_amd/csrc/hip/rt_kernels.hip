@@ -21,6 +21,8 @@
 #include <string>
 #include <vector>
 #include <cmath>
+#include <chrono>
+#include <thread>
 
 namespace rt {
 
@@ -312,7 +314,7 @@ static void host_tri_frame(const float *v, bool flip, float nn[3], float sn[3]) 
 static void build_leaf_order(const std::vector<Node> &nodes, const std::vector<uint32_t> &leaf_refs, const std::vector<DevTri> &tris,
                              std::vector<Node> &tnodes, std::vector<float4> &ltris) {
     tnodes = nodes;
-    ltris.clear();
+    // pass 1 (sequential, arithmetic only): where every leaf's run starts
     size_t off = 0;                                       // float4 units (16 B); a line is 8 units
     for (size_t i = 0; i < nodes.size(); ++i) {
         const Node &n = nodes[i];
@@ -322,16 +324,33 @@ static void build_leaf_order(const std::vector<Node> &nodes, const std::vector<u
         const size_t units = size_t(np) * 3;
         const size_t lines_here = (off % 8 + units + 7) / 8, lines_min = (units + 7) / 8;
         if (lines_here > lines_min) off = (off + 7) / 8 * 8;
-        ltris.resize(off + units, make_float4(0.f, 0.f, 0.f, 0.f));
-        for (uint32_t k = 0; k < np; ++k) {
-            const uint32_t prim = np == 1 ? n.y : leaf_refs[n.y + k];
-            float4 q2 = tris[prim].q2; std::memcpy(&q2.w, &prim, 4);
-            ltris[off + 3 * k] = tris[prim].q0; ltris[off + 3 * k + 1] = tris[prim].q1; ltris[off + 3 * k + 2] = q2;
-        }
-        tnodes[i].y = uint32_t(off);
+        tnodes[i].y = uint32_t(off);                     // (a run beyond 2^32 units is refused by the caller through ltris.size())
         off += units;
     }
-    if (ltris.empty()) ltris.resize(8, make_float4(0.f, 0.f, 0.f, 0.f));
+    if (off >= (size_t(1) << 32)) { ltris.assign(off, make_float4(0.f, 0.f, 0.f, 0.f)); return; }
+    ltris.assign(off ? off : 8, make_float4(0.f, 0.f, 0.f, 0.f));
+    // pass 2 (parallel over node ranges: 10 M triangles are 250 M nodes and 200 M records): copy the records
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const size_t nthreads = nodes.size() < (size_t(1) << 20) ? 1 : hw;
+    auto fill = [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            const Node &n = nodes[i];
+            if ((n.x & 3u) != 3u) continue;
+            const uint32_t np = n.x >> 2;
+            float4 *dst = ltris.data() + tnodes[i].y;
+            for (uint32_t k = 0; k < np; ++k) {
+                const uint32_t prim = np == 1 ? n.y : leaf_refs[n.y + k];
+                float4 q2 = tris[prim].q2; std::memcpy(&q2.w, &prim, 4);
+                dst[3 * k] = tris[prim].q0; dst[3 * k + 1] = tris[prim].q1; dst[3 * k + 2] = q2;
+            }
+        }
+    };
+    if (nthreads == 1) fill(0, nodes.size());
+    else {
+        std::vector<std::thread> pool;
+        for (size_t t = 0; t < nthreads; ++t) pool.emplace_back(fill, nodes.size() * t / nthreads, nodes.size() * (t + 1) / nthreads);
+        for (auto &th : pool) th.join();
+    }
 }
 
 // Triangle::Intersect's frame with the mesh's own uvs (trianglemesh.cpp:248-268 incl. the zero-determinant fallback through
@@ -451,11 +470,20 @@ static void build_pair_blocks(const std::vector<Node> &tn, std::vector<uint4> &p
         return y;
     };
     pairs.resize(order.size());
-    for (size_t i = 0; i < order.size(); ++i) {
-        const uint32_t P = order[i];
-        if (P == ~0u) { pairs[i] = make_uint4(3u, 0u, 3u, 0u); continue; }
-        const uint32_t b = P + 1u, a = tn[P].y;
-        pairs[i] = make_uint4(tn[b].x, word1(b), tn[a].x, word1(a));
+    auto fill = [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            const uint32_t P = order[i];
+            if (P == ~0u) { pairs[i] = make_uint4(3u, 0u, 3u, 0u); continue; }
+            const uint32_t b = P + 1u, a = tn[P].y;
+            pairs[i] = make_uint4(tn[b].x, word1(b), tn[a].x, word1(a));
+        }
+    };
+    const size_t nthreads = order.size() < (size_t(1) << 20) ? 1 : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    if (nthreads == 1) fill(0, order.size());
+    else {
+        std::vector<std::thread> pool;
+        for (size_t t = 0; t < nthreads; ++t) pool.emplace_back(fill, order.size() * t / nthreads, order.size() * (t + 1) / nthreads);
+        for (auto &th : pool) th.join();
     }
     root_y = word1(0u);
 }
@@ -735,6 +763,13 @@ static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel 
     HIPCHK(hipEventCreate(&s->ev0)); HIPCHK(hipEventCreate(&s->ev1));
     s->n_tris = d->n_tris;
 
+    const bool tlog = std::getenv("PBRT_HIP_CREATE_LOG") != nullptr;           // where a scene create spends its time (10 M triangles: a minute)
+    auto t_prev = std::chrono::steady_clock::now();
+    auto tick = [&](const char *what) {
+        if (!tlog) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "CREATE %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_prev).count()); t_prev = now;
+    };
     s->accel_kind = d->accel.kind;
     if (pre) {
         const Node *pn = reinterpret_cast<const Node *>(pre->nodes);
@@ -752,6 +787,7 @@ static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel 
         std::memcpy(s->tree.bounds, s->gridacc.bounds, sizeof s->tree.bounds); s->tree.build_seconds = s->gridacc.build_seconds;
     } else build_kdtree(d->tri_verts, d->n_tris, d->accel, s->tree);
 
+    tick("accelerator");
     // triangles -> 48-byte records
     std::vector<DevTri> tris(d->n_tris);
     uint32_t n_quadric_slots = 0;
@@ -830,6 +866,7 @@ static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel 
         }
         if ((rc = upload(s, dq.data(), dq.size(), &s->dev.quadrics))) return rc;
     }
+    tick("triangle / shading records");
     const uint2 *nodes_dev = nullptr;
     {   // one node of padding: the traversal may fetch node i+1 together with node i
         std::vector<uint2> padded(s->tree.nodes.size() + 1);
@@ -841,7 +878,9 @@ static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel 
     s->dev.tnodes = nodes_dev;
     if (s->accel_kind == RT_ACCEL_KDTREE) {
         std::vector<Node> tn; std::vector<float4> lt;
+        tick("node upload");
         build_leaf_order(s->tree.nodes, s->tree.leaf_refs, tris, tn, lt);
+        tick("leaf-ordered records");
         if (lt.size() >= (size_t(1) << 32)) return fail(RT_EINVAL, "rt_scene_create: leaf-ordered triangle array beyond 2^32 float4 units");
         tn.push_back(Node{3u, 0u});
         const Node *tdev = nullptr;
@@ -857,11 +896,14 @@ static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel 
         if (const char *e = std::getenv("PBRT_HIP_TREELET_ALIGN")) align = std::atoi(e) != 0;
         bool blocks = true;
         if (const char *e = std::getenv("PBRT_HIP_PAIR_BLOCKS")) blocks = std::atoi(e) != 0;                             // layout experiments
+        tick("leaf-order upload");
         if (blocks) build_pair_blocks(tn, pairs, s->dev.root_x, s->dev.root_y);
         else build_pairs(tn, pairs, s->dev.root_x, s->dev.root_y, treelet, align);
         if (pairs.empty() || pairs.size() >= (size_t(1) << 30)) return fail(RT_EINVAL, "rt_scene_create: pair records beyond 2^30");
         if (std::getenv("PBRT_HIP_TREELET_LOG")) std::fprintf(stderr, "TREELET blocks=%d pairs=%d align=%d interior_nodes=%zu records=%zu\n", int(blocks), treelet, int(align), tn.size() / 2, pairs.size());
+        tick("pair blocks");
         if ((rc = upload(s, pairs.data(), pairs.size(), &s->dev.tpairs))) return rc;
+        tick("pair upload");
     }
     if ((rc = upload(s, s->tree.leaf_refs.data(), s->tree.leaf_refs.size(), &s->dev.leaf_refs))) return rc;
 
