@@ -656,6 +656,10 @@ RT_DEV void accel_round_batched(Trav &tv, bool mine, const DevScene &sc, uint2 R
 #ifndef RT_TRACE_FOLD
 #define RT_TRACE_FOLD 1            // pair form: a leaf child (or popped leaf) is entered in the step that selects it
 #endif
+#ifndef RT_STEP_REGION
+#define RT_STEP_REGION 0           // bits 1 / 2 / 4: kdp_step / leaf_test_flat / kdp_pop as ONE predicated region each instead of select-style code: 9 % fewer static VALU
+                                  // instructions in the trace kernel and measurably slower (round 3: 1 M path 64.4 -> 68.9 ms, C5 trace 195 -> 205 ms)
+#endif
 #ifndef RT_TRACE_LEAF_MIN
 #define RT_TRACE_LEAF_MIN 24      // keep testing primitives while at least this many lanes have one left
 #endif
@@ -702,13 +706,38 @@ RT_DEV void kd_step_flat(Trav &tv, bool desc, const DevScene &sc, uint2 RT_L *ld
 template <bool COUNT>
 RT_DEV void leaf_test_flat(Trav &tv, bool leafw, const DevScene &sc, TravCounters &cnt) {
     // leaf-ordered records (DevScene::ltris): primitive li of this leaf sits 3 * li float4s behind the leaf's first
+#ifdef RT_PROBE_UTIL
+    if (COUNT) cnt.tris += 1u;
+#endif
+#if (RT_STEP_REGION & 2)
+    if (leafw) {                                                               // one predicated region (see kdp_step)
+        const float4 RT_G *gt = RT_GPTR(const float4, sc.ltris) + (size_t(tv.ly) + 3u * tv.li);
+        const float4 q0 = gt[0], q1 = gt[1], q2 = gt[2];
+#ifndef RT_PROBE_UTIL
+        if (COUNT) { cnt.tris += 1u; cnt.leaf_refs += tv.ln_ != 1u ? 1u : 0u; }
+#endif
+        tv.li += 1u;
+        const V3 p1 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
+        const V3 s1 = cross3(tv.d, e2);
+        const float divisor = dot3(s1, e1);
+        const float invDivisor = 1.f / divisor;
+        const V3 dd = tv.o - p1;
+        const float b1 = dot3(dd, s1) * invDivisor;
+        const V3 s2 = cross3(dd, e1);
+        const float b2 = dot3(tv.d, s2) * invDivisor;
+        const float t = dot3(e2, s2) * invDivisor;
+        const bool miss = (divisor == 0.f) | (b1 < 0.f) | (b1 > 1.f) | (b2 < 0.f) | (b1 + b2 > 1.f) | (t < tv.mint) | (t > tv.maxt);
+        if (!miss) {
+            if (tv.any) { tv.hit_prim = 0; tv.active = false; }                // kdtree.cpp:432-434
+            else { tv.hit_prim = int(__float_as_uint(q2.w)); tv.maxt = t; tv.b1 = b1; tv.b2 = b2; }   // primitive.cpp:120
+        }
+    }
+#else
     const bool single = tv.ln_ == 1u;
     float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
     if (leafw) { const float4 RT_G *gt = RT_GPTR(const float4, sc.ltris) + (size_t(tv.ly) + 3u * tv.li); q0 = gt[0]; q1 = gt[1]; q2 = gt[2]; }
     const unsigned prim = __float_as_uint(q2.w);
-#ifdef RT_PROBE_UTIL
-    if (COUNT) cnt.tris += 1u;
-#else
+#ifndef RT_PROBE_UTIL
     if (COUNT) { cnt.tris += leafw ? 1u : 0u; cnt.leaf_refs += (leafw && !single) ? 1u : 0u; }
 #endif
     tv.li += leafw ? 1u : 0u;
@@ -730,6 +759,7 @@ RT_DEV void leaf_test_flat(Trav &tv, bool leafw, const DevScene &sc, TravCounter
     tv.b1 = keep ? b1 : tv.b1;
     tv.b2 = keep ? b2 : tv.b2;
     tv.active = stop ? false : tv.active;
+#endif
 }
 template <int NS>
 RT_DEV void kd_pop_flat(Trav &tv, bool done, const uint2 RT_L *lds_stack, const uint2 RT_G *spill, unsigned n_threads, unsigned gtid) {
@@ -778,8 +808,60 @@ RT_DEV void kdp_step(Trav &tv, bool desc, const DevScene &sc, PairStack st, unsi
 #else
     if (COUNT) cnt.nodes += go ? 1u : 0u;
 #endif
+    tv.active = dead ? false : tv.active;
+    const bool leaf = (tv.cx & 3u) == 3u;                                      // only ever a root that is a leaf
+#if (RT_STEP_REGION & 1)
+    // ONE predicated region for the lanes that really step (the others keep their registers: no dummy operands, no "x = stepping ? new : x"
+    // selects); inside it the code is still straight-line with selects
+    if (go && !leaf) {
+        const unsigned axis = tv.cx & 3u;
+        const float split = __uint_as_float(tv.cx);                            // perturbed split, B10
+        const float oa = comp(tv.o, int(axis)), da = comp(tv.d, int(axis)), ia = comp(tv.inv, int(axis));
+        const float tplane = (split - oa) * ia;
+        const bool belowFirst = (oa < split) | ((oa == split) & (da >= 0.f));
+        const bool only_first = (tplane > tv.tmax) | (tplane <= 0.f);
+        const bool only_second = !only_first & (tplane < tv.tmin);
+        const bool both = !only_first & !only_second;
+        const bool c_above = belowFirst ? only_second : !only_second;         // the child the traversal continues in
+        const unsigned idx = tv.cy & 0x3fffffffu, fb = (tv.cy >> 30) & 1u, fa = tv.cy >> 31;
+        const bool two = (c_above ? fa : fb) != 0u;                            // that child's pair sits in this node's block
+        const uint4 RT_G *p = RT_GPTR(const uint4, sc.tpairs) + idx;
+        const uint4 A = p[0];
+        uint4 B = A;
+        if (two) B = p[c_above ? 1u + fb : 1u];
+        const unsigned c_x = c_above ? A.z : A.x, c_y = c_above ? A.w : A.y;
+        const unsigned f_x = c_above ? A.x : A.z, f_y = c_above ? A.y : A.w;
+        if (both) kdp_push<COUNT, NS>(tv, st, f_x, f_y, tv.tmax, n_threads, gtid, cnt);
+        const float tmax1 = both ? tplane : tv.tmax;
+        tv.cx = c_x; tv.cy = c_y; tv.tmax = tmax1;
+        if (two) {                                                             // the chosen child is interior and its pair is B
+            const unsigned axis2 = c_x & 3u;
+            const float split2 = __uint_as_float(c_x);
+            const float oa2 = comp(tv.o, int(axis2)), da2 = comp(tv.d, int(axis2)), ia2 = comp(tv.inv, int(axis2));
+            const float tplane2 = (split2 - oa2) * ia2;
+            const bool belowFirst2 = (oa2 < split2) | ((oa2 == split2) & (da2 >= 0.f));
+            const bool only_first2 = (tplane2 > tmax1) | (tplane2 <= 0.f);
+            const bool only_second2 = !only_first2 & (tplane2 < tv.tmin);
+            const bool both2 = !only_first2 & !only_second2;
+            const bool g_above = belowFirst2 ? only_second2 : !only_second2;
+            const unsigned g_x = g_above ? B.z : B.x, g_y = g_above ? B.w : B.y;
+            const unsigned h_x = g_above ? B.x : B.z, h_y = g_above ? B.y : B.w;
+            if (both2) kdp_push<COUNT, NS>(tv, st, h_x, h_y, tmax1, n_threads, gtid, cnt);
+#ifndef RT_PROBE_UTIL
+            if (COUNT) cnt.nodes += 1u;
+#endif
+            tv.cx = g_x; tv.cy = g_y; tv.tmax = both2 ? tplane2 : tmax1;
+        }
+        if (RT_TRACE_FOLD && (tv.cx & 3u) == 3u) {                             // a leaf child is entered in the step that selects it
+#ifndef RT_PROBE_UTIL
+            if (COUNT) cnt.nodes += 1u;
+#endif
+            tv.at_leaf = true; tv.li = 0u; tv.ln_ = tv.cx >> 2; tv.ly = tv.cy;
+        }
+    }
+    if (go && leaf) { tv.at_leaf = true; tv.li = 0u; tv.ln_ = tv.cx >> 2; tv.ly = tv.cy; }
+#else
     const unsigned axis = tv.cx & 3u;
-    const bool leaf = axis == 3u;
     const bool interior = go && !leaf;
     // ---- level 1: decided from the words in hand
     const float split = __uint_as_float(tv.cx);                                // perturbed split, B10
@@ -831,10 +913,34 @@ RT_DEV void kdp_step(Trav &tv, bool desc, const DevScene &sc, PairStack st, unsi
     tv.li = enter ? 0u : tv.li;
     tv.ln_ = enter ? (tv.cx >> 2) : tv.ln_;
     tv.ly = enter ? tv.cy : tv.ly;
-    tv.active = dead ? false : tv.active;
+#endif
 }
 template <bool COUNT, int NS>
 RT_DEV void kdp_pop(Trav &tv, bool done, PairStack st, unsigned n_threads, unsigned gtid, TravCounters &cnt) {
+#if (RT_STEP_REGION & 4)
+    if (done) {
+        tv.at_leaf = false;
+        if (tv.sp > 0) {
+            --tv.sp;
+            const unsigned r = (unsigned(tv.sp) % NS) * RT_BLOCK + threadIdx.x;
+            const volatile uint2 RT_L *px = (const volatile uint2 RT_L *)st.xy + r;
+            const volatile float RT_L *pt = (const volatile float RT_L *)st.tm + r;
+            unsigned ex = px->x, ey = px->y; float et = *pt;
+            if (tv.sp < tv.sbase) { const uint4 e = st.spill[size_t(tv.sp) * n_threads + gtid]; ex = e.x; ey = e.y; et = __uint_as_float(e.z); tv.sbase = tv.sp; }
+            tv.cx = ex; tv.cy = ey; tv.tmin = tv.tmax; tv.tmax = et;
+            // the popped node's words are in hand: the reference's next iteration checks maxt < tmin (kdtree.cpp:330) and, for a leaf, is in it
+            if (RT_TRACE_FOLD) {
+                if (!tv.any && tv.maxt < tv.tmin) tv.active = false;
+                else if ((ex & 3u) == 3u) {
+#ifndef RT_PROBE_UTIL
+                    if (COUNT) cnt.nodes += 1u;
+#endif
+                    tv.at_leaf = true; tv.li = 0u; tv.ln_ = ex >> 2; tv.ly = ey;
+                }
+            }
+        } else tv.active = false;
+    }
+#else
     const bool pop = done && tv.sp > 0;
     unsigned ex = 0, ey = 0; float et = 0.f;
     if (pop) {
@@ -860,6 +966,7 @@ RT_DEV void kdp_pop(Trav &tv, bool done, PairStack st, unsigned n_threads, unsig
     tv.ln_ = enter ? (ex >> 2) : tv.ln_;
     tv.ly = enter ? ey : tv.ly;
     tv.active = (done && (!pop || dead)) ? false : tv.active;
+#endif
 }
 
 #ifndef RT_TRACE_POP_IN_LOOP

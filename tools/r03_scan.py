@@ -54,3 +54,11 @@ elif g == "prof":
         e = dict(os.environ); e["PBRT_HIP_PIPELINE"] = "0"
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-extra", "--steps", "1", "--warmup", "0", "--workload", wl], env=e, capture_output=True, text=True, timeout=600)
         print(wl, "\n".join([l for l in r.stderr.splitlines() if l.startswith("RT_PROFILE")][-1:]), flush=True)
+
+elif g == "region":
+    for m in (2, 4, 6, 0):
+        for u in ("rt_mega_p", "rt_mega_d", "rt_trace"):
+            T.rebuild(u, ["-DRT_STEP_REGION=%d" % m])
+        for wl in ("c3", "p1000000"):
+            bench("region%d_%s" % (m, wl), workload=wl)
+        bench("region%d_c5" % m, workload="c5")
