@@ -62,3 +62,11 @@ elif g == "region":
         for wl in ("c3", "p1000000"):
             bench("region%d_%s" % (m, wl), workload=wl)
         bench("region%d_c5" % m, workload="c5")
+
+elif g == "vote":
+    for vd, vt in ((8, 0), (16, 0), (0, 16), (0, 32), (8, 24), (0, 0)):
+        for u in ("rt_mega_p", "rt_mega_d", "rt_trace"):
+            T.rebuild(u, ["-DRT_TRACE_VOTE_D=%d" % vd, "-DRT_TRACE_VOTE_T=%d" % vt])
+        for wl in ("c3", "p1000000"):
+            bench("voteD%d_T%d_%s" % (vd, vt, wl), workload=wl)
+        bench("voteD%d_T%d_c5" % (vd, vt), workload="c5")
