@@ -103,7 +103,7 @@ struct DevFrame {
     float fxw, fyw, inv_fxw, inv_fyw;
     const float *filter_table;   // 256 floats in HBM (L1/L2 resident)
     float *accum;                // 5 planes
-    float4 *samples;             // per-shard sample buffer, 2 x float4 per work item
+    float4 *samples;             // per-shard sample buffer, 2 x float4 per work item, laid out by sample_slot()
     int shard_index, shard_count, tile_pixels;
     int tile_w, tile_h, tiles_x;   // 2-D tiles (RtRenderDesc.tile_pixels < 0): tile_w x tile_h pixel blocks of the sample extent, tiles_x of them per row;
                                    // tile_pixels = tile_w * tile_h then.  tile_w == 0: tiles of tile_pixels consecutive pixels in scanline order
@@ -146,5 +146,15 @@ typedef const DevLight RT_G &LightRef;
 #define RT_MAT(sc, i) (*((const DevMaterial RT_G *)(sc).materials + (i)))
 #define RT_LIGHT(sc, i) (*((const DevLight RT_G *)(sc).lights + (i)))
 #define RT_GPTR(T, p) ((T RT_G *)(p))
+
+// Sample-buffer layout (round 3).  Work item w of a shard is sample s = w % spp of the shard's local pixel lp = w / spp (local pixels
+// follow the shard's tiles in order, so on one rank lp is the pixel's scanline index).  64 consecutive local pixels form a chunk stored
+// [sample][L.rgb+alpha | imageX, imageY, -, -][pixel in chunk]: the 64 lanes of a film-gather wave, which sit on 64 consecutive
+// pixels of a row and read the same sample slot of each, fetch 1 KB of consecutive float4s per load instead of 64 separate lines.
+// Returns the float4 index of the L record; the image-position record is RT_SAMPLE_XY float4s further.
+#define RT_SAMPLE_XY 64
+__host__ __device__ inline unsigned long long sample_slot(unsigned lp, unsigned s, int spp) {
+    return ((unsigned long long)(lp >> 6) * unsigned(spp) + s) * 128ull + (lp & 63u);
+}
 
 }  // namespace rt

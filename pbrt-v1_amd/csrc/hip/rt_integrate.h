@@ -135,9 +135,10 @@ RT_DEV void sample_write(const DevFrame &fr, const Lane &ln, V3 Ls, float alpha,
     if (Ls.x != Ls.x || Ls.y != Ls.y || Ls.z != Ls.z) { Ls = mk3(0.f); ++bad; }
     else if (y < -1e-5) { Ls = mk3(0.f); ++bad; }
     else if (isinf(y)) { Ls = mk3(0.f); ++bad; }
-    float4 RT_G *rec = RT_GPTR(float4, fr.samples) + size_t(ln.work) * 2;
+    const uint32_t lp = ln.work / uint32_t(fr.spp);
+    float4 RT_G *rec = RT_GPTR(float4, fr.samples) + sample_slot(lp, ln.work - lp * uint32_t(fr.spp), fr.spp);
     rec[0] = make_float4(Ls.x, Ls.y, Ls.z, alpha);
-    rec[1] = make_float4(ln.image_x, ln.image_y, 0.f, 0.f);
+    rec[RT_SAMPLE_XY] = make_float4(ln.image_x, ln.image_y, 0.f, 0.f);
 }
 
 // ---- camera sample -> camera ray -----------------------------------------------------------------------

@@ -26,6 +26,27 @@
 
 namespace rt {
 
+// Which of this shard's local pixels (work index / spp, rt_integrate.h work_to_sample) is sample pixel (sx, sy) of the sample extent, and
+// does this shard render it at all?  1-D tiles are tile_pixels consecutive scanline pixels dealt round-robin to the shards, 2-D tiles
+// tile_w x tile_h blocks; the whole frame holds < 2^32 camera samples (make_frame), so 32-bit divisions do.
+__device__ inline void gather_local_pixel(const DevFrame &fr, int sx, int sy, bool &mine, unsigned long long &lp) {
+    const unsigned px = unsigned(sx - fr.x_start), py = unsigned(sy - fr.y_start);
+    if (fr.tile_w > 0) {
+        const unsigned tx = px / unsigned(fr.tile_w), ty = py / unsigned(fr.tile_h);
+        const unsigned tile = ty * unsigned(fr.tiles_x) + tx, lt = tile / unsigned(fr.shard_count);
+        const unsigned in_tile = (py - ty * unsigned(fr.tile_h)) * unsigned(fr.tile_w) + (px - tx * unsigned(fr.tile_w));
+        mine = int(tile - lt * unsigned(fr.shard_count)) == fr.shard_index;
+        lp = (unsigned long long)lt * unsigned(fr.tile_pixels) + in_tile;
+    } else {
+        const unsigned pixel = py * unsigned(fr.x_end - fr.x_start) + px;
+        if (fr.shard_count == 1) { mine = true; lp = pixel; return; }
+        const unsigned tile = pixel / unsigned(fr.tile_pixels), in_tile = pixel - tile * unsigned(fr.tile_pixels);
+        const unsigned lt = tile / unsigned(fr.shard_count);
+        mine = int(tile - lt * unsigned(fr.shard_count)) == fr.shard_index;
+        lp = (unsigned long long)lt * unsigned(fr.tile_pixels) + in_tile;
+    }
+}
+
 // ImageFilm::AddSample (film/image.cpp:103-142) as a gather: one thread per film pixel visits, in the reference's
 // sample order (sample-pixel rows, then columns, then sample-in-pixel), every sample of this shard whose filter
 // footprint can contain the pixel, and accumulates w*L, w*alpha, w on top of what the film already holds.  The
@@ -48,8 +69,6 @@ __global__ __launch_bounds__(256) void film_gather_kernel(const DevFrame *__rest
     // sample pixels whose samples (imageX in [sx, sx+1]) can reach pixel x: |x - (sx + u - .5)| <= width
     const int sx0 = max(int(ceilf(x - fr.fxw - 0.5f)), fr.x_start), sx1 = min(int(floorf(x + fr.fxw + 0.5f)), fr.x_end - 1);
     const int sy0 = max(int(ceilf(y - fr.fyw - 0.5f)), fr.y_start), sy1 = min(int(floorf(y + fr.fyw + 0.5f)), fr.y_end - 1);
-    const int ew = fr.x_end - fr.x_start;
-    const unsigned long long per_tile = (unsigned long long)fr.tile_pixels * fr.spp;
     const int xlo = fr.x_pixel_start, xhi = fr.x_pixel_start + fr.x_pixel_count - 1;
     const int ylo = fr.y_pixel_start, yhi = fr.y_pixel_start + fr.y_pixel_count - 1;
     const int X0 = fr.x_pixel_start + bx * 16, Y0 = fr.y_pixel_start + by * 16;
@@ -69,26 +88,8 @@ __global__ __launch_bounds__(256) void film_gather_kernel(const DevFrame *__rest
             // arithmetic once per column, not once per staged float4)
             bool mine_col = false;
             if (int(threadIdx.x) < ncols) {
-                const unsigned long long pixel = (unsigned long long)(sy - fr.y_start) * ew + (cx + int(threadIdx.x) - fr.x_start);
                 bool mine; unsigned long long base;
-                if (fr.tile_w > 0) {                                // 2-D tiles (work_to_sample, rt_integrate.h)
-                    const unsigned px = unsigned(cx + int(threadIdx.x) - fr.x_start), py = unsigned(sy - fr.y_start);
-                    const unsigned tx = px / unsigned(fr.tile_w), ty = py / unsigned(fr.tile_h);
-                    const unsigned tile = ty * unsigned(fr.tiles_x) + tx, lt = tile / unsigned(fr.shard_count);
-                    const unsigned in_tile = (py - ty * unsigned(fr.tile_h)) * unsigned(fr.tile_w) + (px - tx * unsigned(fr.tile_w));
-                    mine = int(tile - lt * unsigned(fr.shard_count)) == fr.shard_index;
-                    base = ((unsigned long long)lt * per_tile + (unsigned long long)in_tile * fr.spp) * 2;
-                } else
-                if (fr.total_pixels <= 0xffffffffull) {             // 32-bit divisions (a 64-bit one is ~150 VALU instructions)
-                    const unsigned p32 = unsigned(pixel), tile = p32 / unsigned(fr.tile_pixels), in_tile = p32 - tile * unsigned(fr.tile_pixels);
-                    const unsigned lt = tile / unsigned(fr.shard_count);
-                    mine = int(tile - lt * unsigned(fr.shard_count)) == fr.shard_index;
-                    base = ((unsigned long long)lt * per_tile + (unsigned long long)in_tile * fr.spp) * 2;
-                } else {
-                    const unsigned long long tile = pixel / fr.tile_pixels;
-                    mine = int(tile % fr.shard_count) == fr.shard_index;
-                    base = ((tile / fr.shard_count) * per_tile + (pixel % fr.tile_pixels) * fr.spp) * 2;
-                }
+                gather_local_pixel(fr, cx + int(threadIdx.x), sy, mine, base);
                 colbase[threadIdx.x] = mine ? base : ~0ull;
                 mine_col = mine;
             }
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void film_gather_kernel(const DevFrame *__rest
 #else
                 if (base != ~0ull) {
 #endif
-                    float4 q = RT_GPTR(const float4, fr.samples)[base + k];
+                    float4 q = RT_GPTR(const float4, fr.samples)[sample_slot(unsigned(base), unsigned(k) >> 1, spp) + (k & 1) * RT_SAMPLE_XY];
                     if (k & 1) {
                         // the sample's pixel footprint (film/image.cpp:108-116) depends on the sample only: computed once here by the
                         // staging thread and packed as two int16 pairs into the record's spare words, not once per pixel under it
@@ -171,6 +172,327 @@ __global__ __launch_bounds__(256) void film_gather_kernel(const DevFrame *__rest
     }
 }
 
+// ---- the film gather as a march down the image (round 3) ---------------------------------------------------------------------
+// One lane per film-pixel COLUMN of a strip of `strip_rows` rows, 64 consecutive columns per wave.  The lane walks the sample rows
+// that can reach its strip from top to bottom and keeps the accumulators of the (at most 2 ry + 1) pixel rows the current sample
+// row can touch in registers, so a sample record is fetched once (one coalesced 1 KB read per wave, sample_slot() layout) and its
+// x-footprint test and filter column index are computed once for all those rows; each row then costs its own y test, its filter
+// row index, the table look-up and the five accumulations of ImageFilm::AddSample (film/image.cpp:103-142), in the reference's
+// sample order (sample-pixel rows, columns, sample in pixel).  Every lane of the wave has the same live rows, so the loops are
+// instantiated per live-row count K and nothing is computed for rows outside the strip; 31 % of the lanes of the staged kernel
+// above did useful work (5 of a workgroup's 16 pixel rows per staged sample row), here all of them do.
+// The footprint test of image.cpp:108-116, x0 = max(Ceil2Int(dImageX - xWidth), xPixelStart) <= x <= x1 = min(Floor2Int(dImageX +
+// xWidth), xPixelStart + xPixelCount - 1), is evaluated for the integer film pixel x as (float)x >= dImageX - xWidth && (float)x <=
+// dImageX + xWidth: x >= ceil(a) <=> x >= a and x <= floor(b) <=> x <= b for an integer x, and x lies inside the film anyway.
+// A sample outside the pixel's footprint is accumulated with weight +0 instead of being skipped (no branch in the loop): x + (+-0) == x
+// for every x but -0, and an accumulator never holds -0 -- it starts at +0 and round-to-nearest addition yields -0 only from (-0) + (-0);
+// L is finite (sample_write zeroes NaN / infinite radiance as scene.cpp:60-74 does), so 0 * L is a zero.
+struct MarchBatch { float4 L[4]; float2 q[4]; };
+typedef float vfloat2 __attribute__((ext_vector_type(2)));
+
+template <int K, int RYMAX>
+__device__ __forceinline__ void march_row(const DevFrame &fr, const float RT_L *ftab, vfloat2 (&acc01)[2 * RYMAX + 1], vfloat2 (&acc23)[2 * RYMAX + 1],
+                                          float (&acc4)[2 * RYMAX + 1], bool live, int x, int sy, int wy0, int rx) {
+    const float xf = float(x), fxw = fr.fxw, fyw = fr.fyw, kx = fr.inv_fxw, ky = fr.inv_fyw;
+    const int spp = fr.spp, nbatch = (spp + 3) >> 2, ncol = 2 * rx + 1;
+    float yf[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) yf[i] = float(wy0 + i);
+    const float4 RT_G *samples = RT_GPTR(const float4, fr.samples);
+    // column j of the window: sample pixel (x - rx + j, sy); a lane whose column lies outside the sample extent or belongs to another shard
+    // reads record 0 of the buffer and weighs it 0
+    auto column = [&](int j, bool &act) __attribute__((always_inline)) -> const float4 RT_G * {
+        const int sx = x - rx + j;
+        act = live & (sx >= fr.x_start) & (sx < fr.x_end);
+        unsigned long long lp = 0;
+        if (act) { bool mine; gather_local_pixel(fr, sx, sy, mine, lp); act = mine; }
+        return samples + (act ? sample_slot(unsigned(lp), 0u, spp) : 0ull);
+    };
+    auto load = [&](MarchBatch &b, const float4 RT_G *rec, int s0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int su = min(s0 + u, spp - 1);                            // a batch past the pixel's last sample re-reads it (weight 0)
+            b.L[u] = rec[size_t(su) * 128];
+            const float4 RT_G *qp = rec + size_t(su) * 128 + RT_SAMPLE_XY;
+            b.q[u] = *(const float2 RT_G *)qp;
+        }
+    };
+    // (v * inv_w) * 16 of image.cpp:124-132 as v * (inv_w * 16): scaling by 16 commutes with the rounding of the product (no overflow here; a
+    // product small enough to underflow indexes entry 0 either way); Floor2Int of a non-negative value is the truncating conversion.
+    // The five accumulations run as two packed-fp32 pairs and a scalar (v_pk_mul_f32 / v_pk_add_f32: IEEE per component, no contraction).
+    const float kx16 = kx * 16, ky16 = ky * 16;
+    auto eval = [&](const MarchBatch &b, bool act, int s0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const vfloat2 Lxy = {b.L[u].x, b.L[u].y}, Lzw = {b.L[u].z, b.L[u].w};
+            const float dImageX = b.q[u].x - 0.5f, dImageY = b.q[u].y - 0.5f;
+            const bool inx = act & (s0 + u < spp) & (xf >= dImageX - fxw) & (xf <= dImageX + fxw);
+            const float ay = dImageY - fyw, by = dImageY + fyw;
+            const int ifx4 = min(int(fabsf((xf - dImageX) * kx16)), 15) << 2;
+            float wt[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const int ify = min(int(fabsf((yf[i] - dImageY) * ky16)), 15);
+                wt[i] = *(const float RT_L *)((const char RT_L *)ftab + ((ify << 6) + ifx4));
+            }
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const float w = (inx & (yf[i] >= ay) & (yf[i] <= by)) ? wt[i] : 0.f;
+                const vfloat2 w2 = {w, w};
+                acc01[i] += w2 * Lxy; acc23[i] += Lzw * w2; acc4[i] += w;       // Spectrum::AddWeighted color.h:116-120, alpha, weight sum
+            }
+        }
+    };
+    // one loop over the (column, batch of 4 samples) pairs of the row, the next batch's records in flight while this one is evaluated
+    MarchBatch cur, nxt;
+    bool act_cur, act_nxt;
+    const float4 RT_G *rec = column(0, act_cur);
+    act_nxt = act_cur;
+    load(cur, rec, 0);
+    int j = 0, bi = 0;
+    for (int n = ncol * nbatch; n > 0; --n) {
+        const int s0 = bi * 4;
+        int bn = bi + 1;
+        if (bn == nbatch) { bn = 0; ++j; if (j < ncol) rec = column(j, act_nxt); }
+        if (n > 1) load(nxt, rec, bn * 4);
+        eval(cur, act_cur, s0);
+        cur = nxt; act_cur = act_nxt; bi = bn;
+    }
+}
+
+template <int RYMAX>
+__global__ __launch_bounds__(64) void film_march_kernel(const DevFrame *__restrict__ frp, int rx, int ry, int strip_rows) {
+    constexpr int NR = 2 * RYMAX + 1;
+    const DevFrame &fr = *frp;
+    __shared__ float ftab_s[256];                                       // FILTER_TABLE_SIZE^2 (film/image.cpp:53-64)
+    for (int i = threadIdx.x; i < 256; i += 64) ftab_s[i] = RT_GPTR(const float, fr.filter_table)[i];
+    __syncthreads();
+    const float RT_L *ftab = (const float RT_L *)ftab_s;
+    const int nbx = (fr.x_pixel_count + 63) / 64;
+    const int bx = blockIdx.x % nbx, by = blockIdx.x / nbx;
+    const int lx = bx * 64 + int(threadIdx.x);
+    const bool live = lx < fr.x_pixel_count;
+    const int x = fr.x_pixel_start + lx;
+    const int ly0 = by * strip_rows, ly1 = min(ly0 + strip_rows, fr.y_pixel_count) - 1;
+    const int yabs0 = fr.y_pixel_start + ly0, yabs1 = fr.y_pixel_start + ly1;
+    const size_t plane = size_t(fr.x_pixel_count) * fr.y_pixel_count;
+    float RT_G *accum = RT_GPTR(float, fr.accum);
+    vfloat2 acc01[NR], acc23[NR]; float acc4[NR];            // window row i: sum w*L.r, w*L.g | sum w*L.b, w*alpha | sum w
+#pragma unroll
+    for (int i = 0; i < NR; ++i) { acc01[i] = vfloat2{0.f, 0.f}; acc23[i] = vfloat2{0.f, 0.f}; acc4[i] = 0.f; }
+    // rows wy0 .. wy0 + k - 1 of the strip are the ones sample row sy can reach: [max(sy - ry, yabs0), min(sy + ry, yabs1)]
+    int wy0 = yabs0, k = 0;
+    auto fetch = [&](int pos, int y) __attribute__((always_inline)) {            // bring pixel row y (what the film already holds) into window position pos
+        float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        if (live) {
+            const size_t px = size_t(y - fr.y_pixel_start) * fr.x_pixel_count + lx;
+#pragma unroll
+            for (int c = 0; c < 5; ++c) v[c] = accum[c * plane + px];
+        }
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {                       // selects: an `if (i == pos)` becomes a store through a phi of pointers and pins the window in scratch
+            acc01[i].x = (i == pos) ? v[0] : acc01[i].x; acc01[i].y = (i == pos) ? v[1] : acc01[i].y;
+            acc23[i].x = (i == pos) ? v[2] : acc23[i].x; acc23[i].y = (i == pos) ? v[3] : acc23[i].y;
+            acc4[i] = (i == pos) ? v[4] : acc4[i];
+        }
+    };
+    fetch(k++, yabs0);                           // the first sample row, yabs0 - ry, reaches row yabs0 only
+    for (int sy = yabs0 - ry; sy <= yabs1 + ry; ++sy) {
+        if (sy >= fr.y_start && sy < fr.y_end) {
+            switch (k) {
+            case 1: march_row<1, RYMAX>(fr, ftab, acc01, acc23, acc4, live, x, sy, wy0, rx); break;
+            case 2: if (NR >= 2) march_row<(NR >= 2 ? 2 : 1), RYMAX>(fr, ftab, acc01, acc23, acc4, live, x, sy, wy0, rx); break;
+            case 3: if (NR >= 3) march_row<(NR >= 3 ? 3 : 1), RYMAX>(fr, ftab, acc01, acc23, acc4, live, x, sy, wy0, rx); break;
+            case 4: if (NR >= 4) march_row<(NR >= 4 ? 4 : 1), RYMAX>(fr, ftab, acc01, acc23, acc4, live, x, sy, wy0, rx); break;
+            case 5: if (NR >= 5) march_row<(NR >= 5 ? 5 : 1), RYMAX>(fr, ftab, acc01, acc23, acc4, live, x, sy, wy0, rx); break;
+            case 6: if (NR >= 6) march_row<(NR >= 6 ? 6 : 1), RYMAX>(fr, ftab, acc01, acc23, acc4, live, x, sy, wy0, rx); break;
+            case 7: if (NR >= 7) march_row<(NR >= 7 ? 7 : 1), RYMAX>(fr, ftab, acc01, acc23, acc4, live, x, sy, wy0, rx); break;
+            default: break;
+            }
+        }
+        if (k > 0 && wy0 == sy - ry) {            // row wy0 is out of reach of the next sample row: it is complete
+            if (live) {
+                const size_t px = size_t(wy0 - fr.y_pixel_start) * fr.x_pixel_count + lx;
+                accum[px] = acc01[0].x; accum[plane + px] = acc01[0].y; accum[2 * plane + px] = acc23[0].x; accum[3 * plane + px] = acc23[0].y;
+                accum[4 * plane + px] = acc4[0];
+            }
+#pragma unroll
+            for (int i = 0; i + 1 < NR; ++i) { acc01[i] = acc01[i + 1]; acc23[i] = acc23[i + 1]; acc4[i] = acc4[i + 1]; }
+            ++wy0; --k;
+        }
+        if (sy + 1 + ry <= yabs1) fetch(k++, sy + 1 + ry);
+    }
+}
+
+// ---- the film gather with one pixel per lane and the sample rows staged in LDS (round 3; the default for filters reaching 1 or 2 pixels) -----
+// The march above is bound by HBM traffic: a lane re-reads every record once per column of its window (5x) and the rows of a strip's halo,
+// 13 GB for the 2.1 GB of records of a 1024^2 x 64 spp frame.  Here a wave owns NC = 64 / (2 ry + 1) film-pixel columns of a strip and stages
+// one sample row of the NC + 2 rx sample-pixel columns that reach them in LDS, each record read from HBM once per strip (x 1.33 for the column
+// halo).  Lane (column xi, slot m) accumulates ONE pixel at a time: of the 2 ry + 1 pixel rows a sample row can reach, slot m takes the one
+// whose row index is congruent to m, keeps it for the 2 ry + 1 consecutive sample rows that reach it, stores it and moves 2 ry + 1 rows down --
+// every lane has exactly one pixel row to serve for every staged sample row.
+// The staging lane evaluates, once per record, ImageFilm::AddSample's footprint test and filter-table index (film/image.cpp:108-132) for
+// each of the 2 rx + 1 pixel columns and 2 ry + 1 pixel rows the sample can reach and packs them as 5-bit entries (inside << 4 | index) into
+// two words next to the record; a pixel's weight is then one look-up in a 1024-entry table indexed by (y entry << 5 | x entry) that holds
+// 0 wherever either "inside" bit is clear (see march_row for why a weight of +0 is the reference's "skip"), and its accumulation is two
+// packed multiply-adds and an add.  Order per pixel: sample rows, then columns, then samples -- the reference's.
+#ifndef RT_SLOT_PROBE
+#define RT_SLOT_PROBE 0          // tools/r03_scan.py slot: 1 no accumulation pass, 2 no entry arithmetic, 4 no record loads (timing ablations, wrong films)
+#endif
+#ifndef RT_SLOT_UNROLL
+#define RT_SLOT_UNROLL 8         // samples per trip of the accumulation pass: their LDS reads are issued together
+#endif
+#ifndef RT_SLOT_PF
+#define RT_SLOT_PF 12            // lookahead for rows of more than 4 records per lane (238 VGPRs: two waves per SIMD, what a 64 spp row's LDS allows anyway)
+#endif
+// PF: records per lane of the NEXT sample row requested before the current row's accumulation pass (they arrive while it runs; 6 VGPRs each)
+template <int RX, int RY, int PF>
+__global__ __launch_bounds__(64, 2) void film_slot_kernel(const DevFrame *__restrict__ frp, int strip_rows) {
+    constexpr int NS = 2 * RY + 1, NC = 64 / NS, NCS = NC + 2 * RX;
+    extern __shared__ __attribute__((aligned(16))) float4 slot_lds[];
+    const DevFrame &fr = *frp;
+    const int spp = fr.spp, lstride = spp + 1;                          // +1: consecutive columns fall on different LDS banks
+    float4 RT_L *Larr = (float4 RT_L *)slot_lds;                        // [NCS][lstride] L.rgb, alpha
+    uint2 RT_L *Warr = (uint2 RT_L *)(Larr + NCS * lstride);            // [NCS][lstride] x entries, y entries
+    float RT_L *tab2 = (float RT_L *)(Warr + NCS * lstride);            // [1024]
+    unsigned RT_L *colbase = (unsigned RT_L *)(tab2 + 1024);            // [2][NCS] local pixel of each staged column (this row | the next), ~0u: none
+    const int l = int(threadIdx.x);
+    for (int t = l; t < 1024; t += 64) {
+        const bool in = ((t >> 9) & 1) & ((t >> 4) & 1);
+        tab2[t] = in ? RT_GPTR(const float, fr.filter_table)[((t >> 5) & 15) * 16 + (t & 15)] : 0.f;
+    }
+    const int nbx = (fr.x_pixel_count + NC - 1) / NC;
+    const int bx = blockIdx.x % nbx, by = blockIdx.x / nbx;
+    const int m = l / NC, xi = l - m * NC;
+    const int lx = bx * NC + xi;
+    const bool col_live = (m < NS) & (lx < fr.x_pixel_count);
+    const int X0 = fr.x_pixel_start + bx * NC;                          // the strip's first pixel column; staged column ci is sample pixel X0 - RX + ci
+    const int ly0 = by * strip_rows, ly1 = min(ly0 + strip_rows, fr.y_pixel_count) - 1;
+    const int yabs0 = fr.y_pixel_start + ly0, yabs1 = fr.y_pixel_start + ly1;
+    const size_t plane = size_t(fr.x_pixel_count) * fr.y_pixel_count;
+    float RT_G *accum = RT_GPTR(float, fr.accum);
+    const float4 RT_G *samples = RT_GPTR(const float4, fr.samples);
+    const float fxw = fr.fxw, fyw = fr.fyw, kx16 = fr.inv_fxw * 16, ky16 = fr.inv_fyw * 16;   // (v * inv) * 16 == v * (inv * 16), see march_row
+    const int nrec = NCS * spp;
+
+    auto resolve = [&](int buf, int sy) __attribute__((always_inline)) {           // lanes 0 .. NCS-1: where the staged columns of sample row sy live
+        if (l < NCS) {
+            const int sx = X0 - RX + l;
+            unsigned base = ~0u;
+            if (sx >= fr.x_start && sx < fr.x_end) { bool mine; unsigned long long lp; gather_local_pixel(fr, sx, sy, mine, lp); if (mine) base = unsigned(lp); }
+            colbase[buf * NCS + l] = base;
+        }
+    };
+    // record r of a staged row: column r % NCS, sample r / NCS (a load instruction covers NCS consecutive columns of 64 / NCS samples)
+    auto request = [&](int buf, int r, float4 &L, float2 &xy) __attribute__((always_inline)) -> bool {
+        const int sv = r / NCS, ci = r - sv * NCS;
+        bool ok = r < nrec;
+        const unsigned base = ok ? colbase[buf * NCS + ci] : ~0u;
+        ok = ok & (base != ~0u);
+        const unsigned long long at = ok ? sample_slot(base, unsigned(sv), spp) : 0ull;
+        if (RT_SLOT_PROBE & 4) { L = make_float4(0.f, 0.f, 0.f, 0.f); xy = make_float2(0.f, 0.f); }
+        else { L = samples[at]; xy = *(const float2 RT_G *)(samples + at + RT_SAMPLE_XY); }
+        return ok;
+    };
+    // the record's footprint tests and filter-table indices for every pixel column / row it can reach (film/image.cpp:108-132), into LDS
+    auto put = [&](int r, int sy, bool ok, float4 L, const float2 &xy) __attribute__((always_inline)) {
+        if (r >= nrec) return;
+        const int sv = r / NCS, ci = r - sv * NCS;
+        const float dImageX = xy.x - 0.5f, dImageY = xy.y - 0.5f;
+        const float ax = dImageX - fxw, bx_ = dImageX + fxw, ay = dImageY - fyw, by_ = dImageY + fyw;
+        unsigned wx = 0, wy = 0;
+        if (RT_SLOT_PROBE & 2) { wx = __float_as_uint(ax) & 0x1ffffffu; wy = __float_as_uint(by_) & 0x1ffffffu; }
+        else {
+#pragma unroll
+            for (int p = 0; p <= 2 * RX; ++p) {
+                const float xf = float(X0 - 2 * RX + ci + p);
+                const unsigned e = (((xf >= ax) & (xf <= bx_)) ? 16u : 0u) | unsigned(min(int(fabsf((xf - dImageX) * kx16)), 15));
+                wx |= e << (5 * p);
+            }
+#pragma unroll
+            for (int p = 0; p <= 2 * RY; ++p) {
+                const float yf = float(sy - RY + p);
+                const unsigned e = (((yf >= ay) & (yf <= by_)) ? 16u : 0u) | unsigned(min(int(fabsf((yf - dImageY) * ky16)), 15));
+                wy |= e << (5 * p);
+            }
+        }
+        if (!ok) { wx = 0; wy = 0; L = make_float4(0.f, 0.f, 0.f, 0.f); }
+        Larr[ci * lstride + sv] = L;
+        Warr[ci * lstride + sv] = make_uint2(wx, wy);
+    };
+
+    vfloat2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f}; float a4 = 0.f;
+    int q = m < NS ? m : 0;                                             // my pixel row is sy - RY + q
+    float4 pL[PF]; float2 pxy[PF]; unsigned pok = 0;                    // the next row's first PF records per lane, requested a row ahead
+    const int sy_lo = max(yabs0 - RY, fr.y_start), sy_hi = min(yabs1 + RY, fr.y_end - 1);
+    int cur = 0;
+    if (sy_lo <= sy_hi) {
+        resolve(0, sy_lo);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PF; ++k) pok |= (request(0, l + 64 * k, pL[k], pxy[k]) ? 1u : 0u) << k;
+    }
+    for (int sy = yabs0 - RY; sy <= yabs1 + RY; ++sy) {
+        const int y = sy - RY + q;
+        const bool valid = col_live & (y >= yabs0) & (y <= yabs1);
+        const size_t px = size_t(valid ? y - fr.y_pixel_start : 0) * fr.x_pixel_count + (valid ? lx : 0);
+        if (q == NS - 1) {                                              // a new pixel: what the film already holds
+            a01 = vfloat2{0.f, 0.f}; a23 = vfloat2{0.f, 0.f}; a4 = 0.f;
+            if (valid) { a01.x = accum[px]; a01.y = accum[plane + px]; a23.x = accum[2 * plane + px]; a23.y = accum[3 * plane + px]; a4 = accum[4 * plane + px]; }
+        }
+        if (sy >= sy_lo && sy <= sy_hi) {
+            __syncthreads();                                            // the previous row's accumulation pass is done with the staged row
+#pragma unroll
+            for (int k = 0; k < PF; ++k) put(l + 64 * k, sy, (pok >> k) & 1u, pL[k], pxy[k]);
+            for (int r0 = l + 64 * PF; r0 < nrec; r0 += 256) {          // rows longer than the lookahead: four records per lane in flight
+                float4 L[4]; float2 xy[4]; bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) ok[u] = request(cur, r0 + 64 * u, L[u], xy[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) put(r0 + 64 * u, sy, ok[u], L[u], xy[u]);
+            }
+            const bool more = sy < sy_hi;
+            if (more) resolve(cur ^ 1, sy + 1);
+            __syncthreads();
+            if (more) {
+                pok = 0;
+#pragma unroll
+                for (int k = 0; k < PF; ++k) pok |= (request(cur ^ 1, l + 64 * k, pL[k], pxy[k]) ? 1u : 0u) << k;
+            }
+            cur ^= 1;
+            const unsigned shy = valid ? unsigned(5 * q) : 25u;         // bits 25.. of the y word are clear: weight 0 for a lane without a pixel
+            // the accumulation pass, column after column; RT_SLOT_UNROLL samples' LDS reads are issued together.  (A three-stage software pipeline --
+            // records of batch b + 2 read, weights of b + 1 looked up, batch b accumulated -- measured slower: 2.36 vs 2.00 ms on C2.)
+            if (!(RT_SLOT_PROBE & 1))
+#pragma unroll
+            for (int j = 0; j <= 2 * RX; ++j) {
+                const float4 RT_L *Lp = Larr + (xi + j) * lstride;
+                const uint2 RT_L *Wp = Warr + (xi + j) * lstride;
+                const unsigned shx = unsigned(5 * (2 * RX - j));
+                auto one = [&](const float4 &L, const uint2 &w) __attribute__((always_inline)) {
+                    const unsigned t = (__builtin_amdgcn_ubfe(w.y, shy, 5u) << 5) | __builtin_amdgcn_ubfe(w.x, shx, 5u);
+                    const float wt = tab2[t];
+                    const vfloat2 w2 = {wt, wt}, Lxy = {L.x, L.y}, Lzw = {L.z, L.w};
+                    a01 += w2 * Lxy; a23 += Lzw * w2; a4 += wt;        // Spectrum::AddWeighted color.h:116-120, alpha, weight sum
+                };
+                int s = 0;
+                for (; s + RT_SLOT_UNROLL <= spp; s += RT_SLOT_UNROLL) {
+                    float4 L[RT_SLOT_UNROLL]; uint2 w[RT_SLOT_UNROLL];
+#pragma unroll
+                    for (int u = 0; u < RT_SLOT_UNROLL; ++u) { L[u] = Lp[s + u]; w[u] = Wp[s + u]; }
+#pragma unroll
+                    for (int u = 0; u < RT_SLOT_UNROLL; ++u) one(L[u], w[u]);
+                }
+                for (; s < spp; ++s) one(Lp[s], Wp[s]);
+            }
+        }
+        if (q == 0 && valid) {                                          // the last sample row that reaches my pixel is done
+            accum[px] = a01.x; accum[plane + px] = a01.y; accum[2 * plane + px] = a23.x; accum[3 * plane + px] = a23.y; accum[4 * plane + px] = a4;
+        }
+        q = q == 0 ? NS - 1 : q - 1;
+    }
+}
+
 // ImageFilm::WriteImage (film/image.cpp:157-203) on the device: XYZ round trip (color.h:177-184, color.cpp:35-43),
 // divide by the weight sum, clamps, premultiply.  out = rgb[H][W][3] then alpha[H][W].
 __global__ void film_resolve_kernel(const float *__restrict__ accum, size_t n, int premultiply, float *__restrict__ rgb,
@@ -194,6 +516,16 @@ __global__ void film_resolve_kernel(const float *__restrict__ accum, size_t n, i
     }
     if (premultiply) { r *= a; g *= a; b *= a; }
     rgb[3 * i] = r; rgb[3 * i + 1] = g; rgb[3 * i + 2] = b; alpha[i] = a;
+}
+
+// rt_samples_read: records [first, first + count) of the shard's work list, out of the sample_slot() layout, as 2 x float4 per sample
+__global__ void samples_unpack_kernel(const float4 *__restrict__ samples, unsigned long long first, unsigned long long count, int spp, float4 *__restrict__ out) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const unsigned long long w = first + i;
+    const unsigned lp = unsigned(w / unsigned(spp));
+    const unsigned long long at = sample_slot(lp, unsigned(w - (unsigned long long)lp * unsigned(spp)), spp);
+    out[2 * i] = samples[at]; out[2 * i + 1] = samples[at + RT_SAMPLE_XY];
 }
 
 __global__ void camera_kernel(DevScene sc, DevFrame fr, unsigned long long first, unsigned count, RtRay *out) {
@@ -260,6 +592,7 @@ struct RtScene {
     unsigned grids[48] = {0};          // resident grid per render_kernel<COUNT, INTEG> instantiation
     DevScene *dev_scene = nullptr; DevFrame *dev_frame = nullptr;   // descriptors in HBM (read with scalar loads)
     float4 *samples = nullptr; size_t samples_cap = 0;          // per-shard sample buffer
+    int samples_spp = 1;
     unsigned long long samples_last = 0;                       // camera samples the LAST rt_render wrote (rt_samples_read's range)
     float ms_render = 0.f, ms_gather = 0.f; hipEvent_t ev2 = nullptr;
     float *resolve_buf = nullptr; size_t resolve_cap = 0;
@@ -1376,10 +1709,11 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
     // ---- scratch
     {
         size_t cap = s->samples_cap;
-        rc = ensure(s, &s->samples, &cap, size_t(fr.total_work ? fr.total_work : 1) * 2); if (rc) return rc;
+        const size_t local_pixels = size_t(fr.total_work / fr.spp);                     // sample_slot(): whole 64-pixel chunks
+        rc = ensure(s, &s->samples, &cap, ((local_pixels + 63) / 64 * 64 + 64) * size_t(fr.spp) * 2); if (rc) return rc;
         s->samples_cap = cap;
     }
-    fr.samples = s->samples; s->samples_last = fr.total_work;
+    fr.samples = s->samples; s->samples_last = fr.total_work; s->samples_spp = fr.spp;
     HIPCHK(hipMemcpyAsync(s->filter_dev, rd->filter_table, 256 * sizeof(float), hipMemcpyHostToDevice, s->stream));
     { hipError_t pre = hipGetLastError(); if (pre != hipSuccess) return fail(RT_EDEVICE, std::string("pending HIP error before launch: ") + hipGetErrorString(pre)); }
     if (fr.pipeline) {
@@ -1408,9 +1742,47 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
         s->last_pipeline = false;
     }
     if (!skip_film) {
-        const unsigned gb = unsigned((fr.x_pixel_count + 15) / 16) * unsigned((fr.y_pixel_count + 15) / 16);
-        const size_t lds_bytes = size_t(cols) * col_bytes + size_t(cols) * sizeof(unsigned long long) + 16;
-        hipLaunchKernelGGL(film_gather_kernel, dim3(gb), dim3(256), lds_bytes, s->stream, s->dev_frame, grx, gry, cols);
+        // film_slot_kernel for filters that reach 1 or 2 pixels either side (box .. gaussian at their default widths) and whose staged sample row
+        // fits LDS; film_march_kernel for up to 3 rows; the staged gather for wider ones.  PBRT_HIP_GATHER=slot|march|staged forces one (tests).
+        const char *ge = std::getenv("PBRT_HIP_GATHER");
+        const bool slot_ok = grx == gry && (grx == 1 || grx == 2);
+        const int slot_ncs = slot_ok ? 64 / (2 * gry + 1) + 2 * grx : 0;
+        const size_t slot_lds = size_t(slot_ncs) * size_t(fr.spp + 1) * 24 + 4096 + size_t(slot_ncs) * 8 + 16;
+        int which = (slot_ok && slot_lds <= 64 * 1024) ? 2 : gry <= 3 ? 1 : 0;
+        if (ge) {
+            which = !std::strcmp(ge, "slot") ? 2 : !std::strcmp(ge, "march") ? 1 : !std::strcmp(ge, "staged") ? 0 : -1;
+            if (which < 0) return fail(RT_EINVAL, "PBRT_HIP_GATHER: slot, march or staged");
+            if (which == 2 && !(slot_ok && slot_lds <= 64 * 1024)) return fail(RT_EINVAL, "PBRT_HIP_GATHER=slot: needs equal filter reaches of 1 or 2 pixels and a sample row that fits 64 KB of LDS");
+            if (which == 1 && gry > 3) return fail(RT_EINVAL, "PBRT_HIP_GATHER=march: the filter reaches more than 3 rows");
+        }
+        int rows = 0;
+        if (const char *e = std::getenv("PBRT_HIP_GATHER_ROWS")) rows = std::max(1, std::atoi(e));
+        if (which == 2) {
+            const int nc = 64 / (2 * gry + 1);
+            const unsigned nbx = unsigned((fr.x_pixel_count + nc - 1) / nc);
+            if (!rows) {                                      // strip height: tall (a strip re-reads 2 ry rows of halo) but >= ~10 waves per CU
+                rows = 64;
+                while (rows > 8 && size_t(nbx) * size_t((fr.y_pixel_count + rows - 1) / rows) < size_t(10) * size_t(std::max(1, s->n_cus))) rows /= 2;
+            }
+            const unsigned gb = nbx * unsigned((fr.y_pixel_count + rows - 1) / rows);
+            const int per_lane = (slot_ncs * fr.spp + 63) / 64;           // records a lane stages per sample row: the lookahead covers them up to RT_SLOT_PF
+            auto k = grx == 1 ? (per_lane <= 4 ? film_slot_kernel<1, 1, 4> : film_slot_kernel<1, 1, RT_SLOT_PF>)
+                              : (per_lane <= 4 ? film_slot_kernel<2, 2, 4> : film_slot_kernel<2, 2, RT_SLOT_PF>);
+            hipLaunchKernelGGL(k, dim3(gb), dim3(64), slot_lds, s->stream, (const DevFrame *)s->dev_frame, rows);
+        } else if (which == 1) {
+            const unsigned nbx = unsigned((fr.x_pixel_count + 63) / 64);
+            if (!rows) {                                      // strip height: the record re-reads shrink with it, the waves in flight too
+                rows = 32;
+                while (rows > 4 && size_t(nbx) * size_t((fr.y_pixel_count + rows - 1) / rows) < size_t(16) * size_t(std::max(1, s->n_cus))) rows /= 2;
+            }
+            const unsigned gb = nbx * unsigned((fr.y_pixel_count + rows - 1) / rows);
+            auto k = gry <= 1 ? film_march_kernel<1> : gry == 2 ? film_march_kernel<2> : film_march_kernel<3>;
+            hipLaunchKernelGGL(k, dim3(gb), dim3(64), 0, s->stream, (const DevFrame *)s->dev_frame, grx, gry, rows);
+        } else {
+            const unsigned gb = unsigned((fr.x_pixel_count + 15) / 16) * unsigned((fr.y_pixel_count + 15) / 16);
+            const size_t lds_bytes = size_t(cols) * col_bytes + size_t(cols) * sizeof(unsigned long long) + 16;
+            hipLaunchKernelGGL(film_gather_kernel, dim3(gb), dim3(256), lds_bytes, s->stream, s->dev_frame, grx, gry, cols);
+        }
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(s->ev2, s->stream));
@@ -1435,7 +1807,16 @@ int rt_samples_read(RtScene *s, uint64_t first, uint64_t count, float *out) {
     if (!s->samples || first > s->samples_last || count > s->samples_last - first) return fail(RT_ESTATE, "rt_samples_read: no frame rendered / range beyond the last frame");
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipStreamSynchronize(s->stream));
-    HIPCHK(hipMemcpy(out, s->samples + 2 * first, size_t(count) * 2 * sizeof(float4), hipMemcpyDeviceToHost));
+    if (count == 0) return RT_OK;
+    float4 *tmp = nullptr;
+    HIPCHK(hipMalloc((void **)&tmp, size_t(count) * 2 * sizeof(float4)));
+    hipLaunchKernelGGL(samples_unpack_kernel, dim3(unsigned((count + 255) / 256)), dim3(256), 0, s->stream, (const float4 *)s->samples,
+                       (unsigned long long)first, (unsigned long long)count, s->samples_spp, tmp);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, tmp, size_t(count) * 2 * sizeof(float4), hipMemcpyDeviceToHost);
+    HIPWARN(hipFree(tmp));
+    if (e != hipSuccess) return fail(RT_EDEVICE, std::string("rt_samples_read: ") + hipGetErrorString(e));
     return RT_OK;
 }
 

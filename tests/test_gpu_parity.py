@@ -245,6 +245,68 @@ def test_shards_on_one_gpu_sum_to_the_full_film(pkg, scenes):
     assert c3["camera_rays"] == c1["camera_rays"] and c3["closest_rays"] == c1["closest_rays"]
 
 
+GATHER_CASES = {
+    # filter reach 2 (mitchell / gaussian / triangle), reach 1 (box), odd film sizes, 1 / 6 / 16 samples per pixel (6: not a multiple of the
+    # accumulation pass's batch), a crop window, a lens, the low-discrepancy sampler
+    "mitchell_4spp": dict(xres=75, yres=53, integrator="path", xsamples=2, ysamples=2, jitter=True, pixel_filter="mitchell"),
+    "gaussian_6spp": dict(xres=64, yres=40, integrator="directlighting", xsamples=3, ysamples=2, jitter=True, pixel_filter="gaussian"),
+    "triangle_1spp": dict(xres=33, yres=130, integrator="whitted", xsamples=1, ysamples=1, jitter=True, pixel_filter="triangle"),
+    "box_16spp_crop": dict(xres=90, yres=70, integrator="path", xsamples=4, ysamples=4, jitter=True, pixel_filter="box", crop=(0.21, 0.83, 0.13, 0.9)),
+    "box_wide": dict(xres=48, yres=48, integrator="whitted", xsamples=2, ysamples=1, jitter=True, pixel_filter="box", filter_params='"float xwidth" [1.3] "float ywidth" [1.3]'),
+    "mitchell_ld8_lens": dict(xres=40, yres=70, integrator="path", sampler="lowdiscrepancy", pixelsamples=8, pixel_filter="mitchell", lensradius=6.0, focaldistance=900.0),
+    "sinc_reach4": dict(xres=50, yres=34, integrator="whitted", xsamples=2, ysamples=2, jitter=True, pixel_filter="sinc"),
+    "gaussian_unequal": dict(xres=44, yres=36, integrator="whitted", xsamples=2, ysamples=2, jitter=True, pixel_filter="gaussian", filter_params='"float xwidth" [2.7] "float ywidth" [1.2]'),
+}
+
+
+GATHER_REACH = {"mitchell_4spp": (2, 2), "gaussian_6spp": (2, 2), "triangle_1spp": (2, 2), "box_16spp_crop": (1, 1), "box_wide": (1, 1),
+                "mitchell_ld8_lens": (2, 2), "sinc_reach4": (4, 4), "gaussian_unequal": (3, 1)}
+
+
+@pytest.mark.parametrize("name", sorted(GATHER_CASES))
+def test_the_three_film_gathers_agree_bit_for_bit(pkg, scenes, name, monkeypatch):
+    """ImageFilm::AddSample runs as one of three kernels (rt_kernels.hip): film_slot_kernel (filters reaching 1 or 2 pixels both ways: one
+    pixel per lane, sample rows staged in LDS with the footprint tests and table indices precomputed per record), film_march_kernel (up
+    to 3 rows: a lane marches down a pixel column) and the staged film_gather_kernel (anything).  All three must produce the SAME bits --
+    the staged one is the kernel the reference-film fixtures were pinned with in rounds 1-2 -- whatever the strip height, on one shard
+    and on the 1-D / 2-D tiles of a 3-rank partition."""
+    need_gpu(pkg)
+    text = scenes.cornell_scene(keyed=True, seed=11, soup_tris=200, **GATHER_CASES[name])
+    ps = pkg.ParsedScene(text=text)
+    ds = pkg.DeviceScene(ps); ds.bind_film()
+    reach = GATHER_REACH[name]                     # floor(filter width + .5) in x and y
+    kinds = ["staged"] + (["march"] if reach[1] <= 3 else []) + (["slot"] if reach[0] == reach[1] and reach[0] in (1, 2) else [])
+    shards = [(0, 1, 1), (1, 3, 16), (2, 3, (16, 8))]
+    for shard in shards:
+        ps.set_shard(*shard)
+        ref = None
+        for kind in kinds:
+            for rows in (None, "1", "3", "7", "1000"):
+                with pytest.MonkeyPatch.context() as mp:
+                    mp.setenv("PBRT_HIP_GATHER", kind)
+                    if rows: mp.setenv("PBRT_HIP_GATHER_ROWS", rows)
+                    ds.clear_film(); ds.render()
+                got = ds.film_accum()
+                if ref is None:
+                    ref = got
+                    assert np.isfinite(ref).all() and ref[4].max() > 0
+                assert np.array_equal(got, ref), (name, shard, kind, rows, float(np.abs(got - ref).max()))
+                if kind == "staged": break
+    # the default choice, and a loud refusal of a kernel that cannot serve the filter
+    ps.set_shard(0, 1, 1)
+    ds.clear_film(); ds.render(); base = ds.film_accum()
+    for kind in ("slot", "march"):
+        if kind not in kinds:
+            monkeypatch.setenv("PBRT_HIP_GATHER", kind)
+            with pytest.raises(pkg.RtError):
+                ds.render()
+            monkeypatch.delenv("PBRT_HIP_GATHER")
+    monkeypatch.setenv("PBRT_HIP_GATHER", "staged")
+    ds.clear_film(); ds.render()
+    assert np.array_equal(ds.film_accum(), base)
+    ds.close()
+
+
 def test_full_size_properties(pkg, scenes):
     """BASELINE configs[1] at full size (1024x1024 @ 64 spp, path maxdepth 5): properties that need no oracle.
       * every camera sample of the extent is rendered exactly once: sum of filter weights per pixel is the same

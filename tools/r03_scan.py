@@ -63,10 +63,25 @@ elif g == "region":
             bench("region%d_%s" % (m, wl), workload=wl)
         bench("region%d_c5" % m, workload="c5")
 
-elif g == "vote":
-    for vd, vt in ((8, 0), (16, 0), (0, 16), (0, 32), (8, 24), (0, 0)):
-        for u in ("rt_mega_p", "rt_mega_d", "rt_trace"):
-            T.rebuild(u, ["-DRT_TRACE_VOTE_D=%d" % vd, "-DRT_TRACE_VOTE_T=%d" % vt])
-        for wl in ("c3", "p1000000"):
-            bench("voteD%d_T%d_%s" % (vd, vt, wl), workload=wl)
-        bench("voteD%d_T%d_c5" % (vd, vt), workload="c5")
+elif g == "slot2":
+    for pf, un in ((8, 8), (4, 8), (10, 8)):
+        T.rebuild("rt_kernels", ["-DRT_SLOT_PF=%d" % pf, "-DRT_SLOT_UNROLL=%d" % un])
+        for wl in ("c2", "c3"):
+            tag = "slot_pf%d_un%d_%s" % (pf, un, wl)
+            bench(tag, workload=wl, steps=2)
+            try:
+                j = json.load(open(os.path.join(ROOT, "gpurun_out", "scan_" + tag + ".json")))
+                print("   ", tag, "film_gather ms", j["roofline"]["frame_kernels_ms"]["film_gather"], flush=True)
+            except Exception as ex:
+                print("   ", tag, ex, flush=True)
+elif g == "slot":
+    # film_slot_kernel ablations on C2 / C3 (the gather's time is in roofline.frame_kernels_ms.film_gather)
+    for m in (1, 2, 4, 6, 7, 0):
+        T.rebuild("rt_kernels", ["-DRT_SLOT_PROBE=%d" % m])
+        for wl in ("c2", "c3"):
+            bench("slotprobe%d_%s" % (m, wl), workload=wl, steps=2)
+            try:
+                j = json.load(open(os.path.join(ROOT, "gpurun_out", "scan_slotprobe%d_%s.json" % (m, wl))))
+                print("   probe", m, wl, "film_gather ms", j["roofline"]["frame_kernels_ms"]["film_gather"], flush=True)
+            except Exception as ex:
+                print("   probe", m, wl, ex, flush=True)
