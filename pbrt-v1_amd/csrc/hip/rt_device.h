@@ -149,12 +149,13 @@ typedef const DevLight RT_G &LightRef;
 
 // Sample-buffer layout (round 3).  Work item w of a shard is sample s = w % spp of the shard's local pixel lp = w / spp (local pixels
 // follow the shard's tiles in order, so on one rank lp is the pixel's scanline index).  64 consecutive local pixels form a chunk stored
-// [sample][L.rgb+alpha | imageX, imageY, -, -][pixel in chunk]: the 64 lanes of a film-gather wave, which sit on 64 consecutive
-// pixels of a row and read the same sample slot of each, fetch 1 KB of consecutive float4s per load instead of 64 separate lines.
+// [sample][pixel in chunk][L.rgb+alpha | imageX, imageY, -, -]: the lanes of a film-gather wave, which sit on consecutive pixels of a
+// row and read the same sample slot of each, fetch 2 KB of consecutive records per load pair instead of 64 separate lines, and the
+// render kernel writes a sample's two float4s into one 32-byte sector.
 // Returns the float4 index of the L record; the image-position record is RT_SAMPLE_XY float4s further.
-#define RT_SAMPLE_XY 64
+#define RT_SAMPLE_XY 1
 __host__ __device__ inline unsigned long long sample_slot(unsigned lp, unsigned s, int spp) {
-    return ((unsigned long long)(lp >> 6) * unsigned(spp) + s) * 128ull + (lp & 63u);
+    return ((unsigned long long)(lp >> 6) * unsigned(spp) + s) * 128ull + (lp & 63u) * 2u;
 }
 
 }  // namespace rt

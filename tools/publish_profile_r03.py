@@ -24,11 +24,12 @@ acc = defaultdict(lambda: defaultdict(float))
 for f in glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         n = r.get("Kernel_Name", "?").split("(")[0].replace("void ", "")
-        if any(k in n for k in ("render_kernel", "pipe_trace", "pipe_shade", "pipe_vertex")):
+        if any(k in n for k in ("render_kernel", "pipe_trace", "pipe_shade", "pipe_vertex", "film_slot", "film_march", "film_gather")):
             acc[n][r["Counter_Name"]] += float(r["Counter_Value"])
 for n, d in acc.items():
     timed = "<false" in n
-    out["pmc_per_frame"][n] = {c: v / (FRAMES - 1 if timed else 1) for c, v in d.items()}     # the counting twin renders one frame, the timed kernel four
+    film = "film_" in n                                                                       # the film gather runs once in every frame
+    out["pmc_per_frame"][n] = {c: v / (FRAMES if film else FRAMES - 1 if timed else 1) for c, v in d.items()}     # the counting twin renders one frame, the timed kernel four
     p = out["pmc_per_frame"][n]
     dv = {}
     if "FETCH_SIZE" in p and "WRITE_SIZE" in p:
@@ -41,6 +42,10 @@ for n, d in acc.items():
         dv["VALUBusy_percent"] = 100.0 * p["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (p["GRBM_GUI_ACTIVE"] / 8)
     if p.get("SQ_THREAD_CYCLES_VALU") and p.get("SQ_ACTIVE_INST_VALU"):
         dv["lanes_active_percent"] = 100.0 * p["SQ_THREAD_CYCLES_VALU"] / (p["SQ_ACTIVE_INST_VALU"] * 64)
+    if p.get("SQ_ACTIVE_INST_LDS") and p.get("GRBM_GUI_ACTIVE"):
+        dv["LDS_instr_busy_percent_of_SIMD_cycles"] = 100.0 * p["SQ_ACTIVE_INST_LDS"] * 4 / 1024 / (p["GRBM_GUI_ACTIVE"] / 8)
+    if p.get("SQ_LDS_BANK_CONFLICT") and p.get("SQ_ACTIVE_INST_LDS"):
+        dv["LDS_bank_conflict_cycles_per_active_LDS_cycle"] = p["SQ_LDS_BANK_CONFLICT"] / p["SQ_ACTIVE_INST_LDS"]
     out["pmc_per_frame"][n]["derived"] = dv
 json.dump(out, open(os.path.join(src, "summary.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:5000])
