@@ -544,6 +544,19 @@ __global__ void camera_kernel(DevScene sc, DevFrame fr, unsigned long long first
 // ------------------------------------------------------------------------------------------ host side
 using namespace rt;
 
+// Experiment / test knobs (PBRT_HIP_*: kernel flavour, pipeline form, film-gather kernel, layout switches, logs) are read only when
+// PBRT_HIP_TUNE is set in the environment -- the tests and tools/ set it -- so a production process cannot change its behaviour through a stray
+// variable; -DRT_NO_TUNABLES compiles them out.
+static const char *knob(const char *name) {
+#ifdef RT_NO_TUNABLES
+    (void)name; return nullptr;
+#else
+    static const bool on = std::getenv("PBRT_HIP_TUNE") != nullptr;
+    return on ? std::getenv(name) : nullptr;
+#endif
+}
+
+
 // render_kernel instantiations live in rt_mega_{w,d,p}.hip, 16 per integrator: k = (VOL*2 + ACCEL)*2 + COUNT for the natural-allocation
 // kernels (0..7; the counting twins always carry the glossy / quadric code, they are not timed), 8 + VOL*2 + ACCEL for the
 // high-occupancy flavour, 12 + VOL*2 + ACCEL for the timed kernels with the glossy (plastic) lobes and quadric slots compiled in
@@ -871,7 +884,7 @@ static int render_pipeline(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, int
     const int integ = rd->integrator;
     // PathIntegrator without a medium: one shade pass per path vertex, all of a vertex's rays in one trace launch (rt_pipe_vertex.h)
     bool by_vertex = integ == RT_INTEGRATOR_PATH && !s->volume.present;
-    if (const char *e = std::getenv("PBRT_HIP_PIPE_VERTEX")) by_vertex = by_vertex && std::atoi(e) != 0;
+    if (const char *e = knob("PBRT_HIP_PIPE_VERTEX")) by_vertex = by_vertex && std::atoi(e) != 0;
     // ---- pool size: 8 M slots unless the frame is smaller or the per-slot scratch would not fit (a fine ray march: 3 floats per step)
     const size_t frame_words = integ != RT_INTEGRATOR_PATH ? size_t(rd->max_depth + 2) * RT_FRAME_WORDS : 0;
     const size_t vol_words = s->volume.present ? size_t(vol_levels) * 8 + 13 + vol_samp_words : 0;
@@ -882,10 +895,10 @@ static int render_pipeline(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, int
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
         const size_t held = size_t(s->pool_cap) * (size_t(RT_PIPE_VEC) * 16 + 9 * 16 + 12) + (s->frames_floats + s->vol_cap) * 4;   // what this scene's pool already holds
         size_t budget = (free_b + held) / 2;                                      // leave half of what is free to the caller (film, other scenes)
-        if (const char *e = std::getenv("PBRT_HIP_PIPE_MEM_MB")) budget = size_t(std::max(1, std::atoi(e))) << 20;      // tests: a small budget
+        if (const char *e = knob("PBRT_HIP_PIPE_MEM_MB")) budget = size_t(std::max(1, std::atoi(e))) << 20;      // tests: a small budget
         if (slot_bytes * want > budget) want = unsigned(std::max<size_t>(budget / slot_bytes, 2 * RT_BLOCK));
     }
-    if (const char *e = std::getenv("PBRT_HIP_PIPE_SLOTS")) want = unsigned(std::max(256, std::atoi(e)));
+    if (const char *e = knob("PBRT_HIP_PIPE_SLOTS")) want = unsigned(std::max(256, std::atoi(e)));
     unsigned long long tw = fr.total_work ? fr.total_work : 1;
     unsigned n_slots = unsigned(std::min<unsigned long long>(want, tw));
     // ---- one pool or two halves taking turns
@@ -893,7 +906,7 @@ static int render_pipeline(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, int
     // 256 CUs takes 78 ms instead of 57, the shade passes on the other 64 take 42 ms instead of 12 -- so side by side is slower than one
     // after the other (1 M-triangle path frame 83 vs 71 ms, C5 440 vs 395 ms).  Off unless asked for.
     bool overlap = false;
-    if (const char *e = std::getenv("PBRT_HIP_OVERLAP")) overlap = std::atoi(e) != 0 && n_slots >= 4 * RT_BLOCK;
+    if (const char *e = knob("PBRT_HIP_OVERLAP")) overlap = std::atoi(e) != 0 && n_slots >= 4 * RT_BLOCK;
     const int H = overlap ? 2 : 1;
     n_slots = (n_slots + H * RT_BLOCK - 1) / (H * RT_BLOCK) * (H * RT_BLOCK);
     const unsigned half = n_slots / H;
@@ -943,7 +956,7 @@ static int render_pipeline(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, int
     if (overlap) {
         // CUs of the trace kernel: a path's shade passes are light (13 ms of 70 on the whole chip), a ray march's are not (150 of 390)
         int tc = s->volume.present ? s->n_cus * 5 / 8 : s->n_cus * 3 / 4;
-        if (const char *e = std::getenv("PBRT_HIP_TRACE_CUS")) tc = std::atoi(e);
+        if (const char *e = knob("PBRT_HIP_TRACE_CUS")) tc = std::atoi(e);
         tc = std::max(8, std::min(s->n_cus - 8, tc));
         int rc = ensure_masked_streams(s, tc); if (rc) return rc;
         st_shade = s->st_shade; st_trace = s->st_trace;
@@ -1002,7 +1015,7 @@ static int render_pipeline(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, int
         HIPCHK(hipStreamWaitEvent(s->stream, s->pipe_hand[4], 0)); HIPCHK(hipStreamWaitEvent(s->stream, s->pipe_hand[5], 0));
     }
 #ifdef RT_PIPE_LOG
-    if (std::getenv("PBRT_HIP_PIPE_TRACE_LOG")) {               // per-launch queue sizes and kernel times (experiments)
+    if (knob("PBRT_HIP_PIPE_TRACE_LOG")) {               // per-launch queue sizes and kernel times (experiments)
         HIPCHK(hipStreamSynchronize(s->stream));
         for (int i = 0; i < (checked + 1) * H && i < RT_PIPE_TIMED; ++i) {
             float ms = 0.f, ms2 = 0.f; HIPCHK(hipEventElapsedTime(&ms, s->pipe_ev[4 * i], s->pipe_ev[4 * i + 1])); HIPCHK(hipEventElapsedTime(&ms2, s->pipe_ev[4 * i + 2], s->pipe_ev[4 * i + 3]));
@@ -1096,7 +1109,7 @@ static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel 
     HIPCHK(hipEventCreate(&s->ev0)); HIPCHK(hipEventCreate(&s->ev1));
     s->n_tris = d->n_tris;
 
-    const bool tlog = std::getenv("PBRT_HIP_CREATE_LOG") != nullptr;           // where a scene create spends its time (10 M triangles: a minute)
+    const bool tlog = knob("PBRT_HIP_CREATE_LOG") != nullptr;           // where a scene create spends its time (10 M triangles: a minute)
     auto t_prev = std::chrono::steady_clock::now();
     auto tick = [&](const char *what) {
         if (!tlog) return;
@@ -1224,16 +1237,16 @@ static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel 
         tn.pop_back();
         std::vector<uint4> pairs;
         int treelet = RT_TREELET_PAIRS;
-        if (const char *e = std::getenv("PBRT_HIP_TREELET_PAIRS")) treelet = std::max(1, std::atoi(e));                  // layout experiments
+        if (const char *e = knob("PBRT_HIP_TREELET_PAIRS")) treelet = std::max(1, std::atoi(e));                  // layout experiments
         bool align = RT_TREELET_ALIGN != 0;
-        if (const char *e = std::getenv("PBRT_HIP_TREELET_ALIGN")) align = std::atoi(e) != 0;
+        if (const char *e = knob("PBRT_HIP_TREELET_ALIGN")) align = std::atoi(e) != 0;
         bool blocks = true;
-        if (const char *e = std::getenv("PBRT_HIP_PAIR_BLOCKS")) blocks = std::atoi(e) != 0;                             // layout experiments
+        if (const char *e = knob("PBRT_HIP_PAIR_BLOCKS")) blocks = std::atoi(e) != 0;                             // layout experiments
         tick("leaf-order upload");
         if (blocks) build_pair_blocks(tn, pairs, s->dev.root_x, s->dev.root_y);
         else build_pairs(tn, pairs, s->dev.root_x, s->dev.root_y, treelet, align);
         if (pairs.empty() || pairs.size() >= (size_t(1) << 30)) return fail(RT_EINVAL, "rt_scene_create: pair records beyond 2^30");
-        if (std::getenv("PBRT_HIP_TREELET_LOG")) std::fprintf(stderr, "TREELET blocks=%d pairs=%d align=%d interior_nodes=%zu records=%zu\n", int(blocks), treelet, int(align), tn.size() / 2, pairs.size());
+        if (knob("PBRT_HIP_TREELET_LOG")) std::fprintf(stderr, "TREELET blocks=%d pairs=%d align=%d interior_nodes=%zu records=%zu\n", int(blocks), treelet, int(align), tn.size() / 2, pairs.size());
         tick("pair blocks");
         if ((rc = upload(s, pairs.data(), pairs.size(), &s->dev.tpairs))) return rc;
         tick("pair upload");
@@ -1337,7 +1350,7 @@ static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel 
     for (int k = 0; k < 8; ++k) {
         int per_cu = 0;
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)g_pipe_trace[k], RT_BLOCK, 0));
-        if (const char *e = std::getenv("PBRT_HIP_TRACE_BLOCKS_PER_CU")) per_cu = std::min(per_cu, std::max(1, std::atoi(e)));   // occupancy experiments
+        if (const char *e = knob("PBRT_HIP_TRACE_BLOCKS_PER_CU")) per_cu = std::min(per_cu, std::max(1, std::atoi(e)));   // occupancy experiments
         s->trace_grids[k] = unsigned(prop.multiProcessorCount) * unsigned(per_cu < 1 ? 1 : per_cu);
         if (s->trace_grids[k] * RT_BLOCK > s->n_threads) s->n_threads = s->trace_grids[k] * RT_BLOCK;      // the spill area is shared
     }
@@ -1534,13 +1547,13 @@ static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool nee
         // measured +1.5 % (16: -13 %); Whitted / DirectLighting on Cornell lose 10 % with any early exit
         fr.exit_thresh = tiny ? (rd->integrator == RT_INTEGRATOR_PATH ? 8 : 0) : 32;
         fr.high_occupancy = tiny ? 0 : 1;
-        if (const char *e = std::getenv("PBRT_HIP_HIGH_OCC")) fr.high_occupancy = std::atoi(e);
-        if (const char *e = std::getenv("PBRT_HIP_TRAV_MODE")) fr.trav_mode = std::atoi(e);
-        if (const char *e = std::getenv("PBRT_HIP_EXIT_THRESH")) fr.exit_thresh = std::atoi(e);
+        if (const char *e = knob("PBRT_HIP_HIGH_OCC")) fr.high_occupancy = std::atoi(e);
+        if (const char *e = knob("PBRT_HIP_TRAV_MODE")) fr.trav_mode = std::atoi(e);
+        if (const char *e = knob("PBRT_HIP_EXIT_THRESH")) fr.exit_thresh = std::atoi(e);
         fr.dbg_x = fr.dbg_y = -1000000;
-        if (const char *e = std::getenv("PBRT_HIP_DEBUG_PIXEL")) std::sscanf(e, "%d,%d", &fr.dbg_x, &fr.dbg_y);
+        if (const char *e = knob("PBRT_HIP_DEBUG_PIXEL")) std::sscanf(e, "%d,%d", &fr.dbg_x, &fr.dbg_y);
         fr.phase_sync = tiny ? 1 : 0;                          // C2: 63.6 vs 82.4 ms; 100k/1M soups (early-exit rounds): 8 % slower
-        if (const char *e = std::getenv("PBRT_HIP_PHASE_SYNC")) fr.phase_sync = std::atoi(e);
+        if (const char *e = knob("PBRT_HIP_PHASE_SYNC")) fr.phase_sync = std::atoi(e);
         // large trees (traversal bound by memory latency): the queue pipeline of rt_pipeline.h; tiny cache-resident ones: the megakernel
         // (measured on the 1 M-triangle frames, 1x MI355X: the pipeline's trace kernel is faster than the megakernel's traversal, but its
         // state traffic and sparse last iterations cost more than that gains, except where shading suspends often: volume marching)
@@ -1548,7 +1561,7 @@ static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool nee
         // built without the SLP vectorizer the 4-wave megakernel no longer spills and is as fast there (69.3 ms) and faster on C4's
         // material mix (71.3 vs 76.3 ms), so it stays the default for frames without a medium
         fr.pipeline = (!tiny && s->volume.present) ? 1 : 0;
-        if (const char *e = std::getenv("PBRT_HIP_PIPELINE")) fr.pipeline = std::atoi(e) != 0;
+        if (const char *e = knob("PBRT_HIP_PIPELINE")) fr.pipeline = std::atoi(e) != 0;
         if (fr.max_depth > 250 || fr.max_depth < 0) fr.pipeline = 0;     // the slot's control word holds depth in 8 bits
         for (int i = 0; i < fr.n2d; ++i) if (fr.two_d[i].n >= 65535) fr.pipeline = 0;         // ... and the light / sample cursors in 16 bits each
         if (s->dev.n_lights >= 65535u) fr.pipeline = 0;
@@ -1682,11 +1695,11 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
     if (rd->max_depth < 0) return fail(RT_EINVAL, "rt_render: negative maxdepth");
     if (!rd->filter_table) return fail(RT_EINVAL, "rt_render: no filter table");
     DevFrame fr; int rc = make_frame(s, rd, fr, true); if (rc) return rc;
-    const bool skip_film = std::getenv("PBRT_HIP_DEBUG_NOFILM") != nullptr;   // perf experiments only
+    const bool skip_film = knob("PBRT_HIP_DEBUG_NOFILM") != nullptr;   // perf experiments only
     const int grx = int(std::floor(fr.fxw + 0.5f)), gry = int(std::floor(fr.fyw + 0.5f));   // reach of a sample pixel: |x - sx| <= w + .5
     const size_t col_bytes = size_t(fr.spp * 2 + 1) * sizeof(float4);
     size_t lds_kb = 40;                                       // 3 workgroups per CU (measured 60 KB: 5.6 ms, 40 KB: 5.3 ms on C2)
-    if (const char *e = std::getenv("PBRT_HIP_GATHER_LDS_KB")) lds_kb = size_t(std::max(4, std::atoi(e)));
+    if (const char *e = knob("PBRT_HIP_GATHER_LDS_KB")) lds_kb = size_t(std::max(4, std::atoi(e)));
     int cols = int((lds_kb << 10) / col_bytes);
     if (fr.x_pixel_start + fr.x_pixel_count > 32767 || fr.y_pixel_start + fr.y_pixel_count > 32767 || fr.x_pixel_start < -32768 || fr.y_pixel_start < -32768)
         return fail(RT_EINVAL, "rt_render: film coordinates beyond 32767 (the gather packs sample footprints as int16)");
@@ -1744,7 +1757,7 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
     if (!skip_film) {
         // film_slot_kernel for filters that reach 1 or 2 pixels either side (box .. gaussian at their default widths) and whose staged sample row
         // fits LDS; film_march_kernel for up to 3 rows; the staged gather for wider ones.  PBRT_HIP_GATHER=slot|march|staged forces one (tests).
-        const char *ge = std::getenv("PBRT_HIP_GATHER");
+        const char *ge = knob("PBRT_HIP_GATHER");
         const bool slot_ok = grx == gry && (grx == 1 || grx == 2);
         const int slot_ncs = slot_ok ? 64 / (2 * gry + 1) + 2 * grx : 0;
         const size_t slot_lds = size_t(slot_ncs) * size_t(fr.spp + 1) * 24 + 4096 + size_t(slot_ncs) * 8 + 16;
@@ -1756,7 +1769,7 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
             if (which == 1 && gry > 3) return fail(RT_EINVAL, "PBRT_HIP_GATHER=march: the filter reaches more than 3 rows");
         }
         int rows = 0;
-        if (const char *e = std::getenv("PBRT_HIP_GATHER_ROWS")) rows = std::max(1, std::atoi(e));
+        if (const char *e = knob("PBRT_HIP_GATHER_ROWS")) rows = std::max(1, std::atoi(e));
         if (which == 2) {
             const int nc = 64 / (2 * gry + 1);
             const unsigned nbx = unsigned((fr.x_pixel_count + nc - 1) / nc);

@@ -6,6 +6,8 @@ import sys
 import numpy as np
 import pytest
 
+os.environ.setdefault("PBRT_HIP_TUNE", "1")      # the library reads its PBRT_HIP_* experiment / flavour knobs only then (rt_kernels.hip knob())
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))

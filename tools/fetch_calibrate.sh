@@ -1,4 +1,5 @@
 #!/bin/bash
+export PBRT_HIP_TUNE=1   # the library reads its PBRT_HIP_* knobs only then
 # usage (GPU box): bash tools/fetch_calibrate.sh  -> gpurun_out/fetch_calibrate.txt
 set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/calib; mkdir -p $OUT

@@ -1,5 +1,6 @@
 """Build kernel variants (-D knobs) on the GPU box and bench each; prints one JSON line per variant."""
 import json, os, subprocess, sys
+os.environ.setdefault("PBRT_HIP_TUNE", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 HIP = os.path.join(ROOT, "pbrt-v1_amd", "csrc", "hip")

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PBRT_HIP_TUNE=1   # the library reads its PBRT_HIP_* knobs only then
 # Profile the bench command with rocprofv3 (GPU box).  usage: tools/profile_r.sh <tag> [bench args...]
 # Pass 1: --kernel-trace --stats (per-kernel time).  Passes 2-4: PMC counters, each in its own run.
 set -u

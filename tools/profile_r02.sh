@@ -1,4 +1,5 @@
 #!/bin/bash
+export PBRT_HIP_TUNE=1   # the library reads its PBRT_HIP_* knobs only then
 # GPU box: rocprofv3 evidence for one workload.  usage: tools/profile_r02.sh <workload>
 # Pass 1: --kernel-trace --stats.  Passes 2..: PMC counters, each group in its own run (no tracing domains next to --pmc).
 set -u

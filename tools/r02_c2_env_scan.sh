@@ -1,4 +1,5 @@
 #!/bin/bash
+export PBRT_HIP_TUNE=1   # the library reads its PBRT_HIP_* knobs only then
 # GPU box: the C2 headline frame under the megakernel's run-time scheduling knobs
 run() { env "$@" python bench.py --no-cpu-baseline --no-extra --steps 3 --warmup 1 2>/dev/null | TAG="$*" python -c '
 import json, os, sys

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PBRT_HIP_TUNE=1   # the library reads its PBRT_HIP_* knobs only then
 # GPU box: first contact of the queue pipeline -- parity, then the 1 M-triangle path frame with both architectures
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/r02_pipe1; mkdir -p $OUT

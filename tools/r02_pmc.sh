@@ -1,4 +1,5 @@
 #!/bin/bash
+export PBRT_HIP_TUNE=1   # the library reads its PBRT_HIP_* knobs only then
 # GPU box: PMC passes over the pipeline's kernels for one workload.  usage: tools/r02_pmc.sh <tag> <workload> [env...]
 TAG=$1; WL=$2
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG; mkdir -p $OUT

@@ -1,6 +1,7 @@
 """GPU box: rebuild only rt_trace.hip with -D knobs, relink, and time the 1 M-triangle path frame through the queue pipeline.
 usage: python tools/r02_trace_scan.py <group>"""
 import json, os, subprocess, sys
+os.environ.setdefault("PBRT_HIP_TUNE", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 HIP = os.path.join(ROOT, "pbrt-v1_amd", "csrc", "hip")

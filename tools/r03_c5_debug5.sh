@@ -1,3 +1,4 @@
+export PBRT_HIP_TUNE=1   # the library reads its PBRT_HIP_* knobs only then
 cd $GRAFT_REPO_ROOT
 python - <<'PY'
 import sys, os

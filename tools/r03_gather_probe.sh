@@ -1,4 +1,5 @@
 #!/bin/bash
+export PBRT_HIP_TUNE=1   # the library reads its PBRT_HIP_* knobs only then
 # film gather: march kernel vs the staged one (PBRT_HIP_GATHER), strip heights; parity tests first
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/r03_gather; mkdir -p $OUT

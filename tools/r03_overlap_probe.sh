@@ -1,4 +1,5 @@
 #!/bin/bash
+export PBRT_HIP_TUNE=1   # the library reads its PBRT_HIP_* knobs only then
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/r03_overlap; mkdir -p $OUT
 timeout 900 python tools/r03_vertex_check.py 2>&1 | grep -v "film_equal True counters_equal True" | tail -20 | tee $OUT/check.log

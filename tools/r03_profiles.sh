@@ -1,4 +1,5 @@
 #!/bin/bash
+export PBRT_HIP_TUNE=1   # the library reads its PBRT_HIP_* knobs only then
 # GPU box: the round's evidence: default bench line (driver-equivalent), rocprofv3 kernel stats + PMC passes per workload, the 10 M-triangle C4 record
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r03

@@ -1,5 +1,6 @@
 """GPU box: rebuild single units with -D knobs and time workloads.  usage: python tools/r03_scan.py <group>"""
 import json, os, subprocess, sys
+os.environ.setdefault("PBRT_HIP_TUNE", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import r02_trace_scan as T

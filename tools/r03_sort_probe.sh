@@ -1,4 +1,5 @@
 #!/bin/bash
+export PBRT_HIP_TUNE=1   # the library reads its PBRT_HIP_* knobs only then
 # GPU box: does ordering the ray queue by entry point pay?  1 M-triangle path frame through the queue pipeline, unsorted vs sorted
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/r03_sort; mkdir -p $OUT

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PBRT_HIP_TUNE=1   # the library reads its PBRT_HIP_* knobs only then
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/r03_vertex; mkdir -p $OUT
 timeout 600 python tools/r03_vertex_check.py 2>&1 | tail -40 | tee $OUT/check.log
