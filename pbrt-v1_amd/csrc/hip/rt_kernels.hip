@@ -375,13 +375,14 @@ __global__ __launch_bounds__(64, 2) void film_slot_kernel(const DevFrame *__rest
     const float fxw = fr.fxw, fyw = fr.fyw, kx16 = fr.inv_fxw * 16, ky16 = fr.inv_fyw * 16;   // (v * inv) * 16 == v * (inv * 16), see march_row
     const int nrec = NCS * spp;
 
-    auto resolve = [&](int buf, int sy) __attribute__((always_inline)) {           // lanes 0 .. NCS-1: where the staged columns of sample row sy live
+    auto resolve = [&](int buf, int sy) __attribute__((always_inline)) -> bool {   // lanes 0 .. NCS-1: where the staged columns of sample row sy live
+        unsigned base = ~0u;
         if (l < NCS) {
             const int sx = X0 - RX + l;
-            unsigned base = ~0u;
             if (sx >= fr.x_start && sx < fr.x_end) { bool mine; unsigned long long lp; gather_local_pixel(fr, sx, sy, mine, lp); if (mine) base = unsigned(lp); }
             colbase[buf * NCS + l] = base;
         }
+        return base != ~0u;
     };
     // record r of a staged row: column r % NCS, sample r / NCS (a load instruction covers NCS consecutive columns of 64 / NCS samples)
     auto request = [&](int buf, int r, float4 &L, float2 &xy) __attribute__((always_inline)) -> bool {
@@ -426,11 +427,25 @@ __global__ __launch_bounds__(64, 2) void film_slot_kernel(const DevFrame *__rest
     float4 pL[PF]; float2 pxy[PF]; unsigned pok = 0;                    // the next row's first PF records per lane, requested a row ahead
     const int sy_lo = max(yabs0 - RY, fr.y_start), sy_hi = min(yabs1 + RY, fr.y_end - 1);
     int cur = 0;
+    // 2-D shard tiles: a wave none of whose (at most a handful of) tiles belongs to this shard has nothing to add to its pixels
+    if (fr.tile_w > 0 && fr.shard_count > 1) {
+        if (sy_lo > sy_hi) return;
+        const int cx0 = max(X0 - RX, fr.x_start), cx1 = min(X0 - RX + NCS - 1, fr.x_end - 1);
+        bool any = false;
+        if (cx0 <= cx1)
+            for (unsigned ty = unsigned(sy_lo - fr.y_start) / unsigned(fr.tile_h); ty <= unsigned(sy_hi - fr.y_start) / unsigned(fr.tile_h); ++ty)
+                for (unsigned tx = unsigned(cx0 - fr.x_start) / unsigned(fr.tile_w); tx <= unsigned(cx1 - fr.x_start) / unsigned(fr.tile_w); ++tx)
+                    any |= int((ty * unsigned(fr.tiles_x) + tx) % unsigned(fr.shard_count)) == fr.shard_index;
+        if (!any) return;
+    }
+    // a sample row none of whose staged columns belongs to this shard is neither staged nor accumulated (N ranks: N - 1 of N rows of a wave)
+    bool cur_any = false;
     if (sy_lo <= sy_hi) {
-        resolve(0, sy_lo);
-        __syncthreads();
+        cur_any = __syncthreads_or(resolve(0, sy_lo));
+        if (cur_any) {
 #pragma unroll
-        for (int k = 0; k < PF; ++k) pok |= (request(0, l + 64 * k, pL[k], pxy[k]) ? 1u : 0u) << k;
+            for (int k = 0; k < PF; ++k) pok |= (request(0, l + 64 * k, pL[k], pxy[k]) ? 1u : 0u) << k;
+        }
     }
     for (int sy = yabs0 - RY; sy <= yabs1 + RY; ++sy) {
         const int y = sy - RY + q;
@@ -441,29 +456,31 @@ __global__ __launch_bounds__(64, 2) void film_slot_kernel(const DevFrame *__rest
             if (valid) { a01.x = accum[px]; a01.y = accum[plane + px]; a23.x = accum[2 * plane + px]; a23.y = accum[3 * plane + px]; a4 = accum[4 * plane + px]; }
         }
         if (sy >= sy_lo && sy <= sy_hi) {
-            __syncthreads();                                            // the previous row's accumulation pass is done with the staged row
+            if (cur_any) {
+                __syncthreads();                                        // the previous row's accumulation pass is done with the staged row
 #pragma unroll
-            for (int k = 0; k < PF; ++k) put(l + 64 * k, sy, (pok >> k) & 1u, pL[k], pxy[k]);
-            for (int r0 = l + 64 * PF; r0 < nrec; r0 += 256) {          // rows longer than the lookahead: four records per lane in flight
-                float4 L[4]; float2 xy[4]; bool ok[4];
+                for (int k = 0; k < PF; ++k) put(l + 64 * k, sy, (pok >> k) & 1u, pL[k], pxy[k]);
+                for (int r0 = l + 64 * PF; r0 < nrec; r0 += 256) {      // rows longer than the lookahead: four records per lane in flight
+                    float4 L[4]; float2 xy[4]; bool ok[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) ok[u] = request(cur, r0 + 64 * u, L[u], xy[u]);
+                    for (int u = 0; u < 4; ++u) ok[u] = request(cur, r0 + 64 * u, L[u], xy[u]);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) put(r0 + 64 * u, sy, ok[u], L[u], xy[u]);
+                    for (int u = 0; u < 4; ++u) put(r0 + 64 * u, sy, ok[u], L[u], xy[u]);
+                }
             }
-            const bool more = sy < sy_hi;
-            if (more) resolve(cur ^ 1, sy + 1);
-            __syncthreads();
-            if (more) {
+            const bool next_any = __syncthreads_or(sy < sy_hi ? resolve(cur ^ 1, sy + 1) : false);   // also: the staged row is complete
+            if (next_any) {
                 pok = 0;
 #pragma unroll
                 for (int k = 0; k < PF; ++k) pok |= (request(cur ^ 1, l + 64 * k, pL[k], pxy[k]) ? 1u : 0u) << k;
             }
             cur ^= 1;
+            const bool row_any = cur_any;
+            cur_any = next_any;
             const unsigned shy = valid ? unsigned(5 * q) : 25u;         // bits 25.. of the y word are clear: weight 0 for a lane without a pixel
             // the accumulation pass, column after column; RT_SLOT_UNROLL samples' LDS reads are issued together.  (A three-stage software pipeline --
             // records of batch b + 2 read, weights of b + 1 looked up, batch b accumulated -- measured slower: 2.36 vs 2.00 ms on C2.)
-            if (!(RT_SLOT_PROBE & 1))
+            if (!(RT_SLOT_PROBE & 1) && row_any)
 #pragma unroll
             for (int j = 0; j <= 2 * RX; ++j) {
                 const float4 RT_L *Lp = Larr + (xi + j) * lstride;
@@ -1773,9 +1790,9 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
         if (which == 2) {
             const int nc = 64 / (2 * gry + 1);
             const unsigned nbx = unsigned((fr.x_pixel_count + nc - 1) / nc);
-            if (!rows) {                                      // strip height: tall (a strip re-reads 2 ry rows of halo) but >= ~10 waves per CU
-                rows = 64;
-                while (rows > 8 && size_t(nbx) * size_t((fr.y_pixel_count + rows - 1) / rows) < size_t(10) * size_t(std::max(1, s->n_cus))) rows /= 2;
+            if (!rows) {                                      // strip height: 16 rows measured best or equal on every frame size, sample count and shard count
+                rows = 16;                                    // (profiles/r03_gather_rows.txt: taller = fewer waves, shorter = more halo rows); small films: 8
+                if (size_t(nbx) * size_t((fr.y_pixel_count + rows - 1) / rows) < size_t(4) * size_t(std::max(1, s->n_cus))) rows = 8;
             }
             const unsigned gb = nbx * unsigned((fr.y_pixel_count + rows - 1) / rows);
             const int per_lane = (slot_ncs * fr.spp + 63) / 64;           // records a lane stages per sample row: the lookahead covers them up to RT_SLOT_PF
