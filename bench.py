@@ -130,7 +130,7 @@ def run_workload(name, args, pkg, torch, dist, world, rank, device_index, steps,
     if not ps.valid or ps.errors:
         raise SystemExit("bench.py: the workload's scene description did not parse cleanly (%d errors): refusing to time a different scene" % ps.errors)
     emu = int(os.environ.get("PBRT_BENCH_EMULATE_WORLD", "0"))      # debugging aid: time rank 0's share of an N-rank job on one GPU
-    tiles = (args.tile_2d, args.tile_2d) if args.tile_2d > 0 else args.tile_pixels
+    tiles = (args.tile_2d, args.tile_h if args.tile_h > 0 else args.tile_2d) if args.tile_2d > 0 else args.tile_pixels
     ps.set_shard(rank, emu if (emu > 1 and world == 1) else world, tiles)
     # One accelerator build per node, not per rank: local rank 0 builds (all host cores: 10 M triangles take 15 s) and publishes the
     # flattened tree under /dev/shm; the other ranks map it (rt_scene_create_prebuilt).  Reference: every cropwindow process builds its own.
@@ -361,6 +361,7 @@ def main():
     # 2-D tiles of T x T pixels (multiples of the film gather's 16x16 blocks): a rank's samples fall on compact pieces of the film, so its
     # gather touches the blocks around them only; 0 = the 1-D tiles above
     ap.add_argument("--tile-2d", type=int, default=64)
+    ap.add_argument("--tile-h", type=int, default=0, help="height of the 2-D tiles when it differs from --tile-2d (experiments)")
     ap.add_argument("--merge", choices=["allreduce", "reduce_scatter"], default="reduce_scatter")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even for one rank: exercises the N > 1 code path on a single GPU")
     args = ap.parse_args()

@@ -289,6 +289,8 @@ typedef struct RtRenderStats {
     int32_t pipeline, iterations, timed_iterations;
     uint32_t slots;
     float shade_ms;            /* queue pipeline: the shade launches summed (they overlap the trace launches when the pool runs as two halves) */
+    int32_t bands;             /* megakernel: launches the frame was rendered in (bands of sample rows; the film rows a band completes are gathered while
+                                * the next bands render, and gather_ms is then only the share of the gather that follows the last render launch) */
 } RtRenderStats;
 /* ImageFilm::WriteImage's normalisation (image.cpp:157-203) of ANY 5-plane accumulator in device memory (planes of n floats each), e.g. the
  * rows of the film a rank owns after a reduce-scatter; rgb[n][3] and alpha[n] stay on the device.  Asynchronous on the scene's stream. */

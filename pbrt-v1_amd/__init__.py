@@ -126,7 +126,7 @@ class RtPrebuiltAccel(C.Structure):
 
 class RtRenderStats(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("render_ms", C.c_float), ("trace_ms", C.c_float), ("gather_ms", C.c_float),
-                ("pipeline", C.c_int32), ("iterations", C.c_int32), ("timed_iterations", C.c_int32), ("slots", C.c_uint32), ("shade_ms", C.c_float)]
+                ("pipeline", C.c_int32), ("iterations", C.c_int32), ("timed_iterations", C.c_int32), ("slots", C.c_uint32), ("shade_ms", C.c_float), ("bands", C.c_int32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -261,7 +261,7 @@ __device__ __forceinline__ void march_row(const DevFrame &fr, const float RT_L *
 }
 
 template <int RYMAX>
-__global__ __launch_bounds__(64) void film_march_kernel(const DevFrame *__restrict__ frp, int rx, int ry, int strip_rows) {
+__global__ __launch_bounds__(64) void film_march_kernel(const DevFrame *__restrict__ frp, int rx, int ry, int strip_rows, int row0, int row_end) {
     constexpr int NR = 2 * RYMAX + 1;
     const DevFrame &fr = *frp;
     __shared__ float ftab_s[256];                                       // FILTER_TABLE_SIZE^2 (film/image.cpp:53-64)
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(64) void film_march_kernel(const DevFrame *__restri
     const int lx = bx * 64 + int(threadIdx.x);
     const bool live = lx < fr.x_pixel_count;
     const int x = fr.x_pixel_start + lx;
-    const int ly0 = by * strip_rows, ly1 = min(ly0 + strip_rows, fr.y_pixel_count) - 1;
+    const int ly0 = row0 + by * strip_rows, ly1 = min(ly0 + strip_rows, row_end) - 1;
     const int yabs0 = fr.y_pixel_start + ly0, yabs1 = fr.y_pixel_start + ly1;
     const size_t plane = size_t(fr.x_pixel_count) * fr.y_pixel_count;
     float RT_G *accum = RT_GPTR(float, fr.accum);
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(64) void film_march_kernel(const DevFrame *__restri
 #endif
 // PF: records per lane of the NEXT sample row requested before the current row's accumulation pass (they arrive while it runs; 6 VGPRs each)
 template <int RX, int RY, int PF>
-__global__ __launch_bounds__(64, 2) void film_slot_kernel(const DevFrame *__restrict__ frp, int strip_rows) {
+__global__ __launch_bounds__(64, 2) void film_slot_kernel(const DevFrame *__restrict__ frp, int strip_rows, int row0, int row_end) {
     constexpr int NS = 2 * RY + 1, NC = 64 / NS, NCS = NC + 2 * RX;
     extern __shared__ __attribute__((aligned(16))) float4 slot_lds[];
     const DevFrame &fr = *frp;
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(64, 2) void film_slot_kernel(const DevFrame *__rest
     const int lx = bx * NC + xi;
     const bool col_live = (m < NS) & (lx < fr.x_pixel_count);
     const int X0 = fr.x_pixel_start + bx * NC;                          // the strip's first pixel column; staged column ci is sample pixel X0 - RX + ci
-    const int ly0 = by * strip_rows, ly1 = min(ly0 + strip_rows, fr.y_pixel_count) - 1;
+    const int ly0 = row0 + by * strip_rows, ly1 = min(ly0 + strip_rows, row_end) - 1;   // film rows [row0, row_end): the whole film, or one band of it
     const int yabs0 = fr.y_pixel_start + ly0, yabs1 = fr.y_pixel_start + ly1;
     const size_t plane = size_t(fr.x_pixel_count) * fr.y_pixel_count;
     float RT_G *accum = RT_GPTR(float, fr.accum);
@@ -600,6 +600,7 @@ static void hip_warn(hipError_t e, const char *what) {
 }
 #define HIPWARN(expr) hip_warn((expr), #expr)
 
+#define RT_MAX_BANDS 8
 struct RtScene {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -630,6 +631,9 @@ struct RtScene {
     RtVolume volume{};
     int spill_depth = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // banded frames (rt_render): render launches alternate between two streams, the bands' film gathers follow on the caller's stream
+    hipStream_t st_band[2] = {nullptr, nullptr}; hipEvent_t ev_band[RT_MAX_BANDS] = {}; DevFrame *dev_frames = nullptr; unsigned long long *band_counters = nullptr;
+    int last_bands = 1;
     bool have_timing = false;
     bool counting = true;
     uint32_t n_tris = 0;
@@ -1371,7 +1375,7 @@ static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel 
         s->trace_grids[k] = unsigned(prop.multiProcessorCount) * unsigned(per_cu < 1 ? 1 : per_cu);
         if (s->trace_grids[k] * RT_BLOCK > s->n_threads) s->n_threads = s->trace_grids[k] * RT_BLOCK;      // the spill area is shared
     }
-    HIPCHK(hipMalloc((void **)&s->spill, size_t(s->spill_depth) * s->n_threads * sizeof(uint4)));     // uint4 entries in the pair form, uint2 otherwise
+    HIPCHK(hipMalloc((void **)&s->spill, 2 * size_t(s->spill_depth) * s->n_threads * sizeof(uint4)));     // uint4 entries in the pair form, uint2 otherwise; x 2: two band launches of a frame can be resident at once
     HIPCHK(hipMalloc((void **)&s->dev_pool, sizeof(PipePool)));
     HIPCHK(hipMalloc((void **)&s->trace_qc, RT_QC_STRIDE * sizeof(unsigned)));
     HIPCHK(hipHostMalloc((void **)&s->h_qcount, size_t(RT_PIPE_QN) * RT_QC_STRIDE * sizeof(unsigned), hipHostMallocDefault));
@@ -1403,6 +1407,10 @@ int rt_scene_destroy(RtScene *s) {
     for (hipEvent_t e : s->pipe_ev) HIPWARN(hipEventDestroy(e));
     for (hipEvent_t e : s->pipe_fence) HIPWARN(hipEventDestroy(e));
     if (s->ev2) HIPWARN(hipEventDestroy(s->ev2));
+    for (int i = 0; i < 2; ++i) if (s->st_band[i]) { HIPWARN(hipStreamSynchronize(s->st_band[i])); HIPWARN(hipStreamDestroy(s->st_band[i])); }
+    for (int i = 0; i < RT_MAX_BANDS; ++i) if (s->ev_band[i]) HIPWARN(hipEventDestroy(s->ev_band[i]));
+    if (s->dev_frames) HIPWARN(hipFree(s->dev_frames));
+    if (s->band_counters) HIPWARN(hipFree(s->band_counters));
     if (s->ev0) HIPWARN(hipEventDestroy(s->ev0));
     if (s->ev1) HIPWARN(hipEventDestroy(s->ev1));
     if (s->own_stream && s->stream) HIPWARN(hipStreamDestroy(s->stream));
@@ -1502,6 +1510,13 @@ static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool nee
     fr.total_pixels = (unsigned long long)(fr.x_end - fr.x_start) * (unsigned long long)(fr.y_end - fr.y_start);
     if (fr.total_pixels * fr.spp > 0xFFFFFFFFull) return fail(RT_EINVAL, "more than 2^32 camera samples per frame");
     unsigned long long n_tiles = 0;
+    if (fr.shard_count == 1) {
+        // one shard: the tiles partition nothing, so the work list is the sample extent in scanline order.  (2-D tiles pad the extent to whole
+        // tiles and the padding's work items are fetched and dropped: 64 x 64 tiles cost C3 5 % of its frame, profiles/r03_work_order.txt.)
+        fr.tile_pixels = 1;
+        if (rd->tile_pixels < 0) { const int tw = (-rd->tile_pixels) & 0xffff, th = (-rd->tile_pixels) >> 16; if (tw < 1 || th < 1 || tw > 4096 || th > 4096) return fail(RT_EINVAL, "bad 2-D tile size"); }
+        n_tiles = fr.total_pixels;
+    } else
     if (rd->tile_pixels < 0) {                               // 2-D tiles: width in the low 16 bits of -tile_pixels, height above (pbrt_hip.h)
         const int tw = (-rd->tile_pixels) & 0xffff, th = (-rd->tile_pixels) >> 16;
         if (tw < 1 || th < 1 || tw > 4096 || th > 4096) return fail(RT_EINVAL, "bad 2-D tile size");
@@ -1746,11 +1761,86 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
     fr.samples = s->samples; s->samples_last = fr.total_work; s->samples_spp = fr.spp;
     HIPCHK(hipMemcpyAsync(s->filter_dev, rd->filter_table, 256 * sizeof(float), hipMemcpyHostToDevice, s->stream));
     { hipError_t pre = hipGetLastError(); if (pre != hipSuccess) return fail(RT_EDEVICE, std::string("pending HIP error before launch: ") + hipGetErrorString(pre)); }
+    // ---- which film gather: film_slot_kernel for filters that reach 1 or 2 pixels either side (box .. gaussian at their default widths) and whose
+    // staged sample row fits LDS; film_march_kernel for up to 3 rows; the staged gather for wider ones.  PBRT_HIP_GATHER=slot|march|staged forces one (tests).
+    const bool slot_ok = grx == gry && (grx == 1 || grx == 2);
+    const int slot_ncs = slot_ok ? 64 / (2 * gry + 1) + 2 * grx : 0;
+    const size_t slot_lds = size_t(slot_ncs) * size_t(fr.spp + 1) * 24 + 4096 + size_t(slot_ncs) * 8 + 16;
+    int which = (slot_ok && slot_lds <= 64 * 1024) ? 2 : gry <= 3 ? 1 : 0;
+    if (const char *ge = knob("PBRT_HIP_GATHER")) {
+        which = !std::strcmp(ge, "slot") ? 2 : !std::strcmp(ge, "march") ? 1 : !std::strcmp(ge, "staged") ? 0 : -1;
+        if (which < 0) return fail(RT_EINVAL, "PBRT_HIP_GATHER: slot, march or staged");
+        if (which == 2 && !(slot_ok && slot_lds <= 64 * 1024)) return fail(RT_EINVAL, "PBRT_HIP_GATHER=slot: needs equal filter reaches of 1 or 2 pixels and a sample row that fits 64 KB of LDS");
+        if (which == 1 && gry > 3) return fail(RT_EINVAL, "PBRT_HIP_GATHER=march: the filter reaches more than 3 rows");
+    }
+    int rows = 0;
+    if (const char *e = knob("PBRT_HIP_GATHER_ROWS")) rows = std::max(1, std::atoi(e));
+    auto launch_gather = [&](const DevFrame *dfr, int row0, int row_end) -> int {      // ImageFilm::AddSample for film rows [row0, row_end), on the caller's stream
+        const int nrows = row_end - row0;
+        if (nrows <= 0) return RT_OK;
+        if (which == 2) {
+            const int nc = 64 / (2 * gry + 1);
+            const unsigned nbx = unsigned((fr.x_pixel_count + nc - 1) / nc);
+            int r = rows;
+            if (!r) {                                         // strip height: 16 rows measured best or equal on every frame size, sample count and shard count
+                r = 16;                                       // (profiles/r03_gather_rows.txt: taller = fewer waves, shorter = more halo rows); small films: 8
+                if (size_t(nbx) * size_t((fr.y_pixel_count + r - 1) / r) < size_t(4) * size_t(std::max(1, s->n_cus))) r = 8;
+            }
+            const unsigned gb = nbx * unsigned((nrows + r - 1) / r);
+            const int per_lane = (slot_ncs * fr.spp + 63) / 64;           // records a lane stages per sample row: the lookahead covers them up to RT_SLOT_PF
+            auto k = grx == 1 ? (per_lane <= 4 ? film_slot_kernel<1, 1, 4> : film_slot_kernel<1, 1, RT_SLOT_PF>)
+                              : (per_lane <= 4 ? film_slot_kernel<2, 2, 4> : film_slot_kernel<2, 2, RT_SLOT_PF>);
+            hipLaunchKernelGGL(k, dim3(gb), dim3(64), slot_lds, s->stream, dfr, r, row0, row_end);
+        } else if (which == 1) {
+            const unsigned nbx = unsigned((fr.x_pixel_count + 63) / 64);
+            int r = rows;
+            if (!r) {                                         // strip height: the record re-reads shrink with it, the waves in flight too
+                r = 32;
+                while (r > 4 && size_t(nbx) * size_t((fr.y_pixel_count + r - 1) / r) < size_t(16) * size_t(std::max(1, s->n_cus))) r /= 2;
+            }
+            const unsigned gb = nbx * unsigned((nrows + r - 1) / r);
+            auto k = gry <= 1 ? film_march_kernel<1> : gry == 2 ? film_march_kernel<2> : film_march_kernel<3>;
+            hipLaunchKernelGGL(k, dim3(gb), dim3(64), 0, s->stream, dfr, grx, gry, r, row0, row_end);
+        } else {
+            const unsigned gb = unsigned((fr.x_pixel_count + 15) / 16) * unsigned((fr.y_pixel_count + 15) / 16);
+            const size_t lds_bytes = size_t(cols) * col_bytes + size_t(cols) * sizeof(unsigned long long) + 16;
+            hipLaunchKernelGGL(film_gather_kernel, dim3(gb), dim3(256), lds_bytes, s->stream, dfr, grx, gry, cols);
+        }
+        HIPCHK(hipGetLastError());
+        return RT_OK;
+    };
+    s->last_bands = 1;
+    bool film_done = false;
     if (fr.pipeline) {
         rc = render_pipeline(s, rd, fr, vol_levels, vol_nmax, vol_samp_words); if (rc) return rc;
     } else {
+        // ---- bands.  The work list of an unsharded frame is in scanline order, so a range of it is a band of sample rows; the frame is rendered as
+        // `bands` launches alternating between two streams and the film rows a band completes are gathered (on the caller's stream) while the next
+        // bands render: of the gather only the last band's share stays exposed, and it fills the machine while a render launch drains.  A pixel still
+        // receives its samples in the reference's order in ONE gather launch (the one after the last sample row that reaches it), so the film is
+        // the same bits; two launches can be resident at once, hence two sets of per-thread scratch.
+        int bands = 1;
+        if (const char *e = knob("PBRT_HIP_BANDS")) bands = std::max(1, std::min(RT_MAX_BANDS, std::atoi(e)));
+        if (fr.shard_count != 1 || fr.tile_w != 0 || which == 0 || skip_film || s->volume.present || fr.y_pixel_count < 64) bands = 1;
+        int row_cut[RT_MAX_BANDS + 1]; unsigned long long work_cut[RT_MAX_BANDS + 1];
+        if (bands > 1) {
+            // band k gathers film rows [row_cut[k], row_cut[k+1]) (cuts on multiples of 16 rows) once the work list is rendered up to work_cut[k+1]:
+            // every sample row that reaches a film row above the cut, i.e. sample rows < y_pixel_start + cut + gry
+            const unsigned long long per_row = (unsigned long long)(fr.x_end - fr.x_start) * fr.spp;
+            int nb = 0;
+            row_cut[0] = 0; work_cut[0] = 0;
+            for (int k = 1; k < bands; ++k) {
+                const int cut = int((long long)fr.y_pixel_count * k / bands / 16 * 16);
+                const long long srow = std::max<long long>(fr.y_start, std::min<long long>(fr.y_end, (long long)fr.y_pixel_start + cut + gry));
+                const unsigned long long w = (unsigned long long)(srow - fr.y_start) * per_row;
+                if (cut > row_cut[nb] && cut < fr.y_pixel_count && w > work_cut[nb] && w < fr.total_work) { ++nb; row_cut[nb] = cut; work_cut[nb] = w; }
+            }
+            ++nb; row_cut[nb] = fr.y_pixel_count; work_cut[nb] = fr.total_work;
+            bands = nb;
+        }
+        const int sets = bands > 1 ? 2 : 1;
         if (rd->integrator != RT_INTEGRATOR_PATH) {           // recursion frames for whitted / directlighting
-            rc = ensure(s, &s->frames, &s->frames_floats, size_t(rd->max_depth + 2) * RT_FRAME_WORDS * s->n_threads); if (rc) return rc;
+            rc = ensure(s, &s->frames, &s->frames_floats, size_t(sets) * size_t(rd->max_depth + 2) * RT_FRAME_WORDS * s->n_threads); if (rc) return rc;
             fr.frames = s->frames;
         }
         if (s->volume.present) {
@@ -1762,59 +1852,54 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
         if (fr.high_occupancy && !s->counting) variant = 24 + ((s->volume.present ? 1 : 0) * 2 + (s->accel_kind == RT_ACCEL_GRID ? 1 : 0)) * 3 + rd->integrator;
         if (s->has_ext && !s->counting) variant = 36 + ((s->volume.present ? 1 : 0) * 2 + (s->accel_kind == RT_ACCEL_GRID ? 1 : 0)) * 3 + rd->integrator;
         if (s->grids[variant] == 0) return fail(RT_ESTATE, "render kernel variant has no resident grid");
-        HIPCHK(hipMemcpyAsync(s->dev_frame, &fr, sizeof(DevFrame), hipMemcpyHostToDevice, s->stream));
-        HIPCHK(hipMemsetAsync(s->work_counter, 0, sizeof(unsigned long long), s->stream));
-        HIPCHK(hipEventRecord(s->ev0, s->stream));
-        hipLaunchKernelGGL(render_kernel_of(variant), dim3(s->grids[variant]), dim3(RT_BLOCK), 0, s->stream,
-                           (const DevScene *)s->dev_scene, (const DevFrame *)s->dev_frame);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(s->ev1, s->stream));
+        if (bands == 1) {
+            HIPCHK(hipMemcpyAsync(s->dev_frame, &fr, sizeof(DevFrame), hipMemcpyHostToDevice, s->stream));
+            HIPCHK(hipMemsetAsync(s->work_counter, 0, sizeof(unsigned long long), s->stream));
+            HIPCHK(hipEventRecord(s->ev0, s->stream));
+            hipLaunchKernelGGL(render_kernel_of(variant), dim3(s->grids[variant]), dim3(RT_BLOCK), 0, s->stream,
+                               (const DevScene *)s->dev_scene, (const DevFrame *)s->dev_frame);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(s->ev1, s->stream));
+        } else {
+            if (!s->st_band[0]) {
+                for (int i = 0; i < 2; ++i) HIPCHK(hipStreamCreateWithFlags(&s->st_band[i], hipStreamNonBlocking));
+                for (int i = 0; i < RT_MAX_BANDS; ++i) HIPCHK(hipEventCreateWithFlags(&s->ev_band[i], hipEventDisableTiming));
+                HIPCHK(hipMalloc((void **)&s->dev_frames, RT_MAX_BANDS * sizeof(DevFrame)));
+                HIPCHK(hipMalloc((void **)&s->band_counters, RT_MAX_BANDS * sizeof(unsigned long long)));
+            }
+            std::vector<DevFrame> host_frames;                               // (a pageable source is staged by the runtime before hipMemcpyAsync returns, as for `fr` above)
+            host_frames.assign(size_t(bands), fr);
+            for (int k = 0; k < bands; ++k) {
+                DevFrame &f = host_frames[size_t(k)];
+                f.work_begin = work_cut[k]; f.total_work = work_cut[k + 1];
+                f.work_counter = s->band_counters + k;
+                if (k & 1) {                                  // the second set of per-thread scratch
+                    f.spill = (decltype(f.spill))((uint4 *)s->spill + size_t(s->spill_depth) * s->n_threads);
+                    if (f.frames) f.frames = s->frames + size_t(rd->max_depth + 2) * RT_FRAME_WORDS * s->n_threads;
+                }
+            }
+            HIPCHK(hipMemcpyAsync(s->dev_frames, host_frames.data(), size_t(bands) * sizeof(DevFrame), hipMemcpyHostToDevice, s->stream));
+            HIPCHK(hipMemcpyAsync(s->dev_frame, &host_frames[0], sizeof(DevFrame), hipMemcpyHostToDevice, s->stream));
+            HIPCHK(hipMemsetAsync(s->band_counters, 0, RT_MAX_BANDS * sizeof(unsigned long long), s->stream));
+            HIPCHK(hipEventRecord(s->ev0, s->stream));
+            for (int i = 0; i < 2; ++i) HIPCHK(hipStreamWaitEvent(s->st_band[i], s->ev0, 0));
+            for (int k = 0; k < bands; ++k) {
+                hipLaunchKernelGGL(render_kernel_of(variant), dim3(s->grids[variant]), dim3(RT_BLOCK), 0, s->st_band[k & 1],
+                                   (const DevScene *)s->dev_scene, (const DevFrame *)(s->dev_frames + k));
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipEventRecord(s->ev_band[k], s->st_band[k & 1]));
+            }
+            for (int k = 0; k < bands; ++k) {
+                HIPCHK(hipStreamWaitEvent(s->stream, s->ev_band[k], 0));
+                if (k == bands - 1) HIPCHK(hipEventRecord(s->ev1, s->stream));           // every band rendered; what follows is the exposed share of the gather
+                rc = launch_gather((const DevFrame *)s->dev_frames, row_cut[k], row_cut[k + 1]); if (rc) return rc;
+            }
+            film_done = true;
+            s->last_bands = bands;
+        }
         s->last_pipeline = false;
     }
-    if (!skip_film) {
-        // film_slot_kernel for filters that reach 1 or 2 pixels either side (box .. gaussian at their default widths) and whose staged sample row
-        // fits LDS; film_march_kernel for up to 3 rows; the staged gather for wider ones.  PBRT_HIP_GATHER=slot|march|staged forces one (tests).
-        const char *ge = knob("PBRT_HIP_GATHER");
-        const bool slot_ok = grx == gry && (grx == 1 || grx == 2);
-        const int slot_ncs = slot_ok ? 64 / (2 * gry + 1) + 2 * grx : 0;
-        const size_t slot_lds = size_t(slot_ncs) * size_t(fr.spp + 1) * 24 + 4096 + size_t(slot_ncs) * 8 + 16;
-        int which = (slot_ok && slot_lds <= 64 * 1024) ? 2 : gry <= 3 ? 1 : 0;
-        if (ge) {
-            which = !std::strcmp(ge, "slot") ? 2 : !std::strcmp(ge, "march") ? 1 : !std::strcmp(ge, "staged") ? 0 : -1;
-            if (which < 0) return fail(RT_EINVAL, "PBRT_HIP_GATHER: slot, march or staged");
-            if (which == 2 && !(slot_ok && slot_lds <= 64 * 1024)) return fail(RT_EINVAL, "PBRT_HIP_GATHER=slot: needs equal filter reaches of 1 or 2 pixels and a sample row that fits 64 KB of LDS");
-            if (which == 1 && gry > 3) return fail(RT_EINVAL, "PBRT_HIP_GATHER=march: the filter reaches more than 3 rows");
-        }
-        int rows = 0;
-        if (const char *e = knob("PBRT_HIP_GATHER_ROWS")) rows = std::max(1, std::atoi(e));
-        if (which == 2) {
-            const int nc = 64 / (2 * gry + 1);
-            const unsigned nbx = unsigned((fr.x_pixel_count + nc - 1) / nc);
-            if (!rows) {                                      // strip height: 16 rows measured best or equal on every frame size, sample count and shard count
-                rows = 16;                                    // (profiles/r03_gather_rows.txt: taller = fewer waves, shorter = more halo rows); small films: 8
-                if (size_t(nbx) * size_t((fr.y_pixel_count + rows - 1) / rows) < size_t(4) * size_t(std::max(1, s->n_cus))) rows = 8;
-            }
-            const unsigned gb = nbx * unsigned((fr.y_pixel_count + rows - 1) / rows);
-            const int per_lane = (slot_ncs * fr.spp + 63) / 64;           // records a lane stages per sample row: the lookahead covers them up to RT_SLOT_PF
-            auto k = grx == 1 ? (per_lane <= 4 ? film_slot_kernel<1, 1, 4> : film_slot_kernel<1, 1, RT_SLOT_PF>)
-                              : (per_lane <= 4 ? film_slot_kernel<2, 2, 4> : film_slot_kernel<2, 2, RT_SLOT_PF>);
-            hipLaunchKernelGGL(k, dim3(gb), dim3(64), slot_lds, s->stream, (const DevFrame *)s->dev_frame, rows);
-        } else if (which == 1) {
-            const unsigned nbx = unsigned((fr.x_pixel_count + 63) / 64);
-            if (!rows) {                                      // strip height: the record re-reads shrink with it, the waves in flight too
-                rows = 32;
-                while (rows > 4 && size_t(nbx) * size_t((fr.y_pixel_count + rows - 1) / rows) < size_t(16) * size_t(std::max(1, s->n_cus))) rows /= 2;
-            }
-            const unsigned gb = nbx * unsigned((fr.y_pixel_count + rows - 1) / rows);
-            auto k = gry <= 1 ? film_march_kernel<1> : gry == 2 ? film_march_kernel<2> : film_march_kernel<3>;
-            hipLaunchKernelGGL(k, dim3(gb), dim3(64), 0, s->stream, (const DevFrame *)s->dev_frame, grx, gry, rows);
-        } else {
-            const unsigned gb = unsigned((fr.x_pixel_count + 15) / 16) * unsigned((fr.y_pixel_count + 15) / 16);
-            const size_t lds_bytes = size_t(cols) * col_bytes + size_t(cols) * sizeof(unsigned long long) + 16;
-            hipLaunchKernelGGL(film_gather_kernel, dim3(gb), dim3(256), lds_bytes, s->stream, s->dev_frame, grx, gry, cols);
-        }
-        HIPCHK(hipGetLastError());
-    }
+    if (!skip_film && !film_done) { rc = launch_gather((const DevFrame *)s->dev_frame, 0, fr.y_pixel_count); if (rc) return rc; }
     HIPCHK(hipEventRecord(s->ev2, s->stream));
     s->have_timing = true;
 #ifdef RT_PROFILE
@@ -1912,6 +1997,7 @@ int rt_last_render_stats(RtScene *s, RtRenderStats *out) {
         out->trace_ms = sum; out->shade_ms = sum2;
         out->slots = s->pipe_slots;
     } else out->trace_ms = out->render_ms;
+    out->bands = s->last_pipeline ? 0 : s->last_bands;
     return RT_OK;
 }
 

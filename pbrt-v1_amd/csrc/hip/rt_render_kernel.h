@@ -93,7 +93,7 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
                 if (have < n_want) {                                      // wave-uniform branch
                     const int leader = __ffsll((long long)want) - 1;
                     if (lane == leader) fresh = atomicAdd(fr.work_counter, (unsigned long long)RT_MEGA_CHUNK);
-                    fresh = uniform64(__shfl(fresh, leader));
+                    fresh = uniform64(__shfl(fresh, leader)) + fr.work_begin;
                 }
                 const unsigned long long rk = __popcll(want & ((1ull << lane) - 1ull));
                 const unsigned long long w_mine = rk < have ? w_next + rk : fresh + (rk - have);

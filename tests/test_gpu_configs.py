@@ -281,6 +281,17 @@ def test_c3_full_size_properties(pkg, scenes):
     ds = pkg.DeviceScene(ps); ds.render(); a = ds.film_accum(); ca = ds.counters()
     ds.reset_counters(); ds.clear_film(); ds.render(); a2 = ds.film_accum(); ca2 = ds.counters()
     ds.set_counting(False); ds.clear_film(); ds.render(); a3 = ds.film_accum()       # the timed flavour the bench uses
+    # banded frames (rt_render: the work list rendered as bands on two streams, each band's film rows gathered while the next bands render):
+    # same film bits, same counters, with two launches resident at once on their own per-thread scratch
+    for bands, counting in ((4, False), (3, True), (8, False)):
+        with pytest.MonkeyPatch.context() as mp:
+            mp.setenv("PBRT_HIP_BANDS", str(bands))
+            ds.set_counting(counting); ds.reset_counters(); ds.clear_film(); ds.render()
+            ab = ds.film_accum()
+            assert ds.last_stats()["bands"] == bands
+            assert np.array_equal(ab, a), (bands, float(np.abs(ab - a).max()))
+            if counting:
+                assert ds.counters() == ca
     ds.close()
     assert ca["camera_rays"] == 1921 * 1081 * 16 and ca["bad_samples"] == 0 and ca == ca2
     assert np.array_equal(a, a2) and np.array_equal(a, a3)
