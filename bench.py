@@ -131,7 +131,7 @@ def run_workload(name, args, pkg, torch, dist, world, rank, device_index, steps,
         raise SystemExit("bench.py: the workload's scene description did not parse cleanly (%d errors): refusing to time a different scene" % ps.errors)
     emu = int(os.environ.get("PBRT_BENCH_EMULATE_WORLD", "0"))      # debugging aid: time rank 0's share of an N-rank job on one GPU
     tiles = (args.tile_2d, args.tile_h if args.tile_h > 0 else args.tile_2d) if args.tile_2d > 0 else args.tile_pixels
-    ps.set_shard(rank, emu if (emu > 1 and world == 1) else world, tiles)
+    tiles_used = ps.set_shard(rank, emu if (emu > 1 and world == 1) else world, tiles, fit=True)   # 2-D tiles sized to pad the sample extent least
     # One accelerator build per node, not per rank: local rank 0 builds (all host cores: 10 M triangles take 15 s) and publishes the
     # flattened tree under /dev/shm; the other ranks map it (rt_scene_create_prebuilt).  Reference: every cropwindow process builds its own.
     shared = None
@@ -272,7 +272,7 @@ def run_workload(name, args, pkg, torch, dist, world, rank, device_index, steps,
                        "rays_per_camera_sample": round(rays_total / max(cam_total, 1), 3),
                        "kd_nodes": int(info.n_nodes), "kd_build_s": round(info.build_seconds, 4),
                        "parallelism": "%s dealt round-robin to %d rank(s); %s; accelerator built once per node (%.2f s scene create on rank 0)"
-                                      % ("2-D tiles of %dx%d pixels" % (args.tile_2d, args.tile_2d) if args.tile_2d > 0 else "tiles of %d consecutive pixels" % args.tile_pixels, world,
+                                      % ("2-D tiles of %dx%d pixels" % tuple(tiles_used) if args.tile_2d > 0 else "tiles of %d consecutive pixels" % args.tile_pixels, world,
                                          {"allreduce": "RCCL all-reduce(sum) of the 5-plane film, rank 0 resolves", "reduce_scatter": "RCCL reduce-scatter of film rows, per-rank resolve, all-gather of the resolved rows",
                                           "none": "single rank"}[merge], t_create),
                        "rng": "counter-based keyed RNG, seed 0"},
