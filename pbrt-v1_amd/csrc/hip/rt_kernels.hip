@@ -1510,13 +1510,6 @@ static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool nee
     fr.total_pixels = (unsigned long long)(fr.x_end - fr.x_start) * (unsigned long long)(fr.y_end - fr.y_start);
     if (fr.total_pixels * fr.spp > 0xFFFFFFFFull) return fail(RT_EINVAL, "more than 2^32 camera samples per frame");
     unsigned long long n_tiles = 0;
-    if (fr.shard_count == 1) {
-        // one shard: the tiles partition nothing, so the work list is the sample extent in scanline order.  (2-D tiles pad the extent to whole
-        // tiles and the padding's work items are fetched and dropped: 64 x 64 tiles cost C3 5 % of its frame, profiles/r03_work_order.txt.)
-        fr.tile_pixels = 1;
-        if (rd->tile_pixels < 0) { const int tw = (-rd->tile_pixels) & 0xffff, th = (-rd->tile_pixels) >> 16; if (tw < 1 || th < 1 || tw > 4096 || th > 4096) return fail(RT_EINVAL, "bad 2-D tile size"); }
-        n_tiles = fr.total_pixels;
-    } else
     if (rd->tile_pixels < 0) {                               // 2-D tiles: width in the low 16 bits of -tile_pixels, height above (pbrt_hip.h)
         const int tw = (-rd->tile_pixels) & 0xffff, th = (-rd->tile_pixels) >> 16;
         if (tw < 1 || th < 1 || tw > 4096 || th > 4096) return fail(RT_EINVAL, "bad 2-D tile size");
@@ -1597,6 +1590,14 @@ static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool nee
         if (fr.max_depth > 250 || fr.max_depth < 0) fr.pipeline = 0;     // the slot's control word holds depth in 8 bits
         for (int i = 0; i < fr.n2d; ++i) if (fr.two_d[i].n >= 65535) fr.pipeline = 0;         // ... and the light / sample cursors in 16 bits each
         if (s->dev.n_lights >= 65535u) fr.pipeline = 0;
+        if (fr.shard_count == 1 && !fr.pipeline) {
+            // One shard: the tiles partition nothing, and the megakernel then renders the sample extent in scanline order.  2-D tiles pad the extent to
+            // whole tiles and every dropped padding item idles a lane for about a ray's time: 64 x 64 tiles cost C3 5 % of its frame
+            // (profiles/r03_work_order.txt).  The queue pipeline keeps the caller's tiles: with millions of paths in flight their compactness is
+            // worth more (C5: L2 misses 5.3 G per frame in 64 x 64 tiles, 6.3 G in scanline order; 328 vs 332 ms).
+            fr.tile_w = fr.tile_h = fr.tiles_x = 0; fr.tile_pixels = 1;
+            fr.total_work = fr.total_pixels * fr.spp;
+        }
         if (fr.trav_mode == 3 && fr.high_occupancy) fr.trav_mode = 1;   // the high-occupancy kernels carry no pooled-leaf scratch
         if (fr.trav_mode < 0 || fr.trav_mode > 4) fr.trav_mode = 1;
     }
