@@ -1566,12 +1566,14 @@ static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool nee
         }
         const double per_leaf = s->per_leaf;
         const bool tiny = nn <= 4096 && per_leaf >= 1.5;       // few fat leaves: triangle tests dominate -> lock-step rounds
-        fr.trav_mode = tiny ? 3 : 2;                           // lock-step rounds with pooled leaf tests (C2: 83.0 vs 87.1 ms for plain
-                                                               // lock-step); else batched rounds (measured best on 100k-1M triangle soups)
+        const bool tiny_path = tiny && rd->integrator == RT_INTEGRATOR_PATH;
+        fr.trav_mode = (tiny && !tiny_path) ? 3 : 2;           // tiny trees, Whitted / DirectLighting: lock-step rounds with pooled leaf tests; else batched
+                                                               // rounds (measured best on 100k-1M triangle soups and, since the spill-free round-3 build,
+                                                               // for the path integrator on tiny trees too: profiles/r03_c2_knobs.txt)
         // long divergent rays: let finished lanes refill early.  Tiny scenes: only with phase gating (path integrator), where 8
         // measured +1.5 % (16: -13 %); Whitted / DirectLighting on Cornell lose 10 % with any early exit
         fr.exit_thresh = tiny ? (rd->integrator == RT_INTEGRATOR_PATH ? 8 : 0) : 32;
-        fr.high_occupancy = tiny ? 0 : 1;
+        fr.high_occupancy = (tiny && !tiny_path) ? 0 : 1;      // C2 (round 3): 4-wave flavour + batched rounds + exit threshold 8 = 54.0 ms, natural allocation + pooled lock-step 56.5
         if (const char *e = knob("PBRT_HIP_HIGH_OCC")) fr.high_occupancy = std::atoi(e);
         if (const char *e = knob("PBRT_HIP_TRAV_MODE")) fr.trav_mode = std::atoi(e);
         if (const char *e = knob("PBRT_HIP_EXIT_THRESH")) fr.exit_thresh = std::atoi(e);
@@ -1736,7 +1738,6 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
     int cols = int((lds_kb << 10) / col_bytes);
     if (fr.x_pixel_start + fr.x_pixel_count > 32767 || fr.y_pixel_start + fr.y_pixel_count > 32767 || fr.x_pixel_start < -32768 || fr.y_pixel_start < -32768)
         return fail(RT_EINVAL, "rt_render: film coordinates beyond 32767 (the gather packs sample footprints as int16)");
-    if (cols < 1) return fail(RT_EINVAL, "rt_render: more samples per pixel than the film gather stages in LDS (max ~1900)");
     if (cols > 16 + 2 * grx) cols = 16 + 2 * grx;
     if (cols > 256) cols = 256;                               // one thread per column resolves the record addresses of a chunk
     if (!(fr.fxw > 0.f) || !(fr.fyw > 0.f)) return fail(RT_EINVAL, "rt_render: filter widths must be positive");
@@ -1774,6 +1775,7 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
         if (which == 2 && !(slot_ok && slot_lds <= 64 * 1024)) return fail(RT_EINVAL, "PBRT_HIP_GATHER=slot: needs equal filter reaches of 1 or 2 pixels and a sample row that fits 64 KB of LDS");
         if (which == 1 && gry > 3) return fail(RT_EINVAL, "PBRT_HIP_GATHER=march: the filter reaches more than 3 rows");
     }
+    if (which == 0 && cols < 1) return fail(RT_EINVAL, "rt_render: more samples per pixel than the staged film gather holds in LDS (max ~1270; filters that reach at most 3 rows take film_march_kernel, which has no limit)");
     int rows = 0;
     if (const char *e = knob("PBRT_HIP_GATHER_ROWS")) rows = std::max(1, std::atoi(e));
     auto launch_gather = [&](const DevFrame *dfr, int row0, int row_end) -> int {      // ImageFilm::AddSample for film rows [row0, row_end), on the caller's stream

@@ -64,6 +64,12 @@ elif g == "region":
             bench("region%d_%s" % (m, wl), workload=wl)
         bench("region%d_c5" % m, workload="c5")
 
+elif g == "c2occ":
+    # C2 on the register-capped flavour (batched rounds, exit threshold 8) at 4 / 5 / 6 / 3 waves per SIMD
+    for w in (5, 6, 3, 4):
+        T.rebuild("rt_mega_p", ["-DRT_HIGH_OCC_WAVES=%d" % w])
+        for et in (8, 12):
+            bench("c2_occwaves%d_et%d" % (w, et), env={"PBRT_HIP_HIGH_OCC": "1", "PBRT_HIP_TRAV_MODE": "2", "PBRT_HIP_EXIT_THRESH": str(et)}, workload="c2")
 elif g == "slot2":
     for pf, un in ((8, 8), (4, 8), (10, 8)):
         T.rebuild("rt_kernels", ["-DRT_SLOT_PF=%d" % pf, "-DRT_SLOT_UNROLL=%d" % un])
