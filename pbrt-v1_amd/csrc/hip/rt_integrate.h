@@ -753,9 +753,6 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
 // shadow ray, from a MIS ray or straight from a vertex.  (A switch executed once per transition would run every
 // stage body once per lane phase: ~8x lower SIMD utilisation with 64 lanes at random phases.)  Backward edges
 // (next light of the all-lights loop, popping a recursion frame) simply take another pass.
-#ifdef RT_PROFILE_STAGES
-__device__ unsigned long long g_pf_stage[64];
-#endif
 // Phase gating (path integrator): a path alternates [closest-hit ray -> VERTEX, DIRECT_NEXT -> shadow ray] and
 // [shadow ray -> SHADOW_DONE .. BOUNCE -> closest-hit ray]; 64 lanes at random phases run every pass of a sweep half
 // empty.  With `phase` 0 / 1 a sweep runs only the first / second group and the kernel alternates them, so the lanes of
@@ -773,7 +770,7 @@ RT_DEV void advance_pass(const DevScene &sc, const DevFrame &fr, Lane &ln, unsig
 #ifdef RT_PROFILE_STAGES
 #define RT_RUN(S) { const unsigned long long m_ = __ballot(!ln.has_ray && ln.stage == S); if (m_) { const unsigned long long t_ = __builtin_readcyclecounter(); \
         if (!ln.has_ray && ln.stage == S) stage_body<COUNT, INTEG, VOL, EXT, S, DEFER>(sc, fr, ln, gtid, c_closest, c_any, c_bad); \
-        if (__lane_id() == 0) { atomicAdd(&g_pf_stage[2 * S], __builtin_readcyclecounter() - t_); atomicAdd(&g_pf_stage[2 * S + 1], (unsigned long long)__popcll(m_) | (1ull << 40)); } } }
+        if (__lane_id() == 0) { atomicAdd(fr.counters + 24 + 2 * S, __builtin_readcyclecounter() - t_); atomicAdd(fr.counters + 24 + 2 * S + 1, (unsigned long long)__popcll(m_) | (1ull << 40)); } } }
 #else
 #define RT_RUN(S) if (!ln.has_ray && ln.stage == S) stage_body<COUNT, INTEG, VOL, EXT, S, DEFER>(sc, fr, ln, gtid, c_closest, c_any, c_bad)
 #endif

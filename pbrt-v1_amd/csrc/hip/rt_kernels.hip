@@ -1361,8 +1361,8 @@ static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel 
     s->n_threads = s->grid * RT_BLOCK;
     s->spill_depth = s->tree.max_depth > RT_TRACE_STACK ? s->tree.max_depth - RT_TRACE_STACK + 1 : 1;     // RT_TRACE_STACK <= RT_STACK_LDS
     HIPCHK(hipMalloc((void **)&s->work_counter, sizeof(unsigned long long)));
-    HIPCHK(hipMalloc((void **)&s->counters, 24 * sizeof(unsigned long long)));
-    HIPCHK(hipMemsetAsync(s->counters, 0, 24 * sizeof(unsigned long long), s->stream));
+    HIPCHK(hipMalloc((void **)&s->counters, 64 * sizeof(unsigned long long)));        // 8 RtCounters, 16 RT_PROFILE, 2 x 16 RT_PROFILE_STAGES
+    HIPCHK(hipMemsetAsync(s->counters, 0, 64 * sizeof(unsigned long long), s->stream));
     HIPCHK(hipMalloc((void **)&s->filter_dev, 256 * sizeof(float)));
     HIPCHK(hipMalloc((void **)&s->dev_scene, sizeof(DevScene)));
     HIPCHK(hipMalloc((void **)&s->dev_frame, sizeof(DevFrame)));
@@ -1912,6 +1912,16 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
         HIPCHK(hipMemcpy(v, s->counters, sizeof v, hipMemcpyDeviceToHost));
         std::fprintf(stderr, "RT_PROFILE shade_cyc=%llu trav_cyc=%llu outer=%llu inner=%llu rounds=%llu act_lane_rounds=%llu rays_at_trav_start=%llu desc_cyc=%llu leaf_cyc=%llu chunks=%llu pooled_rounds=%llu leaf_iters=%llu\n",
                      v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15], v[16], v[17], v[18], v[19]);
+#ifdef RT_PROFILE_STAGES
+        {   // cycles (wave-level, summed over waves) and lane visits per stage of the state machine (rt_integrate.h advance_pass)
+            unsigned long long st[32];
+            HIPCHK(hipMemcpy(st, s->counters + 24, sizeof st, hipMemcpyDeviceToHost));
+            static const char *names[16] = {"FETCH", "VERTEX", "DIRECT_NEXT", "SHADOW_DONE", "MIS_DONE", "ED_BSDF", "ED_DONE", "BOUNCE", "SPECULAR", "SPEC_TRANS", "RETURN", "VOL_BEGIN", "VOL_STEP", "POP", "FINISH", "EXIT"};
+            for (int i = 0; i < 16; ++i) if (st[2 * i + 1])
+                std::fprintf(stderr, "RT_PROFILE_STAGE %-12s cycles=%llu passes=%llu lane_visits=%llu\n", names[i], st[2 * i], st[2 * i + 1] >> 40, st[2 * i + 1] & ((1ull << 40) - 1));
+            HIPCHK(hipMemsetAsync(s->counters + 24, 0, 32 * sizeof(unsigned long long), s->stream));
+        }
+#endif
         HIPCHK(hipMemsetAsync(s->counters + 8, 0, 16 * sizeof(unsigned long long), s->stream));
     }
 #endif

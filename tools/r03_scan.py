@@ -56,6 +56,16 @@ elif g == "prof":
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-extra", "--steps", "1", "--warmup", "0", "--workload", wl], env=e, capture_output=True, text=True, timeout=600)
         print(wl, "\n".join([l for l in r.stderr.splitlines() if l.startswith("RT_PROFILE")][-1:]), flush=True)
 
+elif g == "stages":
+    # per-stage cycle budget of the megakernel (-DRT_PROFILE -DRT_PROFILE_STAGES: s_memtime around every stage of the state machine)
+    for u in ("rt_mega_p", "rt_mega_d", "rt_kernels"):
+        T.rebuild(u, ["-DRT_PROFILE", "-DRT_PROFILE_STAGES"])
+    for wl in ("c2", "c3", "p1000000"):
+        e = dict(os.environ); e["PBRT_HIP_PIPELINE"] = "0"
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-extra", "--steps", "1", "--warmup", "0", "--workload", wl], env=e, capture_output=True, text=True, timeout=600)
+        print("==", wl, flush=True)
+        print("\n".join([l for l in r.stderr.splitlines() if l.startswith("RT_PROFILE")][-20:]), flush=True)
+        if r.returncode: print(r.stderr[-600:], flush=True)
 elif g == "region":
     for m in (2, 4, 6, 0):
         for u in ("rt_mega_p", "rt_mega_d", "rt_trace"):
