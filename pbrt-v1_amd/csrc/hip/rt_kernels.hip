@@ -906,11 +906,13 @@ static int render_pipeline(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, int
     // PathIntegrator without a medium: one shade pass per path vertex, all of a vertex's rays in one trace launch (rt_pipe_vertex.h)
     bool by_vertex = integ == RT_INTEGRATOR_PATH && !s->volume.present;
     if (const char *e = knob("PBRT_HIP_PIPE_VERTEX")) by_vertex = by_vertex && std::atoi(e) != 0;
-    // ---- pool size: 8 M slots unless the frame is smaller or the per-slot scratch would not fit (a fine ray march: 3 floats per step)
+    // ---- pool size: 32 M slots with a medium, 8 M without, unless the frame is smaller or the per-slot scratch would not fit (a fine ray march: 3 floats per step)
     const size_t frame_words = integ != RT_INTEGRATOR_PATH ? size_t(rd->max_depth + 2) * RT_FRAME_WORDS : 0;
     const size_t vol_words = s->volume.present ? size_t(vol_levels) * 8 + 13 + vol_samp_words : 0;
     const size_t slot_bytes = size_t(RT_PIPE_VEC) * 16 + 2 * 16 + 3 * 16 + 4 * 16 + 3 * 4 + (frame_words + vol_words) * 4;
-    unsigned want = 1u << 23;
+    // (C5, 64 spp with a march per ray: 8 M slots 329 ms, 16 M 311, 32 M 289, 48 M 312, 64 M 326 -- fewer, fuller iterations until the shade passes' state
+    // traffic takes over; the by-vertex path frame on the 1 M tree: 8 M 70.6 ms, 16 M 72.1; profiles/r03_c5_knobs.txt)
+    unsigned want = s->volume.present ? 1u << 25 : 1u << 23;
     {
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
