@@ -111,6 +111,7 @@ struct DevFrame {
     int exit_thresh;             // leave the shared traversal loop when <= this many lanes still traverse (0 = never)
     int phase_sync;             // path integrator: alternate the two halves of the state machine between sweeps (rt_integrate.h)
     int high_occupancy;          // host-side choice of the 5-waves/SIMD kernel flavour (not read by the device)
+    int leaf_min;                // batched rounds: keep testing leaf primitives while at least this many lanes hold an untested one
     int trav_mode;               // 0 = one node per lane per round, 1 = lock-step (descend all, then test), 2 = batched
     int pipeline;                // host-side choice: the queue pipeline (rt_pipeline.h) instead of the megakernel (not read by the device)
     unsigned long long total_work;     // samples this shard renders (a banded frame, rt_render: the END of this band's range of the work list)

@@ -1577,6 +1577,8 @@ static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool nee
         fr.exit_thresh = tiny ? (rd->integrator == RT_INTEGRATOR_PATH ? 8 : 0) : 32;
         fr.high_occupancy = (tiny && !tiny_path) ? 0 : 1;      // C2 (round 3): 4-wave flavour + batched rounds + exit threshold 8 = 54.0 ms, natural allocation + pooled lock-step 56.5
         if (const char *e = knob("PBRT_HIP_HIGH_OCC")) fr.high_occupancy = std::atoi(e);
+        fr.leaf_min = tiny ? 8 : RT_TRACE_LEAF_MIN;          // C2: 50.8 ms at 8, 54.0 at 24 (few fat leaves: waiting for a fuller batch only idles lanes)
+        if (const char *e = knob("PBRT_HIP_LEAF_MIN")) fr.leaf_min = std::max(1, std::atoi(e));
         if (const char *e = knob("PBRT_HIP_TRAV_MODE")) fr.trav_mode = std::atoi(e);
         if (const char *e = knob("PBRT_HIP_EXIT_THRESH")) fr.exit_thresh = std::atoi(e);
         fr.dbg_x = fr.dbg_y = -1000000;

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
             RT_PF(++pf_rounds; pf_act += __popcll(am);)
             if (fr.exit_thresh > 0 && __popcll(am) <= fr.exit_thresh && __any(!act && ln.stage != ST_EXIT)) break;
             if (fr.trav_mode == 1) accel_round<COUNT, ACCEL, EXT>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc);
-            else if (fr.trav_mode == 2) trace_round<COUNT, ACCEL, EXT, RT_STACK_LDS, !POOL>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, lds_tm, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc);
+            else if (fr.trav_mode == 2) trace_round<COUNT, ACCEL, EXT, RT_STACK_LDS, !POOL>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, lds_tm, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc, fr.leaf_min);
             else if (fr.trav_mode == 4) accel_round_batched<COUNT, ACCEL, EXT>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc);
             else if (POOL && fr.trav_mode == 3) accel_round_pooled<COUNT, ACCEL, EXT>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc, pool);
             else if (act) accel_step<COUNT, ACCEL, EXT>(ln.tv, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc);

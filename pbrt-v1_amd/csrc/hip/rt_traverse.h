@@ -661,7 +661,7 @@ RT_DEV void accel_round_batched(Trav &tv, bool mine, const DevScene &sc, uint2 R
                                   // instructions in the trace kernel and measurably slower (round 3: 1 M path 64.4 -> 68.9 ms, C5 trace 195 -> 205 ms)
 #endif
 #ifndef RT_TRACE_LEAF_MIN
-#define RT_TRACE_LEAF_MIN 24      // keep testing primitives while at least this many lanes have one left
+#define RT_TRACE_LEAF_MIN 24      // keep testing primitives while at least this many lanes have one left (the megakernel takes DevFrame::leaf_min: 8 on tiny trees)
 #endif
 
 // ---- the trace kernel's own traversal steps ------------------------------------------------------------------------------
@@ -976,7 +976,8 @@ RT_DEV void kdp_pop(Trav &tv, bool done, PairStack st, unsigned n_threads, unsig
 #define RT_TRACE_LEAF_GO 65       // leave the descent steps early once this many lanes hold an untested primitive (65 = never)
 #endif
 template <bool COUNT, int ACCEL, bool EXT, int NS, bool PAIRS_OK = true, int DSTEPS = RT_TRACE_DSTEPS>
-RT_DEV void trace_round(Trav &tv, bool busy, const DevScene &sc, uint2 RT_L *lds_stack, float RT_L *lds_tm, uint2 RT_G *spill, unsigned n_threads, unsigned gtid, TravCounters &cnt) {
+RT_DEV void trace_round(Trav &tv, bool busy, const DevScene &sc, uint2 RT_L *lds_stack, float RT_L *lds_tm, uint2 RT_G *spill, unsigned n_threads, unsigned gtid, TravCounters &cnt,
+                        int leaf_min = RT_TRACE_LEAF_MIN) {
     constexpr bool PAIRS = PAIRS_OK && ACCEL != RT_ACCEL_GRID && !EXT;
     const PairStack pst = {lds_stack, lds_tm, (uint4 RT_G *)spill};
     if (ACCEL == RT_ACCEL_GRID) {
@@ -1013,7 +1014,7 @@ RT_DEV void trace_round(Trav &tv, bool busy, const DevScene &sc, uint2 RT_L *lds
         if (nl == 0) break;
         if (ACCEL == RT_ACCEL_GRID || EXT) { if (leafw) leaf_test_one<COUNT, ACCEL == RT_ACCEL_GRID, EXT>(tv, sc, cnt); }
         else leaf_test_flat<COUNT>(tv, leafw, sc, cnt);
-        if (nl < RT_TRACE_LEAF_MIN) break;
+        if (nl < leaf_min) break;
     }
     const bool done = busy && tv.active && tv.at_leaf && tv.li >= tv.ln_;
     if (ACCEL == RT_ACCEL_GRID) { if (done) grid_voxel_done(tv, sc); }

@@ -74,6 +74,19 @@ elif g == "region":
             bench("region%d_%s" % (m, wl), workload=wl)
         bench("region%d_c5" % m, workload="c5")
 
+elif g == "c5final":
+    # C5 on the 32 M-slot pool: steps per round of the trace kernel, waves of the volume shade kernels, leaf batch
+    for defs in (["-DRT_PIPE_TRACE_DSTEPS=2"], ["-DRT_TRACE_LEAF_MIN=16"], ["-DRT_TRACE_LEAF_MIN=32"], []):
+        T.rebuild("rt_trace", defs)
+        bench("c5final_trace_%s" % "_".join(defs), workload="c5", steps=2)
+    for w in (2, 4, 3):
+        T.rebuild("rt_pipe_d", ["-DRT_SHADE_VOL_WAVES=%d" % w])
+        bench("c5final_shadewaves%d" % w, workload="c5", steps=2)
+elif g == "c2steps":
+    # C2 on the 4-wave flavour with batched rounds: steps per round and leaf batch (tuned on the 1 M-triangle frames so far)
+    for ds, lm in ((1, 24), (2, 8), (1, 8), (3, 24), (2, 24)):
+        T.rebuild("rt_mega_p", ["-DRT_TRACE_DSTEPS=%d" % ds, "-DRT_TRACE_LEAF_MIN=%d" % lm])
+        bench("c2steps_d%d_l%d" % (ds, lm), workload="c2", steps=2)
 elif g == "c2occ":
     # C2 on the register-capped flavour (batched rounds, exit threshold 8) at 4 / 5 / 6 / 3 waves per SIMD
     for w in (5, 6, 3, 4):
