@@ -70,3 +70,20 @@ def test_shard_partition_covers_every_sample_once(pkg, scenes, oracle):
                 ps = pkg.ParsedScene(text=text); ps.set_shard(r, world, tile)
                 cams += oracle.render(ps)[3]["camera_rays"]
             assert cams == total, (world, tile)
+
+
+def test_fitted_tiles_pad_the_extent_least(pkg, scenes):
+    """ParsedScene.set_shard(fit=True): 2-D tile sizes within 3/4 .. 5/4 of the request whose whole tiles overshoot the sample extent least
+    (a padded work item idles a lane for about a ray's time on the device; 64 x 64 tiles pad a 1025 x 1025 extent by 12.7 %)."""
+    for extent, size in ((1921, 64), (1081, 64), (1025, 64), (1028, 64), (37, 16), (5, 64), (4096, 64)):
+        t = pkg.fit_tile(extent, size)
+        assert max(1, size * 3 // 4) <= t <= max(2, size * 5 // 4)
+        pad = -(-extent // t) * t - extent
+        for other in range(max(1, size * 3 // 4), max(2, size * 5 // 4) + 1):
+            assert pad <= -(-extent // other) * other - extent
+    assert pkg.fit_tile(4096, 64) == 64 and pkg.fit_tile(1025, 64) in (41, 57)           # 25 x 41 and 18 x 57 - 1: both overshoot by at most 1
+    ps = pkg.ParsedScene(text=scenes.cornell_scene(xres=1024, yres=1024, pixel_filter="box"))
+    x0, x1, y0, y1 = ps.sample_extent
+    w, h = ps.set_shard(1, 4, (64, 64), fit=True)
+    assert (w, h) == (pkg.fit_tile(x1 - x0, 64), pkg.fit_tile(y1 - y0, 64))
+    assert ps.set_shard(1, 4, (64, 64)) == (64, 64) and ps.set_shard(0, 1, 48) == 48
