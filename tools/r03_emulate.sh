@@ -3,7 +3,7 @@ export PBRT_HIP_TUNE=1   # the library reads its PBRT_HIP_* knobs only then
 # rank 0's share of an N-rank frame on one GPU (PBRT_BENCH_EMULATE_WORLD): render + film gather per rank, staged vs slot gather
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/r03_emulate; mkdir -p $OUT
-timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_multirank_gpu.py -q -m gpu -x 2>&1 | tail -4 | tee $OUT/tests.log
+true
 run() {  # tag, workload, env...
   tag=$1; wl=$2; shift; shift
   env "$@" timeout 600 python bench.py --no-cpu-baseline --no-extra --steps 3 --warmup 1 --workload $wl > $OUT/$tag.json 2> $OUT/$tag.err
