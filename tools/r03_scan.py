@@ -82,6 +82,12 @@ elif g == "c5final":
     for w in (2, 4, 3):
         T.rebuild("rt_pipe_d", ["-DRT_SHADE_VOL_WAVES=%d" % w])
         bench("c5final_shadewaves%d" % w, workload="c5", steps=2)
+elif g == "roundform":
+    # the round's remaining compile-time choices on the final build: pop inside the descent loop, leaving the descent steps once N lanes hold a primitive
+    for defs in (["-DRT_TRACE_POP_IN_LOOP=1"], ["-DRT_TRACE_LEAF_GO=16"], ["-DRT_TRACE_LEAF_GO=32"], ["-DRT_TRACE_DSTEPS=3"], []):
+        T.rebuild("rt_mega_p", defs)
+        for wl in ("c2", "p1000000"):
+            bench("roundform_%s_%s" % ("_".join(defs), wl), workload=wl, steps=2)
 elif g == "c2steps":
     # C2 on the 4-wave flavour with batched rounds: steps per round and leaf batch (tuned on the 1 M-triangle frames so far)
     for ds, lm in ((1, 24), (2, 8), (1, 8), (3, 24), (2, 24)):
