@@ -177,7 +177,10 @@ typedef struct RtRenderDesc {
      * pixels; this call renders tiles t with t % shard_count == shard_index.
      * tile_pixels < 0 selects 2-D tiles: -tile_pixels = tile_w | tile_h << 16, blocks of tile_w x tile_h pixels of the sample extent
      * numbered row by row (border blocks are clipped).  A rank then owns compact pieces of the film: its film gather touches only the
-     * blocks around them, and the partial films can be merged row-wise (bench.py: reduce-scatter + per-rank resolve). */
+     * blocks around them, and the partial films can be merged row-wise (bench.py: reduce-scatter + per-rank resolve).
+     * Border blocks are whole blocks whose pixels outside the extent are fetched and dropped (a lane idles for about a ray's time per dropped
+     * item): pick sizes that pad the extent little (pbrt-v1_amd ParsedScene.set_shard(fit=True)).  With shard_count == 1 the tiles partition
+     * nothing and a frame without a medium is rendered in scanline order whatever is passed here. */
     int32_t shard_index, shard_count, tile_pixels;
 } RtRenderDesc;
 
