@@ -678,8 +678,19 @@ static void host_tri_frame(const float *v, bool flip, float nn[3], float sn[3]) 
 // consecutive 48-byte records; its run starts at a 128-byte boundary whenever starting where the previous leaf ended would make
 // it touch more 128-byte lines than necessary (measured: one L2 miss costs the same whether 8 or 128 bytes of the line are used,
 // ~56 G misses/s for the whole chip, and the 1 M-triangle frame makes 17 triangle tests per ray).
+// A vector whose resize() leaves the new elements uninitialised: the 12 GB of leaf-ordered records of a 10 M-triangle scene are first touched by
+// the threads that fill them, not zero-filled page by page by one thread beforehand.
+template <class T> struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInitAlloc<U>; };
+    NoInitAlloc() = default;
+    template <class U> NoInitAlloc(const NoInitAlloc<U> &) {}
+    template <class U> void construct(U *) noexcept {}
+    template <class U, class... A> void construct(U *p, A &&...a) { ::new ((void *)p) U(std::forward<A>(a)...); }
+};
+typedef std::vector<float4, NoInitAlloc<float4>> LeafRecords;
+
 static void build_leaf_order(const std::vector<Node> &nodes, const std::vector<uint32_t> &leaf_refs, const std::vector<DevTri> &tris,
-                             std::vector<Node> &tnodes, std::vector<float4> &ltris) {
+                             std::vector<Node> &tnodes, LeafRecords &ltris) {
     tnodes = nodes;
     // pass 1 (sequential, arithmetic only): where every leaf's run starts
     size_t off = 0;                                       // float4 units (16 B); a line is 8 units
@@ -694,16 +705,26 @@ static void build_leaf_order(const std::vector<Node> &nodes, const std::vector<u
         tnodes[i].y = uint32_t(off);                     // (a run beyond 2^32 units is refused by the caller through ltris.size())
         off += units;
     }
-    if (off >= (size_t(1) << 32)) { ltris.assign(off, make_float4(0.f, 0.f, 0.f, 0.f)); return; }
-    ltris.assign(off ? off : 8, make_float4(0.f, 0.f, 0.f, 0.f));
+    if (off >= (size_t(1) << 32)) { ltris.resize(off); return; }                   // refused by the caller (size check); contents irrelevant
+    ltris.resize(off ? off : 8);
+    if (!off) for (size_t i = 0; i < 8; ++i) ltris[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     // pass 2 (parallel over node ranges: 10 M triangles are 250 M nodes and 200 M records): copy the records
-    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const unsigned hw = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
     const size_t nthreads = nodes.size() < (size_t(1) << 20) ? 1 : hw;
     auto fill = [&](size_t lo, size_t hi) {
+        // where the run of the last non-empty leaf before node `lo` ends: the units between it and this range's first run are alignment padding
+        size_t prev_end = 0;
+        for (size_t j = lo; j-- > 0;) {
+            const Node &m = nodes[j];
+            if ((m.x & 3u) == 3u && (m.x >> 2)) { prev_end = size_t(tnodes[j].y) + size_t(m.x >> 2) * 3; break; }
+        }
         for (size_t i = lo; i < hi; ++i) {
             const Node &n = nodes[i];
             if ((n.x & 3u) != 3u) continue;
             const uint32_t np = n.x >> 2;
+            if (np == 0) continue;
+            for (size_t u = prev_end; u < size_t(tnodes[i].y); ++u) ltris[u] = make_float4(0.f, 0.f, 0.f, 0.f);    // padding before an aligned run
+            prev_end = size_t(tnodes[i].y) + size_t(np) * 3;
             float4 *dst = ltris.data() + tnodes[i].y;
             for (uint32_t k = 0; k < np; ++k) {
                 const uint32_t prim = np == 1 ? n.y : leaf_refs[n.y + k];
@@ -845,7 +866,7 @@ static void build_pair_blocks(const std::vector<Node> &tn, std::vector<uint4> &p
             pairs[i] = make_uint4(tn[b].x, word1(b), tn[a].x, word1(a));
         }
     };
-    const size_t nthreads = order.size() < (size_t(1) << 20) ? 1 : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const size_t nthreads = order.size() < (size_t(1) << 20) ? 1 : std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
     if (nthreads == 1) fill(0, order.size());
     else {
         std::vector<std::thread> pool;
@@ -1246,7 +1267,7 @@ static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel 
     s->dev.nodes = nodes_dev;
     s->dev.tnodes = nodes_dev;
     if (s->accel_kind == RT_ACCEL_KDTREE) {
-        std::vector<Node> tn; std::vector<float4> lt;
+        std::vector<Node> tn; LeafRecords lt;
         tick("node upload");
         build_leaf_order(s->tree.nodes, s->tree.leaf_refs, tris, tn, lt);
         tick("leaf-ordered records");
