@@ -69,6 +69,12 @@ def workload(name: str):
                                     jitter=True, pixel_filter="mitchell", soup_tris=ntri)
         label = "Cornell + %d-triangle LCG soup, DirectLighting(all), 1920x1080 @ 16 spp, mitchell, kd-tree" % ntri
         crop = (0.2, 0.8, 0.2, 0.8)
+    elif name == "c4full":                  # BASELINE config 4 as stated: 10 M triangles, 2048 x 2048 @ 256 spp (1.07 G camera samples per frame, a 34 GB sample
+        ntri = 10_000_000                   # buffer: fits one MI355X; its reference-CPU leg would take days, so this one is a committed record: profiles/r04_c4_full.json)
+        text = scenes.cornell_scene(xres=2048, yres=2048, integrator="path", maxdepth=8, xsamples=16, ysamples=16, jitter=True,
+                                    pixel_filter="mitchell", soup_tris=ntri, soup_materials=True)
+        label = "Cornell + %d-triangle LCG soup, matte/glass/mirror mix, PathIntegrator maxdepth=8, 2048x2048 @ 256 spp, mitchell, kd-tree" % ntri
+        crop = (0.495, 0.505, 0.495, 0.505)
     elif name.startswith("c4"):             # c4_1000000: BASELINE config 4 at single-GPU size (material mix, path depth 8)
         ntri = 1_000_000 if name == "c4" else int(name.split("_")[1])
         text = scenes.cornell_scene(xres=1024, yres=1024, integrator="path", maxdepth=8, xsamples=4, ysamples=4, jitter=True,

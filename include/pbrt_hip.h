@@ -273,7 +273,12 @@ int rt_render(RtScene *s, const RtRenderDesc *rd);
 int rt_sync(RtScene *s);
 /* per-camera-sample results of the last rt_render, before filtering: out[count][8] = L.rgb, alpha, imageX, imageY, 0, 0 in the
  * sampler's order (what Scene::Render hands to Film::AddSample, scene.cpp:76).  The reference-side binding
- * (oracle/ref/hip_adapter.cpp) serves SurfaceIntegrator::Li from it. */
+ * (oracle/ref/hip_adapter.cpp) serves SurfaceIntegrator::Li from it.
+ * Order: record w is work item w of this shard's work list.  shard_count == 1 rendered by the megakernel (every frame without a
+ * medium): scanline order of the sample extent, whatever tile shape the descriptor names (one shard's tiles partition nothing).
+ * Otherwise the shard's tiles in order, a tile's pixels in scanline order, a pixel's samples consecutively; with 2-D tiles the
+ * border tiles are padded to whole tiles and the work items that fall off the sample extent are never rendered: their records hold
+ * zeros or what an earlier frame left there (finite), and the film gathers never look at them. */
 int rt_samples_read(RtScene *s, uint64_t first, uint64_t count, float *out);
 int rt_counters(RtScene *s, RtCounters *out);             /* synchronises */
 int rt_counters_reset(RtScene *s);
@@ -291,9 +296,8 @@ typedef struct RtRenderStats {
     float total_ms, render_ms, trace_ms, gather_ms;
     int32_t pipeline, iterations, timed_iterations;
     uint32_t slots;
-    float shade_ms;            /* queue pipeline: the shade launches summed (they overlap the trace launches when the pool runs as two halves) */
-    int32_t bands;             /* megakernel: launches the frame was rendered in (bands of sample rows; the film rows a band completes are gathered while
-                                * the next bands render, and gather_ms is then only the share of the gather that follows the last render launch) */
+    float shade_ms;            /* queue pipeline: the shade launches summed */
+    int32_t bands;             /* megakernel: 1 (one launch per frame); pipeline: 0 */
 } RtRenderStats;
 /* ImageFilm::WriteImage's normalisation (image.cpp:157-203) of ANY 5-plane accumulator in device memory (planes of n floats each), e.g. the
  * rows of the film a rank owns after a reduce-scatter; rgb[n][3] and alpha[n] stay on the device.  Asynchronous on the scene's stream. */

@@ -18,6 +18,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 HIP_LIB = os.path.join(LIB_DIR, "libpbrt_hip.so")
+if os.environ.get("PBRT_HIP_TUNE") and os.environ.get("PBRT_HIP_LIB_PATH"):      # A/B measurements: a variant built by tools/build_variant.py
+    HIP_LIB = os.environ["PBRT_HIP_LIB_PATH"]
 HOST_LIB = os.path.join(LIB_DIR, "libpbrt_host.so")
 CSRC = os.path.join(_HERE, "csrc")
 
@@ -65,7 +67,9 @@ def build(force: bool = False, verbose: bool = False, defines=(), jobs: int | No
         return seen
 
     stamp = os.path.join(obj_dir, "defines.txt")
-    dtext = " ".join(defines)
+    # the stamp holds the compiler flags too: an object built with other flags (e.g. before -fno-slp-vectorize, a correctness fix) must
+    # not survive an incremental build just because it is newer than its sources
+    dtext = " ".join(HIPCC_FLAGS) + " | " + " ".join(HOST_FLAGS) + " | " + " ".join(defines)
     if (open(stamp).read() if os.path.exists(stamp) else "") != dtext:
         force = True
     todo = []
@@ -137,6 +141,32 @@ HIT_DTYPE = np.dtype([("prim", np.int32), ("t", np.float32), ("b1", np.float32),
 
 _hip = None
 _host = None
+
+
+def code_id(path: str | None = None) -> str:
+    """Identity of the DEVICE code in libpbrt_hip.so: sha256 (16 hex digits) of its .hip_fatbin section (the gfx950 code objects of every
+    kernel).  tools/publish_profile.py stores it with the PMC summaries under profiles/, bench.py compares it with the library it has
+    loaded and refuses to print counters that were collected on other kernels."""
+    import hashlib, struct
+    data = open(path or HIP_LIB, "rb").read()
+    if data[:4] != b"\x7fELF" or data[4] != 2:
+        raise RuntimeError("not a 64-bit ELF file: " + (path or HIP_LIB))
+    shoff, = struct.unpack_from("<Q", data, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", data, 0x3A)
+    def sh(i):
+        name, typ, flags, addr, off, size = struct.unpack_from("<IIQQQQ", data, shoff + i * shentsize)
+        return name, off, size
+    _, stroff, _ = sh(shstrndx)
+    h = hashlib.sha256()
+    found = False
+    for i in range(shnum):
+        name, off, size = sh(i)
+        end = data.index(b"\0", stroff + name)
+        if data[stroff + name:end] == b".hip_fatbin":
+            h.update(data[off:off + size]); found = True
+    if not found:
+        raise RuntimeError("no .hip_fatbin section in " + (path or HIP_LIB))
+    return h.hexdigest()[:16]
 
 
 def hip_lib():

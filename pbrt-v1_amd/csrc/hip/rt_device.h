@@ -112,10 +112,9 @@ struct DevFrame {
     int phase_sync;             // path integrator: alternate the two halves of the state machine between sweeps (rt_integrate.h)
     int high_occupancy;          // host-side choice of the 5-waves/SIMD kernel flavour (not read by the device)
     int leaf_min;                // batched rounds: keep testing leaf primitives while at least this many lanes hold an untested one
-    int trav_mode;               // 0 = one node per lane per round, 1 = lock-step (descend all, then test), 2 = batched
+    int trav_mode;               // 2 = the flat traversal round (trace_round), 3 = lock-step rounds with pooled leaf tests (tiny trees with fat leaves; natural-allocation kernels only)
     int pipeline;                // host-side choice: the queue pipeline (rt_pipeline.h) instead of the megakernel (not read by the device)
-    unsigned long long total_work;     // samples this shard renders (a banded frame, rt_render: the END of this band's range of the work list)
-    unsigned long long work_begin;     // first work item of this launch's range (0 unless the frame is rendered in bands); megakernel only
+    unsigned long long total_work;     // samples this shard renders
     unsigned long long total_pixels;   // pixels in the sample extent
     // sampler dimension table (Sample::oneD/twoD, sampling.cpp:41-70)
     int n1d, n2d;

@@ -209,11 +209,13 @@ RT_DEV bool work_to_sample(const DevFrame &fr, unsigned long long w, unsigned lo
     // every frame of practical size has fewer than 2^32 samples: 32-bit divisions (a 64-bit division is ~150 VALU instructions
     // on gfx950, and this runs in the sparsely populated fetch path)
     if (fr.tile_w > 0) {                                    // 2-D tiles: a tile is a tile_w x tile_h block of the sample extent; the pixels of
-        const unsigned long long lt = w / per_tile, rem = w - lt * per_tile;           // the border tiles that fall off the extent are skipped
-        const unsigned long long tile = lt * unsigned(fr.shard_count) + unsigned(fr.shard_index);
-        const unsigned q = unsigned(rem / unsigned(fr.spp));
-        s = int(rem - (unsigned long long)q * unsigned(fr.spp));
-        const unsigned ty = unsigned(tile / unsigned(fr.tiles_x)), tx = unsigned(tile - (unsigned long long)ty * unsigned(fr.tiles_x));
+        // the border tiles that fall off the extent are skipped.  make_frame guarantees n_tiles * tile_pixels * spp < 2^32: all 32-bit
+        const unsigned w32 = unsigned(w), pt = unsigned(per_tile);
+        const unsigned lt = w32 / pt, rem = w32 - lt * pt;
+        const unsigned tile = lt * unsigned(fr.shard_count) + unsigned(fr.shard_index);
+        const unsigned q = rem / unsigned(fr.spp);
+        s = int(rem - q * unsigned(fr.spp));
+        const unsigned ty = tile / unsigned(fr.tiles_x), tx = tile - ty * unsigned(fr.tiles_x);
         const unsigned qy = q / unsigned(fr.tile_w), qx = q - qy * unsigned(fr.tile_w);
         const unsigned px = tx * unsigned(fr.tile_w) + qx, py = ty * unsigned(fr.tile_h) + qy;
         const unsigned ew = unsigned(fr.x_end - fr.x_start), eh = unsigned(fr.y_end - fr.y_start);

@@ -98,11 +98,7 @@ __global__ __launch_bounds__(256) void film_gather_kernel(const DevFrame *__rest
             int c = int(threadIdx.x) / per_col, k = int(threadIdx.x) - c * per_col;
             for (; c < ncols;) {
                 const unsigned long long base = colbase[c];
-#ifdef RT_GATHER_NOSTAGE
-                if (false) {
-#else
                 if (base != ~0ull) {
-#endif
                     float4 q = RT_GPTR(const float4, fr.samples)[sample_slot(unsigned(base), unsigned(k) >> 1, spp) + (k & 1) * RT_SAMPLE_XY];
                     if (k & 1) {
                         // the sample's pixel footprint (film/image.cpp:108-116) depends on the sample only: computed once here by the
@@ -119,9 +115,6 @@ __global__ __launch_bounds__(256) void film_gather_kernel(const DevFrame *__rest
                 while (k >= per_col) { k -= per_col; ++c; }
             }
             __syncthreads();
-#ifdef RT_GATHER_NOACC
-            continue;
-#endif
             if (!live || sy < sy0 || sy > sy1) continue;
             for (int sx = max(cx, sx0); sx <= min(cx + ncols - 1, sx1); ++sx) {
                 const int c = sx - cx;
@@ -336,9 +329,6 @@ __global__ __launch_bounds__(64) void film_march_kernel(const DevFrame *__restri
 // two words next to the record; a pixel's weight is then one look-up in a 1024-entry table indexed by (y entry << 5 | x entry) that holds
 // 0 wherever either "inside" bit is clear (see march_row for why a weight of +0 is the reference's "skip"), and its accumulation is two
 // packed multiply-adds and an add.  Order per pixel: sample rows, then columns, then samples -- the reference's.
-#ifndef RT_SLOT_PROBE
-#define RT_SLOT_PROBE 0          // tools/r03_scan.py slot: 1 no accumulation pass, 2 no entry arithmetic, 4 no record loads (timing ablations, wrong films)
-#endif
 #ifndef RT_SLOT_UNROLL
 #define RT_SLOT_UNROLL 8         // samples per trip of the accumulation pass: their LDS reads are issued together
 #endif
@@ -391,8 +381,7 @@ __global__ __launch_bounds__(64, 2) void film_slot_kernel(const DevFrame *__rest
         const unsigned base = ok ? colbase[buf * NCS + ci] : ~0u;
         ok = ok & (base != ~0u);
         const unsigned long long at = ok ? sample_slot(base, unsigned(sv), spp) : 0ull;
-        if (RT_SLOT_PROBE & 4) { L = make_float4(0.f, 0.f, 0.f, 0.f); xy = make_float2(0.f, 0.f); }
-        else { L = samples[at]; xy = *(const float2 RT_G *)(samples + at + RT_SAMPLE_XY); }
+        L = samples[at]; xy = *(const float2 RT_G *)(samples + at + RT_SAMPLE_XY);
         return ok;
     };
     // the record's footprint tests and filter-table indices for every pixel column / row it can reach (film/image.cpp:108-132), into LDS
@@ -402,8 +391,7 @@ __global__ __launch_bounds__(64, 2) void film_slot_kernel(const DevFrame *__rest
         const float dImageX = xy.x - 0.5f, dImageY = xy.y - 0.5f;
         const float ax = dImageX - fxw, bx_ = dImageX + fxw, ay = dImageY - fyw, by_ = dImageY + fyw;
         unsigned wx = 0, wy = 0;
-        if (RT_SLOT_PROBE & 2) { wx = __float_as_uint(ax) & 0x1ffffffu; wy = __float_as_uint(by_) & 0x1ffffffu; }
-        else {
+        {
 #pragma unroll
             for (int p = 0; p <= 2 * RX; ++p) {
                 const float xf = float(X0 - 2 * RX + ci + p);
@@ -480,7 +468,7 @@ __global__ __launch_bounds__(64, 2) void film_slot_kernel(const DevFrame *__rest
             const unsigned shy = valid ? unsigned(5 * q) : 25u;         // bits 25.. of the y word are clear: weight 0 for a lane without a pixel
             // the accumulation pass, column after column; RT_SLOT_UNROLL samples' LDS reads are issued together.  (A three-stage software pipeline --
             // records of batch b + 2 read, weights of b + 1 looked up, batch b accumulated -- measured slower: 2.36 vs 2.00 ms on C2.)
-            if (!(RT_SLOT_PROBE & 1) && row_any)
+            if (row_any)
 #pragma unroll
             for (int j = 0; j <= 2 * RX; ++j) {
                 const float4 RT_L *Lp = Larr + (xi + j) * lstride;
@@ -600,7 +588,6 @@ static void hip_warn(hipError_t e, const char *what) {
 }
 #define HIPWARN(expr) hip_warn((expr), #expr)
 
-#define RT_MAX_BANDS 8
 struct RtScene {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -631,9 +618,6 @@ struct RtScene {
     RtVolume volume{};
     int spill_depth = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // banded frames (rt_render): render launches alternate between two streams, the bands' film gathers follow on the caller's stream
-    hipStream_t st_band[2] = {nullptr, nullptr}; hipEvent_t ev_band[RT_MAX_BANDS] = {}; DevFrame *dev_frames = nullptr; unsigned long long *band_counters = nullptr;
-    int last_bands = 1;
     bool have_timing = false;
     bool counting = true;
     uint32_t n_tris = 0;
@@ -646,9 +630,7 @@ struct RtScene {
     std::vector<hipEvent_t> pipe_fence;
     bool last_pipeline = false; int pipe_iters = 0, pipe_timed = 0; unsigned pipe_slots = 0;
     float4 *trace_buf = nullptr; size_t trace_cap = 0;   // rt_trace_*: rays (2 x float4) and hits, reused across calls
-    // overlapped pipeline: two CU-masked streams (trace kernel | shade passes) and the events that hand a half of the pool from one to the other
-    hipStream_t st_trace = nullptr, st_shade = nullptr; int trace_cus = 0, n_cus = 0;
-    std::vector<hipEvent_t> pipe_hand;
+    int n_cus = 0;
     unsigned *trace_qc = nullptr;
 };
 #define RT_PIPE_QN 4096          // ring of per-iteration queue counters
@@ -768,54 +750,8 @@ static void host_tri_frame_uv(const float *v, const float *uv, bool flip, float 
     for (int a = 0; a < 3; ++a) { nn[a] = c[a] * inv; if (flip) nn[a] = -1.f * nn[a]; }
 }
 
-// The tree as sibling pairs (rt_device.h DevScene::tpairs).  A pair is addressed by its absolute index, so the ORDER of the records is
-// free: the traversal (visit order, tie rules, counters) does not depend on it, only which records share a cache line does.
-// `treelet` <= 1: depth-first (the pair of a node's children, then the below child's subtree, then the above child's).
-// `treelet` = T: the tree is cut into treelets of up to T pairs grown breadth-first from their root (the root's pair, its children's
-// pairs, its grandchildren's ... until T records are taken); a treelet's records are consecutive (T = 8: one 128-byte line), the
-// treelets left hanging below it follow depth-first.  A ray walking down k levels inside a treelet touches one line, not k.
-#ifndef RT_TREELET_PAIRS
-#define RT_TREELET_PAIRS 8          // records per treelet of the pair layout (8 x 16 B = one 128-byte line); 1 = depth-first order
-#endif
-#ifndef RT_TREELET_ALIGN
-#define RT_TREELET_ALIGN 1          // treelets never straddle a line (next-fit padding)
-#endif
-static void build_pairs(const std::vector<Node> &tn, std::vector<uint4> &pairs, uint32_t &root_x, uint32_t &root_y, int treelet, bool align) {
-    pairs.clear();
-    if (tn.empty()) { root_x = 3u; root_y = 0u; pairs.push_back(make_uint4(3u, 0u, 3u, 0u)); return; }
-    root_x = tn[0].x;
-    if ((tn[0].x & 3u) == 3u) { root_y = tn[0].y; pairs.push_back(make_uint4(3u, 0u, 3u, 0u)); return; }
-    auto interior = [&](uint32_t n) { return (tn[n].x & 3u) != 3u; };
-    std::vector<uint32_t> order; order.reserve(tn.size() / 2 + 1);            // parent node of each emitted pair (~0u = padding record)
-    std::vector<uint32_t> pos(tn.size(), ~0u);                                // parent node -> index of its children's pair
-    std::vector<uint32_t> roots{0u}, frontier;
-    const size_t T = treelet <= 1 ? 1 : size_t(treelet);
-    while (!roots.empty()) {
-        frontier.clear(); frontier.push_back(roots.back()); roots.pop_back();
-        size_t head = 0;
-        while (head < frontier.size() && head < T) {
-            const uint32_t P = frontier[head++];
-            const uint32_t b = P + 1u, a = tn[P].y;
-            if (interior(b)) frontier.push_back(b);
-            if (interior(a)) frontier.push_back(a);
-        }
-        // `align`: a treelet never straddles a T-record boundary (next-fit: pad up to the boundary when it would)
-        if (align && T > 1 && (order.size() % T) + head > T) while (order.size() % T) order.push_back(~0u);
-        for (size_t k = 0; k < head; ++k) { pos[frontier[k]] = uint32_t(order.size()); order.push_back(frontier[k]); }
-        for (size_t k = frontier.size(); k > head; --k) roots.push_back(frontier[k - 1]);     // the first one left over is taken up next
-    }
-    if (order.size() >= (size_t(1) << 32)) { pairs.clear(); return; }
-    pairs.resize(order.size());
-    for (size_t i = 0; i < order.size(); ++i) {
-        const uint32_t P = order[i];
-        if (P == ~0u) { pairs[i] = make_uint4(3u, 0u, 3u, 0u); continue; }
-        const uint32_t b = P + 1u, a = tn[P].y;
-        pairs[i] = make_uint4(tn[b].x, interior(b) ? pos[b] : tn[b].y, tn[a].x, interior(a) ? pos[a] : tn[a].y);
-    }
-    root_y = pos[0];
-}
-
-// The same sibling pairs laid out in BLOCKS for the two-level step (kdp_step, rt_traverse.h): an "owner" node P is followed by the pairs of
+// The tree as sibling pairs (rt_device.h DevScene::tpairs: a record holds the two node words of a node's below child and the two of its above
+// child, addressed by absolute index) laid out in BLOCKS for the two-level step (kdp_step, rt_traverse.h): an "owner" node P is followed by the pairs of
 // its interior children -- {pair(P), pair(below(P)), pair(above(P))}, 16 / 32 / 48 bytes, never across a 64-byte boundary (next-fit
 // padding) -- and bits 30 / 31 of every word 1 that points at P say which of the two follow.  The owners are the root and, recursively,
 // the interior grandchildren of an owner; the nodes in between are "members" of their parent's block (flags 0: when a member is reached
@@ -897,31 +833,9 @@ static int ensure(RtScene *s, T **buf, size_t *cap, size_t need) {
     return RT_OK;
 }
 
-// The queue pipeline: alternate pipe_shade_kernel / pipe_trace_kernel until a shade pass enqueues no ray.  The host learns the
-// queue sizes RT_PIPE_BATCH iterations late (page-locked copy + fence event per batch), so the GPU never waits for it; the
-// iterations launched after the last productive one find every slot in ST_EXIT and return at once.
-// (re)create the two CU-masked streams of the overlapped pipeline: the trace kernel's persistent waves own CUs [0, trace_cus), the shade
-// passes the rest.  On this part a mask bit is one CU and consecutive bits fall on different XCDs (tools/cumask_probe.hip: N bits = N CUs spread
-// over all 8 XCDs, two disjoint masks run side by side), so each side keeps all eight L2s.
-static int ensure_masked_streams(RtScene *s, int trace_cus) {
-    if (s->st_trace && s->trace_cus == trace_cus) return RT_OK;
-    if (s->st_trace) { HIPWARN(hipStreamSynchronize(s->st_trace)); HIPWARN(hipStreamDestroy(s->st_trace)); s->st_trace = nullptr; }
-    if (s->st_shade) { HIPWARN(hipStreamSynchronize(s->st_shade)); HIPWARN(hipStreamDestroy(s->st_shade)); s->st_shade = nullptr; }
-    const int ncu = s->n_cus;
-    std::vector<uint32_t> mt((ncu + 31) / 32, 0u), ms((ncu + 31) / 32, 0u);
-    for (int i = 0; i < ncu; ++i) (i < trace_cus ? mt : ms)[i / 32] |= 1u << (i % 32);
-    HIPCHK(hipExtStreamCreateWithCUMask(&s->st_trace, uint32_t(mt.size()), mt.data()));
-    HIPCHK(hipExtStreamCreateWithCUMask(&s->st_shade, uint32_t(ms.size()), ms.data()));
-    s->trace_cus = trace_cus;
-    return RT_OK;
-}
-
 // The queue pipeline: alternate a shade kernel (pipe_shade_kernel, or pipe_vertex_kernel for a path without a medium) and pipe_trace_kernel
 // until a shade pass enqueues no ray.  The host learns the queue sizes RT_PIPE_BATCH iterations late (page-locked copy + fence event per
 // batch), so the GPU never waits for it; the iterations launched after the last productive one find every slot in ST_EXIT and return at once.
-// Overlapped form (round 3): the pool is run as two halves that take turns -- while one half's rays are traced on most of the CUs, the other
-// half is shaded on the CUs the trace kernel does not own (two CU-masked streams, one event per hand-over).  The shade passes are streaming
-// kernels bound by HBM bandwidth, the trace kernel by the latency of dependent gathers: side by side they cost little more than the slower.
 static int render_pipeline(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, int vol_levels, int vol_nmax, size_t vol_samp_words) {
     const int integ = rd->integrator;
     // PathIntegrator without a medium: one shade pass per path vertex, all of a vertex's rays in one trace launch (rt_pipe_vertex.h)
@@ -945,15 +859,7 @@ static int render_pipeline(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, int
     if (const char *e = knob("PBRT_HIP_PIPE_SLOTS")) want = unsigned(std::max(256, std::atoi(e)));
     unsigned long long tw = fr.total_work ? fr.total_work : 1;
     unsigned n_slots = unsigned(std::min<unsigned long long>(want, tw));
-    // ---- one pool or two halves taking turns
-    // Measured (tools/r03_overlap_probe.sh, profiles/r03_overlap_scan.txt): both kernels scale with the CUs they own -- the trace kernel on 192 of
-    // 256 CUs takes 78 ms instead of 57, the shade passes on the other 64 take 42 ms instead of 12 -- so side by side is slower than one
-    // after the other (1 M-triangle path frame 83 vs 71 ms, C5 440 vs 395 ms).  Off unless asked for.
-    bool overlap = false;
-    if (const char *e = knob("PBRT_HIP_OVERLAP")) overlap = std::atoi(e) != 0 && n_slots >= 4 * RT_BLOCK;
-    const int H = overlap ? 2 : 1;
-    n_slots = (n_slots + H * RT_BLOCK - 1) / (H * RT_BLOCK) * (H * RT_BLOCK);
-    const unsigned half = n_slots / H;
+    n_slots = (n_slots + RT_BLOCK - 1) / RT_BLOCK * RT_BLOCK;
     if (n_slots >= (1u << 30)) return fail(RT_EINVAL, "rt_render: more than 2^30 pipeline slots");
     const int vec = RT_PIPE_VEC;
     if (n_slots > s->pool_cap) {
@@ -985,90 +891,56 @@ static int render_pipeline(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, int
     }
     fr.frames = s->frames; fr.n_threads = n_slots;
     if (s->pipe_ev.empty()) {
-        s->pipe_ev.resize(4 * RT_PIPE_TIMED); s->pipe_fence.resize(RT_PIPE_QN / RT_PIPE_BATCH); s->pipe_hand.resize(6);
+        s->pipe_ev.resize(4 * RT_PIPE_TIMED); s->pipe_fence.resize(RT_PIPE_QN / RT_PIPE_BATCH);
         for (auto &e : s->pipe_ev) HIPCHK(hipEventCreate(&e));
         for (auto &e : s->pipe_fence) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        for (auto &e : s->pipe_hand) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     const int f = s->counting ? 1 : (s->has_ext ? 2 : 0);
     const PipeShadeFn *st = integ == RT_INTEGRATOR_WHITTED ? g_pipe_shade_whitted : integ == RT_INTEGRATOR_DIRECT ? g_pipe_shade_direct : g_pipe_shade_path;
     const PipeShadeFn shade = by_vertex ? g_pipe_vertex[f] : st[(s->volume.present ? 3 : 0) + f];
     const int tk = (s->accel_kind == RT_ACCEL_GRID ? 4 : 0) + (s->counting ? (s->has_ext ? 1 : 3) : (s->has_ext ? 2 : 0));
     const PipeTraceFn trace = g_pipe_trace[tk];
-    hipStream_t st_shade = s->stream, st_trace = s->stream;
-    unsigned trace_grid = s->trace_grids[tk];
-    if (overlap) {
-        // CUs of the trace kernel: a path's shade passes are light (13 ms of 70 on the whole chip), a ray march's are not (150 of 390)
-        int tc = s->volume.present ? s->n_cus * 5 / 8 : s->n_cus * 3 / 4;
-        if (const char *e = knob("PBRT_HIP_TRACE_CUS")) tc = std::atoi(e);
-        tc = std::max(8, std::min(s->n_cus - 8, tc));
-        int rc = ensure_masked_streams(s, tc); if (rc) return rc;
-        st_shade = s->st_shade; st_trace = s->st_trace;
-        trace_grid = unsigned((unsigned long long)trace_grid * unsigned(tc) / unsigned(s->n_cus));
-        if (trace_grid < 1) trace_grid = 1;
-    }
+    const unsigned trace_grid = s->trace_grids[tk];
     HIPCHK(hipMemcpyAsync(s->dev_frame, &fr, sizeof(DevFrame), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemcpyAsync(s->dev_pool, &pl, sizeof(PipePool), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemsetAsync(s->work_counter, 0, sizeof(unsigned long long), s->stream));
     HIPCHK(hipMemsetAsync(pl.state + n_slots, 0, size_t(n_slots) * sizeof(float4), s->stream));      // control words: every slot in ST_FETCH
     HIPCHK(hipMemsetAsync(pl.wave_work, 0, size_t(n_slots / 64 + 1) * 2 * sizeof(unsigned long long), s->stream));
     HIPCHK(hipEventRecord(s->ev0, s->stream));
-    if (overlap) { HIPCHK(hipStreamWaitEvent(st_shade, s->ev0, 0)); HIPCHK(hipStreamWaitEvent(st_trace, s->ev0, 0)); }
-    hipEvent_t *shaded = &s->pipe_hand[0], *traced = &s->pipe_hand[2];      // [half]: the half's rays are queued / its hits are written
-    int iter = 0, checked = 0, batch = 0, launches = 0;
+    int iter = 0, checked = 0, batch = 0;
     bool done = false;
     const int max_iters = 1 << 20;
     while (!done) {
         for (int k = 0; k < RT_PIPE_BATCH; ++k, ++iter) {
-            for (int h = 0; h < H; ++h, ++launches) {
-                const unsigned qi = unsigned(launches % RT_PIPE_QN);
-                PipeLaunch pk{}; pk.qi = qi; pk.slot_base = unsigned(h) * half; pk.q_base = by_vertex ? 3u * pk.slot_base : pk.slot_base;
-                if (overlap && iter > 0) HIPCHK(hipStreamWaitEvent(st_shade, traced[h], 0));
-                HIPCHK(hipMemsetAsync(pl.q_count + size_t(RT_QC_STRIDE) * qi, 0, RT_QC_STRIDE * sizeof(unsigned), st_shade));
-                if (launches < RT_PIPE_TIMED) HIPCHK(hipEventRecord(s->pipe_ev[4 * launches + 2], st_shade));
-                hipLaunchKernelGGL(shade, dim3(half / RT_BLOCK), dim3(RT_BLOCK), 0, st_shade, (const DevScene *)s->dev_scene,
-                                   (const DevFrame *)s->dev_frame, (const PipePool *)s->dev_pool, pk);
-                if (launches < RT_PIPE_TIMED) HIPCHK(hipEventRecord(s->pipe_ev[4 * launches + 3], st_shade));
-                if (overlap) { HIPCHK(hipEventRecord(shaded[h], st_shade)); HIPCHK(hipStreamWaitEvent(st_trace, shaded[h], 0)); }
-                TraceJob job{};
-                job.q_o = pl.q_o; job.q_d = pl.q_d; job.q_slot = pl.q_slot; job.q_count = pl.q_count + size_t(RT_QC_STRIDE) * qi; job.hit = pl.hit;
-                job.n_slots = n_slots; job.q_base = pk.q_base; job.spill = s->spill; job.n_threads = s->n_threads; job.counters = s->counters;
-                if (by_vertex) { job.by_slot = 1; job.q_o = pl.ray_o; job.q_d = pl.ray_d; }
-                if (launches < RT_PIPE_TIMED) HIPCHK(hipEventRecord(s->pipe_ev[4 * launches], st_trace));
-                hipLaunchKernelGGL(trace, dim3(trace_grid), dim3(RT_BLOCK), 0, st_trace, (const DevScene *)s->dev_scene, job);
-                if (launches < RT_PIPE_TIMED) HIPCHK(hipEventRecord(s->pipe_ev[4 * launches + 1], st_trace));
-                if (overlap) HIPCHK(hipEventRecord(traced[h], st_trace));
-                HIPCHK(hipMemcpyAsync(s->h_qcount + size_t(RT_QC_STRIDE) * qi, pl.q_count + size_t(RT_QC_STRIDE) * qi, (RT_QC_ANY + 1) * sizeof(unsigned), hipMemcpyDeviceToHost, st_trace));
-            }
+            const unsigned qi = unsigned(iter % RT_PIPE_QN);
+            PipeLaunch pk{}; pk.qi = qi; pk.slot_base = 0; pk.q_base = 0;
+            HIPCHK(hipMemsetAsync(pl.q_count + size_t(RT_QC_STRIDE) * qi, 0, RT_QC_STRIDE * sizeof(unsigned), s->stream));
+            if (iter < RT_PIPE_TIMED) HIPCHK(hipEventRecord(s->pipe_ev[4 * iter + 2], s->stream));
+            hipLaunchKernelGGL(shade, dim3(n_slots / RT_BLOCK), dim3(RT_BLOCK), 0, s->stream, (const DevScene *)s->dev_scene,
+                               (const DevFrame *)s->dev_frame, (const PipePool *)s->dev_pool, pk);
+            if (iter < RT_PIPE_TIMED) HIPCHK(hipEventRecord(s->pipe_ev[4 * iter + 3], s->stream));
+            TraceJob job{};
+            job.q_o = pl.q_o; job.q_d = pl.q_d; job.q_slot = pl.q_slot; job.q_count = pl.q_count + size_t(RT_QC_STRIDE) * qi; job.hit = pl.hit;
+            job.n_slots = n_slots; job.q_base = pk.q_base; job.spill = s->spill; job.n_threads = s->n_threads; job.counters = s->counters;
+            if (by_vertex) { job.by_slot = 1; job.q_o = pl.ray_o; job.q_d = pl.ray_d; }
+            if (iter < RT_PIPE_TIMED) HIPCHK(hipEventRecord(s->pipe_ev[4 * iter], s->stream));
+            hipLaunchKernelGGL(trace, dim3(trace_grid), dim3(RT_BLOCK), 0, s->stream, (const DevScene *)s->dev_scene, job);
+            if (iter < RT_PIPE_TIMED) HIPCHK(hipEventRecord(s->pipe_ev[4 * iter + 1], s->stream));
+            HIPCHK(hipMemcpyAsync(s->h_qcount + size_t(RT_QC_STRIDE) * qi, pl.q_count + size_t(RT_QC_STRIDE) * qi, (RT_QC_ANY + 1) * sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
         }
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(s->pipe_fence[batch % (RT_PIPE_QN / RT_PIPE_BATCH)], st_trace));
+        HIPCHK(hipEventRecord(s->pipe_fence[batch % (RT_PIPE_QN / RT_PIPE_BATCH)], s->stream));
         if (batch >= 1) {                                                   // look at the batch before the one just launched
             HIPCHK(hipEventSynchronize(s->pipe_fence[(batch - 1) % (RT_PIPE_QN / RT_PIPE_BATCH)]));
             for (int k = 0; k < RT_PIPE_BATCH; ++k, ++checked) {
-                unsigned rays = 0;
-                for (int h = 0; h < H; ++h) { const unsigned *q = s->h_qcount + size_t(RT_QC_STRIDE) * ((checked * H + h) % RT_PIPE_QN); rays += q[0] + q[RT_QC_ANY]; }
-                if (rays == 0) { done = true; break; }
+                const unsigned *q = s->h_qcount + size_t(RT_QC_STRIDE) * (checked % RT_PIPE_QN);
+                if (q[0] + q[RT_QC_ANY] == 0) { done = true; break; }
             }
         }
         ++batch;
         if (iter > max_iters) return fail(RT_ESTATE, "rt_render: the queue pipeline did not terminate");
     }
-    if (overlap) {                                                          // join: whatever follows on the scene's stream sees the finished frame
-        HIPCHK(hipEventRecord(s->pipe_hand[4], st_shade)); HIPCHK(hipEventRecord(s->pipe_hand[5], st_trace));
-        HIPCHK(hipStreamWaitEvent(s->stream, s->pipe_hand[4], 0)); HIPCHK(hipStreamWaitEvent(s->stream, s->pipe_hand[5], 0));
-    }
-#ifdef RT_PIPE_LOG
-    if (knob("PBRT_HIP_PIPE_TRACE_LOG")) {               // per-launch queue sizes and kernel times (experiments)
-        HIPCHK(hipStreamSynchronize(s->stream));
-        for (int i = 0; i < (checked + 1) * H && i < RT_PIPE_TIMED; ++i) {
-            float ms = 0.f, ms2 = 0.f; HIPCHK(hipEventElapsedTime(&ms, s->pipe_ev[4 * i], s->pipe_ev[4 * i + 1])); HIPCHK(hipEventElapsedTime(&ms2, s->pipe_ev[4 * i + 2], s->pipe_ev[4 * i + 3]));
-            const unsigned *q = s->h_qcount + size_t(RT_QC_STRIDE) * (i % RT_PIPE_QN);
-            std::fprintf(stderr, "PIPE launch %d closest %u any %u trace_ms %.3f Mrays/s %.0f shade_ms %.3f\n", i, q[0], q[RT_QC_ANY], ms, (q[0] + q[RT_QC_ANY]) / (ms * 1e3 + 1e-9), ms2);
-        }
-    }
-#endif
-    s->pipe_slots = n_slots; s->pipe_iters = checked + 1; s->pipe_timed = std::min(s->pipe_iters * H, RT_PIPE_TIMED);
+    s->pipe_slots = n_slots; s->pipe_iters = checked + 1; s->pipe_timed = std::min(s->pipe_iters, RT_PIPE_TIMED);
     HIPCHK(hipEventRecord(s->ev1, s->stream));
     s->last_pipeline = true;
     return RT_OK;
@@ -1096,15 +968,24 @@ static int check_prebuilt(const RtPrebuiltAccel *a, uint32_t n_tris) {
     for (uint32_t i = 0; i < a->n_leaf_refs; ++i) if (a->leaf_refs[i] >= n_tris) return fail(RT_EINVAL, "rt_scene_create_prebuilt: primitive index out of range");
     if (a->kind == RT_ACCEL_KDTREE) {
         if (a->n_nodes == 0 && n_tris != 0) return fail(RT_EINVAL, "rt_scene_create_prebuilt: empty tree");
+        // The per-thread spill area of the traversal stack is sized from max_depth (scene_create), so the claim is checked, not trusted: a
+        // child's index is larger than its parent's, hence one forward sweep gives every node's depth (the deeper path wins if a node has two parents).
+        if (a->max_depth > 64) return fail(RT_EINVAL, "rt_scene_create_prebuilt: max_depth beyond 64");
+        std::vector<uint8_t> depth(a->n_nodes, 0);
         for (uint32_t i = 0; i < a->n_nodes; ++i) {
             const uint32_t x = nd[2 * size_t(i)], y = nd[2 * size_t(i) + 1];
-            if ((x & 3u) != 3u) { if (y <= i + 1u || y >= a->n_nodes || i + 1u >= a->n_nodes) return fail(RT_EINVAL, "rt_scene_create_prebuilt: child index out of range"); }
-            else {
+            if ((x & 3u) != 3u) {
+                if (y <= i + 1u || y >= a->n_nodes || i + 1u >= a->n_nodes) return fail(RT_EINVAL, "rt_scene_create_prebuilt: child index out of range");
+                if (!std::isfinite(*reinterpret_cast<const float *>(&nd[2 * size_t(i)]))) return fail(RT_EINVAL, "rt_scene_create_prebuilt: split position is not finite");
+                const unsigned dc = unsigned(depth[i]) + 1u;
+                if (dc > a->max_depth) return fail(RT_EINVAL, "rt_scene_create_prebuilt: the tree is deeper than its max_depth says");
+                if (depth[i + 1u] < dc) depth[i + 1u] = uint8_t(dc);
+                if (depth[y] < dc) depth[y] = uint8_t(dc);
+            } else {
                 const uint32_t np = x >> 2;
                 if (np == 1u ? y >= n_tris : (np > 1u && (y > a->n_leaf_refs || np > a->n_leaf_refs - y))) return fail(RT_EINVAL, "rt_scene_create_prebuilt: leaf list out of range");
             }
         }
-        if (a->max_depth > 64) return fail(RT_EINVAL, "rt_scene_create_prebuilt: max_depth beyond 64");
     } else {
         const unsigned long long nv = (unsigned long long)a->grid_nvoxels[0] * a->grid_nvoxels[1] * a->grid_nvoxels[2];
         if (a->grid_nvoxels[0] < 1 || a->grid_nvoxels[1] < 1 || a->grid_nvoxels[2] < 1 || nv != a->n_nodes) return fail(RT_EINVAL, "rt_scene_create_prebuilt: voxel counts do not match");
@@ -1112,6 +993,13 @@ static int check_prebuilt(const RtPrebuiltAccel *a, uint32_t n_tris) {
             const uint32_t off = nd[2 * size_t(i)], cnt = nd[2 * size_t(i) + 1];
             if (off > a->n_leaf_refs || cnt > a->n_leaf_refs - off) return fail(RT_EINVAL, "rt_scene_create_prebuilt: voxel list out of range");
         }
+    }
+    for (int k = 0; k < 6; ++k) if (!std::isfinite(a->bounds[k])) return fail(RT_EINVAL, "rt_scene_create_prebuilt: bounds are not finite");
+    for (int k = 0; k < 3; ++k) {
+        if (a->bounds[k] > a->bounds[3 + k] && n_tris != 0) return fail(RT_EINVAL, "rt_scene_create_prebuilt: bounds are inverted");
+        // (a flat scene has width = inv_width = 0 on its thin axis, as GridAccel's constructor makes them: grid.cpp:102-104)
+        if (a->kind == RT_ACCEL_GRID && (!(a->grid_width[k] >= 0.f) || !(a->grid_inv_width[k] >= 0.f) || !std::isfinite(a->grid_width[k]) || !std::isfinite(a->grid_inv_width[k])))
+            return fail(RT_EINVAL, "rt_scene_create_prebuilt: voxel widths must be non-negative and finite");
     }
     return RT_OK;
 }
@@ -1280,17 +1168,9 @@ static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel 
         s->n_leaf_tri_units = lt.size();
         tn.pop_back();
         std::vector<uint4> pairs;
-        int treelet = RT_TREELET_PAIRS;
-        if (const char *e = knob("PBRT_HIP_TREELET_PAIRS")) treelet = std::max(1, std::atoi(e));                  // layout experiments
-        bool align = RT_TREELET_ALIGN != 0;
-        if (const char *e = knob("PBRT_HIP_TREELET_ALIGN")) align = std::atoi(e) != 0;
-        bool blocks = true;
-        if (const char *e = knob("PBRT_HIP_PAIR_BLOCKS")) blocks = std::atoi(e) != 0;                             // layout experiments
         tick("leaf-order upload");
-        if (blocks) build_pair_blocks(tn, pairs, s->dev.root_x, s->dev.root_y);
-        else build_pairs(tn, pairs, s->dev.root_x, s->dev.root_y, treelet, align);
+        build_pair_blocks(tn, pairs, s->dev.root_x, s->dev.root_y);
         if (pairs.empty() || pairs.size() >= (size_t(1) << 30)) return fail(RT_EINVAL, "rt_scene_create: pair records beyond 2^30");
-        if (knob("PBRT_HIP_TREELET_LOG")) std::fprintf(stderr, "TREELET blocks=%d pairs=%d align=%d interior_nodes=%zu records=%zu\n", int(blocks), treelet, int(align), tn.size() / 2, pairs.size());
         tick("pair blocks");
         if ((rc = upload(s, pairs.data(), pairs.size(), &s->dev.tpairs))) return rc;
         tick("pair upload");
@@ -1398,7 +1278,7 @@ static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel 
         s->trace_grids[k] = unsigned(prop.multiProcessorCount) * unsigned(per_cu < 1 ? 1 : per_cu);
         if (s->trace_grids[k] * RT_BLOCK > s->n_threads) s->n_threads = s->trace_grids[k] * RT_BLOCK;      // the spill area is shared
     }
-    HIPCHK(hipMalloc((void **)&s->spill, 2 * size_t(s->spill_depth) * s->n_threads * sizeof(uint4)));     // uint4 entries in the pair form, uint2 otherwise; x 2: two band launches of a frame can be resident at once
+    HIPCHK(hipMalloc((void **)&s->spill, size_t(s->spill_depth) * s->n_threads * sizeof(uint4)));     // uint4 entries in the pair form, uint2 otherwise
     HIPCHK(hipMalloc((void **)&s->dev_pool, sizeof(PipePool)));
     HIPCHK(hipMalloc((void **)&s->trace_qc, RT_QC_STRIDE * sizeof(unsigned)));
     HIPCHK(hipHostMalloc((void **)&s->h_qcount, size_t(RT_PIPE_QN) * RT_QC_STRIDE * sizeof(unsigned), hipHostMallocDefault));
@@ -1423,17 +1303,10 @@ int rt_scene_destroy(RtScene *s) {
     HIPWARN(hipFree(s->pool.state)); HIPWARN(hipFree(s->pool.ray_o)); HIPWARN(hipFree(s->pool.hit)); HIPWARN(hipFree(s->pool.q_o));
     HIPWARN(hipFree(s->pool.q_slot)); HIPWARN(hipFree(s->pool.q_count)); HIPWARN(hipFree(s->pool.wave_work)); HIPWARN(hipFree(s->dev_pool));
     HIPWARN(hipFree(s->trace_buf)); HIPWARN(hipFree(s->trace_qc));
-    if (s->st_trace) { HIPWARN(hipStreamSynchronize(s->st_trace)); HIPWARN(hipStreamDestroy(s->st_trace)); }
-    if (s->st_shade) { HIPWARN(hipStreamSynchronize(s->st_shade)); HIPWARN(hipStreamDestroy(s->st_shade)); }
-    for (hipEvent_t e : s->pipe_hand) HIPWARN(hipEventDestroy(e));
     if (s->h_qcount) HIPWARN(hipHostFree(s->h_qcount));
     for (hipEvent_t e : s->pipe_ev) HIPWARN(hipEventDestroy(e));
     for (hipEvent_t e : s->pipe_fence) HIPWARN(hipEventDestroy(e));
     if (s->ev2) HIPWARN(hipEventDestroy(s->ev2));
-    for (int i = 0; i < 2; ++i) if (s->st_band[i]) { HIPWARN(hipStreamSynchronize(s->st_band[i])); HIPWARN(hipStreamDestroy(s->st_band[i])); }
-    for (int i = 0; i < RT_MAX_BANDS; ++i) if (s->ev_band[i]) HIPWARN(hipEventDestroy(s->ev_band[i]));
-    if (s->dev_frames) HIPWARN(hipFree(s->dev_frames));
-    if (s->band_counters) HIPWARN(hipFree(s->band_counters));
     if (s->ev0) HIPWARN(hipEventDestroy(s->ev0));
     if (s->ev1) HIPWARN(hipEventDestroy(s->ev1));
     if (s->own_stream && s->stream) HIPWARN(hipStreamDestroy(s->stream));
@@ -1625,8 +1498,7 @@ static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool nee
             fr.tile_w = fr.tile_h = fr.tiles_x = 0; fr.tile_pixels = 1;
             fr.total_work = fr.total_pixels * fr.spp;
         }
-        if (fr.trav_mode == 3 && fr.high_occupancy) fr.trav_mode = 1;   // the high-occupancy kernels carry no pooled-leaf scratch
-        if (fr.trav_mode < 0 || fr.trav_mode > 4) fr.trav_mode = 1;
+        if (fr.trav_mode != 3 || fr.high_occupancy) fr.trav_mode = 2;  // (the high-occupancy kernels carry no pooled-leaf scratch)
     }
     fr.work_counter = s->work_counter; fr.counters = s->counters; fr.spill = s->spill; fr.n_threads = s->n_threads;
     fr.frames = s->frames;
@@ -1782,7 +1654,12 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
     {
         size_t cap = s->samples_cap;
         const size_t local_pixels = size_t(fr.total_work / fr.spp);                     // sample_slot(): whole 64-pixel chunks
-        rc = ensure(s, &s->samples, &cap, ((local_pixels + 63) / 64 * 64 + 64) * size_t(fr.spp) * 2); if (rc) return rc;
+        const size_t need = ((local_pixels + 63) / 64 * 64 + 64) * size_t(fr.spp) * 2;
+        rc = ensure(s, &s->samples, &cap, need); if (rc) return rc;
+        // A fresh buffer is zeroed once: the film gathers weigh the records of lanes without a column of their own (film_march_kernel: record 0)
+        // and of dropped border items with +0, which is only a zero if the record is finite -- from here on sample_write keeps it so; a rank
+        // that owns no tile at all writes nothing, ever.  For dropped items rt_samples_read returns zeros or what an earlier frame left there.
+        if (cap != s->samples_cap) HIPCHK(hipMemsetAsync(s->samples, 0, cap * sizeof(float4), s->stream));
         s->samples_cap = cap;
     }
     fr.samples = s->samples; s->samples_last = fr.total_work; s->samples_spp = fr.spp;
@@ -1837,38 +1714,11 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
         HIPCHK(hipGetLastError());
         return RT_OK;
     };
-    s->last_bands = 1;
-    bool film_done = false;
     if (fr.pipeline) {
         rc = render_pipeline(s, rd, fr, vol_levels, vol_nmax, vol_samp_words); if (rc) return rc;
     } else {
-        // ---- bands.  The work list of an unsharded frame is in scanline order, so a range of it is a band of sample rows; the frame is rendered as
-        // `bands` launches alternating between two streams and the film rows a band completes are gathered (on the caller's stream) while the next
-        // bands render: of the gather only the last band's share stays exposed, and it fills the machine while a render launch drains.  A pixel still
-        // receives its samples in the reference's order in ONE gather launch (the one after the last sample row that reaches it), so the film is
-        // the same bits; two launches can be resident at once, hence two sets of per-thread scratch.
-        int bands = 1;
-        if (const char *e = knob("PBRT_HIP_BANDS")) bands = std::max(1, std::min(RT_MAX_BANDS, std::atoi(e)));
-        if (fr.shard_count != 1 || fr.tile_w != 0 || which == 0 || skip_film || s->volume.present || fr.y_pixel_count < 64) bands = 1;
-        int row_cut[RT_MAX_BANDS + 1]; unsigned long long work_cut[RT_MAX_BANDS + 1];
-        if (bands > 1) {
-            // band k gathers film rows [row_cut[k], row_cut[k+1]) (cuts on multiples of 16 rows) once the work list is rendered up to work_cut[k+1]:
-            // every sample row that reaches a film row above the cut, i.e. sample rows < y_pixel_start + cut + gry
-            const unsigned long long per_row = (unsigned long long)(fr.x_end - fr.x_start) * fr.spp;
-            int nb = 0;
-            row_cut[0] = 0; work_cut[0] = 0;
-            for (int k = 1; k < bands; ++k) {
-                const int cut = int((long long)fr.y_pixel_count * k / bands / 16 * 16);
-                const long long srow = std::max<long long>(fr.y_start, std::min<long long>(fr.y_end, (long long)fr.y_pixel_start + cut + gry));
-                const unsigned long long w = (unsigned long long)(srow - fr.y_start) * per_row;
-                if (cut > row_cut[nb] && cut < fr.y_pixel_count && w > work_cut[nb] && w < fr.total_work) { ++nb; row_cut[nb] = cut; work_cut[nb] = w; }
-            }
-            ++nb; row_cut[nb] = fr.y_pixel_count; work_cut[nb] = fr.total_work;
-            bands = nb;
-        }
-        const int sets = bands > 1 ? 2 : 1;
         if (rd->integrator != RT_INTEGRATOR_PATH) {           // recursion frames for whitted / directlighting
-            rc = ensure(s, &s->frames, &s->frames_floats, size_t(sets) * size_t(rd->max_depth + 2) * RT_FRAME_WORDS * s->n_threads); if (rc) return rc;
+            rc = ensure(s, &s->frames, &s->frames_floats, size_t(rd->max_depth + 2) * RT_FRAME_WORDS * s->n_threads); if (rc) return rc;
             fr.frames = s->frames;
         }
         if (s->volume.present) {
@@ -1880,54 +1730,16 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
         if (fr.high_occupancy && !s->counting) variant = 24 + ((s->volume.present ? 1 : 0) * 2 + (s->accel_kind == RT_ACCEL_GRID ? 1 : 0)) * 3 + rd->integrator;
         if (s->has_ext && !s->counting) variant = 36 + ((s->volume.present ? 1 : 0) * 2 + (s->accel_kind == RT_ACCEL_GRID ? 1 : 0)) * 3 + rd->integrator;
         if (s->grids[variant] == 0) return fail(RT_ESTATE, "render kernel variant has no resident grid");
-        if (bands == 1) {
-            HIPCHK(hipMemcpyAsync(s->dev_frame, &fr, sizeof(DevFrame), hipMemcpyHostToDevice, s->stream));
-            HIPCHK(hipMemsetAsync(s->work_counter, 0, sizeof(unsigned long long), s->stream));
-            HIPCHK(hipEventRecord(s->ev0, s->stream));
-            hipLaunchKernelGGL(render_kernel_of(variant), dim3(s->grids[variant]), dim3(RT_BLOCK), 0, s->stream,
-                               (const DevScene *)s->dev_scene, (const DevFrame *)s->dev_frame);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipEventRecord(s->ev1, s->stream));
-        } else {
-            if (!s->st_band[0]) {
-                for (int i = 0; i < 2; ++i) HIPCHK(hipStreamCreateWithFlags(&s->st_band[i], hipStreamNonBlocking));
-                for (int i = 0; i < RT_MAX_BANDS; ++i) HIPCHK(hipEventCreateWithFlags(&s->ev_band[i], hipEventDisableTiming));
-                HIPCHK(hipMalloc((void **)&s->dev_frames, RT_MAX_BANDS * sizeof(DevFrame)));
-                HIPCHK(hipMalloc((void **)&s->band_counters, RT_MAX_BANDS * sizeof(unsigned long long)));
-            }
-            std::vector<DevFrame> host_frames;                               // (a pageable source is staged by the runtime before hipMemcpyAsync returns, as for `fr` above)
-            host_frames.assign(size_t(bands), fr);
-            for (int k = 0; k < bands; ++k) {
-                DevFrame &f = host_frames[size_t(k)];
-                f.work_begin = work_cut[k]; f.total_work = work_cut[k + 1];
-                f.work_counter = s->band_counters + k;
-                if (k & 1) {                                  // the second set of per-thread scratch
-                    f.spill = (decltype(f.spill))((uint4 *)s->spill + size_t(s->spill_depth) * s->n_threads);
-                    if (f.frames) f.frames = s->frames + size_t(rd->max_depth + 2) * RT_FRAME_WORDS * s->n_threads;
-                }
-            }
-            HIPCHK(hipMemcpyAsync(s->dev_frames, host_frames.data(), size_t(bands) * sizeof(DevFrame), hipMemcpyHostToDevice, s->stream));
-            HIPCHK(hipMemcpyAsync(s->dev_frame, &host_frames[0], sizeof(DevFrame), hipMemcpyHostToDevice, s->stream));
-            HIPCHK(hipMemsetAsync(s->band_counters, 0, RT_MAX_BANDS * sizeof(unsigned long long), s->stream));
-            HIPCHK(hipEventRecord(s->ev0, s->stream));
-            for (int i = 0; i < 2; ++i) HIPCHK(hipStreamWaitEvent(s->st_band[i], s->ev0, 0));
-            for (int k = 0; k < bands; ++k) {
-                hipLaunchKernelGGL(render_kernel_of(variant), dim3(s->grids[variant]), dim3(RT_BLOCK), 0, s->st_band[k & 1],
-                                   (const DevScene *)s->dev_scene, (const DevFrame *)(s->dev_frames + k));
-                HIPCHK(hipGetLastError());
-                HIPCHK(hipEventRecord(s->ev_band[k], s->st_band[k & 1]));
-            }
-            for (int k = 0; k < bands; ++k) {
-                HIPCHK(hipStreamWaitEvent(s->stream, s->ev_band[k], 0));
-                if (k == bands - 1) HIPCHK(hipEventRecord(s->ev1, s->stream));           // every band rendered; what follows is the exposed share of the gather
-                rc = launch_gather((const DevFrame *)s->dev_frames, row_cut[k], row_cut[k + 1]); if (rc) return rc;
-            }
-            film_done = true;
-            s->last_bands = bands;
-        }
+        HIPCHK(hipMemcpyAsync(s->dev_frame, &fr, sizeof(DevFrame), hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemsetAsync(s->work_counter, 0, sizeof(unsigned long long), s->stream));
+        HIPCHK(hipEventRecord(s->ev0, s->stream));
+        hipLaunchKernelGGL(render_kernel_of(variant), dim3(s->grids[variant]), dim3(RT_BLOCK), 0, s->stream,
+                           (const DevScene *)s->dev_scene, (const DevFrame *)s->dev_frame);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(s->ev1, s->stream));
         s->last_pipeline = false;
     }
-    if (!skip_film && !film_done) { rc = launch_gather((const DevFrame *)s->dev_frame, 0, fr.y_pixel_count); if (rc) return rc; }
+    if (!skip_film) { rc = launch_gather((const DevFrame *)s->dev_frame, 0, fr.y_pixel_count); if (rc) return rc; }
     HIPCHK(hipEventRecord(s->ev2, s->stream));
     s->have_timing = true;
 #ifdef RT_PROFILE
@@ -2035,7 +1847,7 @@ int rt_last_render_stats(RtScene *s, RtRenderStats *out) {
         out->trace_ms = sum; out->shade_ms = sum2;
         out->slots = s->pipe_slots;
     } else out->trace_ms = out->render_ms;
-    out->bands = s->last_pipeline ? 0 : s->last_bands;
+    out->bands = s->last_pipeline ? 0 : 1;
     return RT_OK;
 }
 

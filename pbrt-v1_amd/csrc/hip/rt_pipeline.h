@@ -39,17 +39,10 @@
 #ifndef RT_PIPE_TRACE_DSTEPS
 #define RT_PIPE_TRACE_DSTEPS 1    // steps per round in the trace kernel (the megakernel takes RT_TRACE_DSTEPS = 2): C5's trace launches 203 -> 195 ms
 #endif
-#ifndef RT_TRACE_RANGES
-#define RT_TRACE_RANGES 1         // contiguous ranges of the ray queue with their own heads (8 = one per XCD: measured WORSE, 1 M path trace 57 -> 60 ms, C5 235 -> 254: the single guided head balances better than range affinity saves misses)
-#endif
-static_assert(RT_TRACE_RANGES >= 1 && RT_TRACE_RANGES <= 8, "the heads sit at q_count[RT_QC_HEAD .. RT_QC_HEAD + 7]");
 
 namespace rt {
 
 static_assert(ST_EXIT < 16, "the slot's control word holds the stage in 4 bits");
-#ifndef RT_PIPE_VOL_SLIM
-#define RT_PIPE_VOL_SLIM 15        // a slot waiting inside a ray march loads / stores only what the march needs
-#endif
 #define RT_PIPE_VEC 12            // float4 planes of slot state (the 11th only for DirectLighting "all", the 12th for the EXT kernels)
 
 struct PipePool {
@@ -93,7 +86,7 @@ RT_DEV void pipe_load(const PipePool &pl, const DevFrame &fr, unsigned slot, Lan
         ln.L = mk3(0.f); ln.thr = mk3(1.f);
         return;
     }
-    if ((RT_PIPE_VOL_SLIM & 1) && ln.stage == ST_VOL_STEP) {   // a ray march waiting for a step's shadow ray: the surface vertex is dead (the march
+    if (ln.stage == ST_VOL_STEP) {                               // a ray march waiting for a step's shadow ray: the surface vertex is dead (the march
         const float4 a2 = st[2 * n], a8 = st[8 * n], a9 = st[9 * n];   // state lives in fr.vol_state); only L, the pending contribution and the ids are live
         ln.L = mk3(a2.x, a2.y, a2.z);
         { const unsigned ml = __float_as_uint(a2.w); ln.v.mat = int(ml & 0xffffu); ln.v.light = int(ml >> 16) - 1; }
@@ -129,9 +122,9 @@ RT_DEV void pipe_store(const PipePool &pl, unsigned slot, const Lane &ln) {
     st[n] = make_float4(__uint_as_float(ln.dim_base), __uint_as_float(ln.rng.ctr), __uint_as_float(ctl), ln.alpha);
     if (ln.stage == ST_EXIT) return;
     st[2 * n] = make_float4(ln.L.x, ln.L.y, ln.L.z, __uint_as_float(unsigned(ln.v.mat) | (unsigned(ln.v.light + 1) << 16)));
-    const bool slim = (RT_PIPE_VOL_SLIM & 2) && ln.stage == ST_VOL_STEP;      // see pipe_load
-    if (!(slim && (RT_PIPE_VOL_SLIM & 4))) st[3 * n] = make_float4(ln.thr.x, ln.thr.y, ln.thr.z, __uint_as_float(unsigned(ln.li) | (unsigned(ln.lj) << 16)));
-    if (!(slim && (RT_PIPE_VOL_SLIM & 8))) {
+    const bool slim = ln.stage == ST_VOL_STEP;                // see pipe_load: a slot waiting inside a ray march stores only what the march needs
+    if (!slim) st[3 * n] = make_float4(ln.thr.x, ln.thr.y, ln.thr.z, __uint_as_float(unsigned(ln.li) | (unsigned(ln.lj) << 16)));
+    if (!slim) {
     st[4 * n] = make_float4(ln.v.p.x, ln.v.p.y, ln.v.p.z, __int_as_float(ln.cur_light));
     st[5 * n] = make_float4(ln.v.nn.x, ln.v.nn.y, ln.v.nn.z, ln.bs1);
     st[6 * n] = make_float4(ln.v.sn.x, ln.v.sn.y, ln.v.sn.z, ln.bs2);
@@ -277,9 +270,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) void pipe_trace_kernel(co
     bool exhausted = false;
     unsigned w_next = 0, w_end = 0;                                     // this wave's chunk of the queue (wave-uniform)
     bool head_done = false;                                             // the global head has passed the end of the queue
+    unsigned w_seen = 0;
     const unsigned n_waves = gridDim.x * (RT_BLOCK / 64);
-    const unsigned home = blockIdx.x % RT_TRACE_RANGES;                 // the queue range this wave draws from first: its XCD's
-    unsigned r_shift = 0, r_seen = 0;                                   // ranges given up so far; the current range's head as last seen
     // Outer loop: report finished rays, refill the idle lanes from the queue (one wave-aggregated atomic).  Inner loop: rounds of
     // traversal with nothing else in it, until enough lanes have finished for a refill to pay (or, once the queue is exhausted,
     // until the wave's last ray ends).
@@ -299,26 +291,15 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) void pipe_trace_kernel(co
             const unsigned have = w_end - w_next;                       // w_end never exceeds total
             unsigned f_lo = 0, f_hi = 0;                                 // the fresh chunk, clipped to the queue
             if (have < n_idle && !head_done) {                          // wave-uniform branch
-                // The queue is cut into RT_TRACE_RANGES contiguous ranges, each with its own head; a wave draws from the range of ITS XCD
-                // (workgroup i runs on XCD i mod 8) and moves on to the next range when that one is empty.  Neighbours in the queue are
-                // neighbours on the film and, for the first bounces, in the scene: kept on one XCD they share that XCD's L2 instead of
-                // being fetched into all eight (the L2s are private; a line two XCDs need is two misses).
                 const int leader = __ffsll((long long)idle) - 1;
-#pragma unroll 1
-                while (!head_done) {
-                    const unsigned r = (home + r_shift) % RT_TRACE_RANGES;
-                    const unsigned lo = unsigned((unsigned long long)total * r / RT_TRACE_RANGES), hi = unsigned((unsigned long long)total * (r + 1u) / RT_TRACE_RANGES);
-                    const unsigned left = hi - lo > r_seen ? hi - lo - r_seen : 0u;     // r_seen: this range's head as this wave last saw it
-                    unsigned want = left / (2u * n_waves / RT_TRACE_RANGES + 1u);
-                    want = want < RT_TRACE_CHUNK_MIN ? RT_TRACE_CHUNK_MIN : (want > RT_TRACE_CHUNK_MAX ? RT_TRACE_CHUNK_MAX : want);
-                    want = want < n_idle - have ? n_idle - have : want;
-                    unsigned base = 0;
-                    if (lane == leader) base = atomicAdd(job.q_count + RT_QC_HEAD + r, want);
-                    base = __builtin_amdgcn_readfirstlane(__shfl(base, leader));
-                    if (base < hi - lo) { f_lo = lo + base; f_hi = lo + base + want < hi ? lo + base + want : hi; r_seen = base + want; break; }
-                    ++r_shift; r_seen = 0u;
-                    head_done = r_shift >= RT_TRACE_RANGES;
-                }
+                unsigned want = (total > w_seen ? total - w_seen : 0u) / (2u * n_waves + 1u);     // w_seen: the head as this wave last saw it
+                want = want < RT_TRACE_CHUNK_MIN ? RT_TRACE_CHUNK_MIN : (want > RT_TRACE_CHUNK_MAX ? RT_TRACE_CHUNK_MAX : want);
+                want = want < n_idle - have ? n_idle - have : want;
+                unsigned base = 0;
+                if (lane == leader) base = atomicAdd(job.q_count + RT_QC_HEAD, want);
+                base = __builtin_amdgcn_readfirstlane(__shfl(base, leader));
+                if (base < total) { f_lo = base; f_hi = base + want < total ? base + want : total; w_seen = base + want; }
+                else head_done = true;
             }
             const unsigned rk = unsigned(__popcll(idle & ((1ull << lane) - 1ull)));
             const unsigned fi = f_lo + (rk - have);

@@ -28,12 +28,6 @@ RT_DEV unsigned long long uniform64(unsigned long long v) {
 #ifndef RT_HIGH_OCC_WAVES
 #define RT_HIGH_OCC_WAVES 4
 #endif
-#ifndef RT_EXIT_THRESH
-#define RT_EXIT_THRESH 0
-#endif
-#ifndef RT_LOCKSTEP
-#define RT_LOCKSTEP 1
-#endif
 // Scene and frame descriptors are read through pointers (uniform addresses -> scalar loads on demand) instead of
 // being passed by value: the by-value form pinned >100 SGPRs and spilled them.
 // MINW = minimum waves per SIMD the register allocator must make room for: 1 = natural allocation (~160 VGPRs, 3 waves/SIMD,
@@ -93,7 +87,7 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
                 if (have < n_want) {                                      // wave-uniform branch
                     const int leader = __ffsll((long long)want) - 1;
                     if (lane == leader) fresh = atomicAdd(fr.work_counter, (unsigned long long)RT_MEGA_CHUNK);
-                    fresh = uniform64(__shfl(fresh, leader)) + fr.work_begin;
+                    fresh = uniform64(__shfl(fresh, leader));
                 }
                 const unsigned long long rk = __popcll(want & ((1ull << lane) - 1ull));
                 const unsigned long long w_mine = rk < have ? w_next + rk : fresh + (rk - have);
@@ -133,11 +127,8 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
             if (!am) break;
             RT_PF(++pf_rounds; pf_act += __popcll(am);)
             if (fr.exit_thresh > 0 && __popcll(am) <= fr.exit_thresh && __any(!act && ln.stage != ST_EXIT)) break;
-            if (fr.trav_mode == 1) accel_round<COUNT, ACCEL, EXT>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc);
-            else if (fr.trav_mode == 2) trace_round<COUNT, ACCEL, EXT, RT_STACK_LDS, !POOL>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, lds_tm, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc, fr.leaf_min);
-            else if (fr.trav_mode == 4) accel_round_batched<COUNT, ACCEL, EXT>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc);
-            else if (POOL && fr.trav_mode == 3) accel_round_pooled<COUNT, ACCEL, EXT>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc, pool);
-            else if (act) accel_step<COUNT, ACCEL, EXT>(ln.tv, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc);
+            if (POOL && fr.trav_mode == 3) accel_round_pooled<COUNT, ACCEL, EXT>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc, pool);
+            else trace_round<COUNT, ACCEL, EXT, RT_STACK_LDS, !POOL>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, lds_tm, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc, fr.leaf_min);
         }
         if (ln.has_ray && !ln.tv.active) ln.has_ray = false;
         RT_PF(pf_trav += __builtin_readcyclecounter() - pf_t0;)

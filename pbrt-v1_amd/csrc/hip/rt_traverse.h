@@ -27,18 +27,16 @@
 #endif
 // Per-lane 4-entry mailbox window: measured SLOWER on MI355X (C2 92.9 vs 87.8 ms, 100k-soup path 169 vs 165 ms): the
 // four compares + rotates per candidate cost more VALU than the avoided re-tests save.  Kept as a compile-time knob.
-#ifndef RT_MAILBOX
-#define RT_MAILBOX 0
-#endif
 
 namespace rt {
 
+// A value the compiler must treat as defined without spending an instruction on it: the select-style steps read their load results on
+// every lane and commit them under lane masks, so a lane that did not load needs no particular value -- initialising the eight words of a
+// step's two pair records cost 14 v_mov_b32 per step (of ~100 vector instructions).
+RT_DEV void undef_u4(uint4 &v) { asm("" : "=v"(v.x), "=v"(v.y), "=v"(v.z), "=v"(v.w)); }
+RT_DEV void undef_f4(float4 &v) { asm("" : "=v"(v.x), "=v"(v.y), "=v"(v.z), "=v"(v.w)); }
+
 struct Ray { V3 o, d; float mint, maxt; };
-#ifdef RT_PAIR_FETCH
-#define RT_PAIR_INIT(tv) tv.nxt_node = 0xffffffffu;
-#else
-#define RT_PAIR_INIT(tv)
-#endif
 
 struct Trav {
     // ray being traced
@@ -49,16 +47,9 @@ struct Trav {
     unsigned cx, cy;               // sibling-pair form (kdp_step): the CONTENTS of the current node instead of its index
     float tmin, tmax;
     int sp, sbase;                 // todo stack: entries [sbase, sp) live in the LDS ring, [0, sbase) in HBM
-#ifdef RT_PAIR_FETCH
-    uint2 nxt; unsigned nxt_node;  // contents of node nxt_node (the below child of the node fetched last), fetched with its parent
-#endif
     // leaf / voxel primitive-list cursor for the lock-step ("while-while") traversal: at_leaf => test prims [li, ln)
     unsigned li, ln_, ly;
     bool at_leaf;
-#if RT_MAILBOX
-    unsigned mb0, mb1, mb2, mb3;   // the last four primitives tested for this ray (the reference mailboxes every primitive,
-                                   // kdtree.cpp:373-374; a short per-lane window removes most repeat tests of straddling triangles)
-#endif
     // grid 3D-DDA cursor (grid.cpp:238-260): voxel position and the ray parameter of the next crossing per axis
     int gpos[3];
     float gnext[3];
@@ -232,10 +223,7 @@ RT_DEV uint2 stack_pop(Trav &tv, const uint2 RT_L *lds_stack, const uint2 RT_G *
 // start a traversal: slab-clip against the tree bounds (geometry.cpp:51-68, NaN-preserving ternaries)
 RT_DEV void trav_begin(Trav &tv, const DevScene &sc, const Ray &r, bool any) {
     tv.o = r.o; tv.d = r.d; tv.mint = r.mint; tv.maxt = r.maxt; tv.any = any;
-    tv.hit_prim = -1; tv.b1 = 0.f; tv.b2 = 0.f; tv.sp = 0; tv.sbase = 0; RT_PAIR_INIT(tv) tv.node = 0; tv.at_leaf = false; tv.li = tv.ln_ = tv.ly = 0;
-#if RT_MAILBOX
-    tv.mb0 = tv.mb1 = tv.mb2 = tv.mb3 = 0xffffffffu;
-#endif
+    tv.hit_prim = -1; tv.b1 = 0.f; tv.b2 = 0.f; tv.sp = 0; tv.sbase = 0; tv.node = 0; tv.at_leaf = false; tv.li = tv.ln_ = tv.ly = 0;
     float t0 = r.mint, t1 = r.maxt;
     bool ok = true;
 #pragma unroll
@@ -254,64 +242,13 @@ RT_DEV void trav_begin(Trav &tv, const DevScene &sc, const Ray &r, bool any) {
     tv.active = ok && sc.n_tris > 0;
 }
 
-// one node visit
-template <bool COUNT, bool EXT>
-RT_DEV void trav_step(Trav &tv, const DevScene &sc, uint2 RT_L *lds_stack, uint2 RT_G *spill, unsigned n_threads,
-                      unsigned gtid, TravCounters &cnt) {
-    if (!tv.any && tv.maxt < tv.tmin) { tv.active = false; return; }      // kdtree.cpp:330
-    const uint2 nd = RT_GPTR(const uint2, sc.nodes)[tv.node];
-    if (COUNT) ++cnt.nodes;
-    if ((nd.x & 3u) != 3u) {
-        const int axis = int(nd.x & 3u);
-        const float split = __uint_as_float(nd.x);                         // perturbed split, B10
-        const float oa = comp(tv.o, axis), da = comp(tv.d, axis);
-        const float tplane = (split - oa) * comp(tv.inv, axis);
-        const bool belowFirst = (oa < split) || (oa == split && da >= 0.f);
-        const unsigned first = belowFirst ? tv.node + 1 : nd.y;
-        const unsigned second = belowFirst ? nd.y : tv.node + 1;
-        if (tplane > tv.tmax || tplane <= 0.f) tv.node = first;
-        else if (tplane < tv.tmin) tv.node = second;
-        else {
-            stack_push<COUNT>(tv, make_uint2(second, __float_as_uint(tv.tmax)), lds_stack, spill, n_threads, gtid, cnt);
-            tv.node = first;
-            tv.tmax = tplane;
-        }
-        return;
-    }
-    // leaf
-    const unsigned np = nd.x >> 2;
-    for (unsigned i = 0; i < np; ++i) {
-        const unsigned prim = (np == 1) ? nd.y : RT_GPTR(const unsigned, sc.leaf_refs)[nd.y + i];
-        if (COUNT && np > 1) ++cnt.leaf_refs;
-#if RT_MAILBOX
-        if (prim == tv.mb0 || prim == tv.mb1 || prim == tv.mb2 || prim == tv.mb3) continue;
-        tv.mb3 = tv.mb2; tv.mb2 = tv.mb1; tv.mb1 = tv.mb0; tv.mb0 = prim;
-#endif
-        if (COUNT) ++cnt.tris;
-        float t, b1, b2;
-        if (prim_test<EXT>(sc, prim, tv.o, tv.d, tv.mint, tv.maxt, t, b1, b2)) {
-            if (tv.any) { tv.hit_prim = 0; tv.active = false; return; }    // kdtree.cpp:432-434
-            tv.maxt = t; tv.hit_prim = int(prim); tv.b1 = b1; tv.b2 = b2;  // primitive.cpp:120
-        }
-    }
-    if (tv.sp > 0) {
-        const uint2 e = stack_pop(tv, lds_stack, spill, n_threads, gtid);
-        tv.node = e.x;
-        tv.tmin = tv.tmax;
-        tv.tmax = __uint_as_float(e.y);
-    } else tv.active = false;
-}
-
 
 // ---- uniform grid: GridAccel::Intersect / IntersectP (reference accelerators/grid.cpp:224-286, :331-390) -------
 RT_DEV float arr3(const float *a, int i) { return i == 0 ? a[0] : (i == 1 ? a[1] : a[2]); }
 RT_DEV int arr3i(const int *a, int i) { return i == 0 ? a[0] : (i == 1 ? a[1] : a[2]); }
 RT_DEV void grid_begin(Trav &tv, const DevScene &sc, const Ray &r, bool any) {
     tv.o = r.o; tv.d = r.d; tv.mint = r.mint; tv.maxt = r.maxt; tv.any = any;
-    tv.hit_prim = -1; tv.b1 = 0.f; tv.b2 = 0.f; tv.sp = 0; tv.sbase = 0; RT_PAIR_INIT(tv) tv.node = 0; tv.at_leaf = false; tv.li = tv.ln_ = tv.ly = 0;
-#if RT_MAILBOX
-    tv.mb0 = tv.mb1 = tv.mb2 = tv.mb3 = 0xffffffffu;
-#endif
+    tv.hit_prim = -1; tv.b1 = 0.f; tv.b2 = 0.f; tv.sp = 0; tv.sbase = 0; tv.node = 0; tv.at_leaf = false; tv.li = tv.ln_ = tv.ly = 0;
     tv.inv = mk3(0.f); tv.tmin = tv.tmax = 0.f;
     float rayT;
     const V3 pm = r.o + r.d * r.mint;                                        // bounds.Inside(ray(ray.mint))
@@ -346,78 +283,11 @@ RT_DEV void grid_begin(Trav &tv, const DevScene &sc, const Ray &r, bool any) {
     tv.active = ok && sc.n_tris > 0;
 }
 
-// one voxel visit
-template <bool COUNT, bool EXT>
-RT_DEV void grid_step(Trav &tv, const DevScene &sc, TravCounters &cnt) {
-    const uint2 vx = RT_GPTR(const uint2, sc.nodes)[(size_t(tv.gpos[2]) * sc.nvox[1] + tv.gpos[1]) * sc.nvox[0] + tv.gpos[0]];
-    if (COUNT) ++cnt.nodes;
-    for (unsigned i = 0; i < vx.y; ++i) {
-        const unsigned prim = RT_GPTR(const unsigned, sc.leaf_refs)[vx.x + i];
-        if (COUNT) ++cnt.leaf_refs;
-#if RT_MAILBOX
-        if (prim == tv.mb0 || prim == tv.mb1 || prim == tv.mb2 || prim == tv.mb3) continue;
-        tv.mb3 = tv.mb2; tv.mb2 = tv.mb1; tv.mb1 = tv.mb0; tv.mb0 = prim;
-#endif
-        if (COUNT) ++cnt.tris;
-        float t, b1, b2;
-        if (prim_test<EXT>(sc, prim, tv.o, tv.d, tv.mint, tv.maxt, t, b1, b2)) {
-            if (tv.any) { tv.hit_prim = 0; tv.active = false; return; }
-            tv.maxt = t; tv.hit_prim = int(prim); tv.b1 = b1; tv.b2 = b2;
-        }
-    }
-    // advance to the next voxel (grid.cpp:273-283)
-    const int bits = ((tv.gnext[0] < tv.gnext[1]) << 2) + ((tv.gnext[0] < tv.gnext[2]) << 1) + ((tv.gnext[1] < tv.gnext[2]));
-    const int stepAxis = (0x00221212 >> (4 * bits)) & 3;                      // cmpToAxis[8] = {2,1,2,1,2,2,0,0}
-    const float nx = arr3(tv.gnext, stepAxis);
-    if (tv.maxt < nx) { tv.active = false; return; }
-    const float da = comp(tv.d, stepAxis);
-    const int step = da >= 0 ? 1 : -1, out = da >= 0 ? arr3i(sc.nvox, stepAxis) : -1;
-    const int np = arr3i(tv.gpos, stepAxis) + step;
-    if (np == out) { tv.active = false; return; }
-    const float delta = (da >= 0 ? arr3(sc.gwidth, stepAxis) : -arr3(sc.gwidth, stepAxis)) / da;   // DeltaT
-    if (stepAxis == 0) { tv.gpos[0] = np; tv.gnext[0] = nx + delta; }
-    else if (stepAxis == 1) { tv.gpos[1] = np; tv.gnext[1] = nx + delta; }
-    else { tv.gpos[2] = np; tv.gnext[2] = nx + delta; }
-}
-
 // ---- lock-step ("while-while") form of the same traversals ---------------------------------------------------
 // The per-lane order of node visits and triangle tests is exactly that of trav_step / grid_step (so hits, ties and
 // counters are unchanged); what changes is how the 64 lanes are interleaved: all lanes first walk interior nodes
 // (cheap) until each sits at a leaf, then the expensive ray-triangle tests run with every lane that has a primitive
 // left -- instead of one lane's 8-triangle leaf serialising against 63 lanes doing 20-instruction plane tests.
-template <bool COUNT, int NS = RT_STACK_LDS>
-RT_DEV void kd_descend(Trav &tv, const DevScene &sc, uint2 RT_L *lds_stack, uint2 RT_G *spill, unsigned n_threads, unsigned gtid, TravCounters &cnt) {
-    if (!tv.any && tv.maxt < tv.tmin) { tv.active = false; return; }      // kdtree.cpp:330
-#ifdef RT_PAIR_FETCH
-    // the below child sits right behind its parent (depth-first layout): fetch the pair with one 16-byte request and skip the
-    // next round trip when the traversal continues there (the array is padded by one node)
-    uint2 nd;
-    if (tv.nxt_node == tv.node) { nd = tv.nxt; tv.nxt_node = 0xffffffffu; }
-    else {
-        typedef uint4 __attribute__((aligned(8))) uint4_a8;
-        const uint4_a8 pr = *(const uint4_a8 RT_G *)(RT_GPTR(const uint2, sc.nodes) + tv.node);
-        nd = make_uint2(pr.x, pr.y); tv.nxt = make_uint2(pr.z, pr.w); tv.nxt_node = tv.node + 1u;
-    }
-#else
-    const uint2 nd = RT_GPTR(const uint2, sc.nodes)[tv.node];
-#endif
-    if (COUNT) ++cnt.nodes;
-    if ((nd.x & 3u) == 3u) { tv.at_leaf = true; tv.li = 0; tv.ln_ = nd.x >> 2; tv.ly = nd.y; return; }
-    const int axis = int(nd.x & 3u);
-    const float split = __uint_as_float(nd.x);
-    const float oa = comp(tv.o, axis), da = comp(tv.d, axis);
-    const float tplane = (split - oa) * comp(tv.inv, axis);
-    const bool belowFirst = (oa < split) || (oa == split && da >= 0.f);
-    const unsigned first = belowFirst ? tv.node + 1 : nd.y;
-    const unsigned second = belowFirst ? nd.y : tv.node + 1;
-    if (tplane > tv.tmax || tplane <= 0.f) tv.node = first;
-    else if (tplane < tv.tmin) tv.node = second;
-    else {
-        stack_push<COUNT, NS>(tv, make_uint2(second, __float_as_uint(tv.tmax)), lds_stack, spill, n_threads, gtid, cnt);
-        tv.node = first;
-        tv.tmax = tplane;
-    }
-}
 // one primitive of the current leaf / voxel list
 template <bool COUNT, bool GRID, bool EXT>
 RT_DEV void leaf_test_one(Trav &tv, const DevScene &sc, TravCounters &cnt) {
@@ -425,10 +295,6 @@ RT_DEV void leaf_test_one(Trav &tv, const DevScene &sc, TravCounters &cnt) {
     const unsigned prim = single ? tv.ly : RT_GPTR(const unsigned, sc.leaf_refs)[tv.ly + tv.li];
     ++tv.li;
     if (COUNT && !single) ++cnt.leaf_refs;
-#if RT_MAILBOX
-    if (prim == tv.mb0 || prim == tv.mb1 || prim == tv.mb2 || prim == tv.mb3) return;   // already tested for this ray: same t, same outcome
-    tv.mb3 = tv.mb2; tv.mb2 = tv.mb1; tv.mb1 = tv.mb0; tv.mb0 = prim;
-#endif
     if (COUNT) ++cnt.tris;
     float t, b1, b2;
     if (prim_test<EXT>(sc, prim, tv.o, tv.d, tv.mint, tv.maxt, t, b1, b2)) {
@@ -464,28 +330,6 @@ RT_DEV void grid_voxel_done(Trav &tv, const DevScene &sc) {               // gri
     if (stepAxis == 0) { tv.gpos[0] = np; tv.gnext[0] = nx + delta; }
     else if (stepAxis == 1) { tv.gpos[1] = np; tv.gnext[1] = nx + delta; }
     else { tv.gpos[2] = np; tv.gnext[2] = nx + delta; }
-}
-
-// One lock-step round for the whole wave: descend -> test -> pop.  `mine` = this lane carries a live traversal.
-template <bool COUNT, int ACCEL, bool EXT>
-RT_DEV void accel_round(Trav &tv, bool mine, const DevScene &sc, uint2 RT_L *lds_stack, uint2 RT_G *spill, unsigned n_threads,
-                        unsigned gtid, TravCounters &cnt) {
-    RT_PFT(unsigned long long t0 = __builtin_readcyclecounter();)
-    if (ACCEL == RT_ACCEL_GRID) {
-        if (mine && tv.active && !tv.at_leaf) grid_enter_voxel<COUNT>(tv, sc, cnt);
-    } else {
-        while (__any(mine && tv.active && !tv.at_leaf))
-            if (mine && tv.active && !tv.at_leaf) kd_descend<COUNT>(tv, sc, lds_stack, spill, n_threads, gtid, cnt);
-    }
-    RT_PFT(unsigned long long t1 = __builtin_readcyclecounter(); cnt.c_desc += t1 - t0;)
-    while (__any(mine && tv.active && tv.at_leaf && tv.li < tv.ln_)) {
-        RT_PFT(++cnt.n_iter;)
-        if (mine && tv.active && tv.at_leaf && tv.li < tv.ln_) leaf_test_one<COUNT, ACCEL == RT_ACCEL_GRID, EXT>(tv, sc, cnt);
-    }
-    RT_PFT(cnt.c_leaf += __builtin_readcyclecounter() - t1;)
-    if (mine && tv.active && tv.at_leaf) {
-        if (ACCEL == RT_ACCEL_GRID) grid_voxel_done(tv, sc); else kd_leaf_done(tv, lds_stack, spill, n_threads, gtid);
-    }
 }
 
 // ---- pooled leaf tests ----------------------------------------------------------------------------------------
@@ -588,16 +432,11 @@ RT_DEV void accel_round_pooled(Trav &tv, bool mine, const DevScene &sc, uint2 RT
     if (ACCEL == RT_ACCEL_GRID) {
         if (mine && tv.active && !tv.at_leaf) grid_enter_voxel<COUNT>(tv, sc, cnt);
     } else {
-#ifdef RT_POOLED_BRANCHY_DESCENT
-        while (__any(mine && tv.active && !tv.at_leaf))
-            if (mine && tv.active && !tv.at_leaf) kd_descend<COUNT>(tv, sc, lds_stack, spill, n_threads, gtid, cnt);
-#else
         for (;;) {
             const bool desc = mine && tv.active && !tv.at_leaf;
             if (!__any(desc)) break;
             kd_step_flat<COUNT, RT_STACK_LDS, false>(tv, desc, sc, lds_stack, spill, n_threads, gtid, cnt);
         }
-#endif
     }
     RT_PFT(unsigned long long t1 = __builtin_readcyclecounter(); cnt.c_desc += t1 - t0;)
     const bool need = mine && tv.active && tv.at_leaf;
@@ -621,44 +460,11 @@ RT_DEV void accel_round_pooled(Trav &tv, bool mine, const DevScene &sc, uint2 RT
     }
 }
 
-// Batched form: every round each descending lane takes ONE interior step; lanes parked at a leaf wait until at least
-// RT_BATCH_K lanes have a primitive to test (or nobody is descending any more), then one ray-triangle test is issued
-// for all of them together.  Adapts between the tiny-tree regime (many primitives per leaf: behaves like lock-step)
-// and the big-tree regime (long interior chains, ~1 primitive per leaf: lanes are not held hostage by one another).
-#ifndef RT_BATCH_K
-#define RT_BATCH_K 16
-#endif
-template <bool COUNT, int ACCEL, bool EXT, int NS = RT_STACK_LDS>
-RT_DEV void accel_round_batched(Trav &tv, bool mine, const DevScene &sc, uint2 RT_L *lds_stack, uint2 RT_G *spill, unsigned n_threads,
-                                unsigned gtid, TravCounters &cnt) {
-    const bool act = mine && tv.active;
-    const bool desc = act && !tv.at_leaf;
-    const bool leafw = act && tv.at_leaf && tv.li < tv.ln_;
-    const int nd = __popcll(__ballot(desc)), nl = __popcll(__ballot(leafw));
-    if (desc) {
-        if (ACCEL == RT_ACCEL_GRID) grid_enter_voxel<COUNT>(tv, sc, cnt);
-        else kd_descend<COUNT, NS>(tv, sc, lds_stack, spill, n_threads, gtid, cnt);
-    }
-    if (nl && (nl >= RT_BATCH_K || nd == 0)) {
-        if (leafw) leaf_test_one<COUNT, ACCEL == RT_ACCEL_GRID, EXT>(tv, sc, cnt);
-    }
-    if (mine && tv.active && tv.at_leaf && tv.li >= tv.ln_) {
-        if (ACCEL == RT_ACCEL_GRID) grid_voxel_done(tv, sc); else kd_leaf_done<NS>(tv, lds_stack, spill, n_threads, gtid);
-    }
-}
-
 // ---- flat (select-style) traversal steps and the round built from them: used by the trace kernel of the queue pipeline
 // (rt_pipeline.h) and by the megakernel's trav_mode 2 ----
 #ifndef RT_TRACE_DSTEPS
 #define RT_TRACE_DSTEPS 2         // steps (of up to two levels each) a descending lane may take per round before the leaf phase gets its turn
                                   // (round 3, two-level steps: 2 beats 4 by 7 % on the 1 M-triangle path frame, 5 % on C3)
-#endif
-#ifndef RT_TRACE_FOLD
-#define RT_TRACE_FOLD 1            // pair form: a leaf child (or popped leaf) is entered in the step that selects it
-#endif
-#ifndef RT_STEP_REGION
-#define RT_STEP_REGION 0           // bits 1 / 2 / 4: kdp_step / leaf_test_flat / kdp_pop as ONE predicated region each instead of select-style code: 9 % fewer static VALU
-                                  // instructions in the trace kernel and measurably slower (round 3: 1 M path 64.4 -> 68.9 ms, C5 trace 195 -> 205 ms)
 #endif
 #ifndef RT_TRACE_LEAF_MIN
 #define RT_TRACE_LEAF_MIN 24      // keep testing primitives while at least this many lanes have one left (the megakernel takes DevFrame::leaf_min: 8 on tiny trees)
@@ -676,11 +482,7 @@ RT_DEV void kd_step_flat(Trav &tv, bool desc, const DevScene &sc, uint2 RT_L *ld
     const bool go = desc && !dead;
     uint2 nd = make_uint2(3u, 0u);
     if (go) nd = RT_GPTR(const uint2, LEAF_ORDER ? sc.tnodes : sc.nodes)[tv.node];
-#ifdef RT_PROBE_UTIL
-    if (COUNT) cnt.nodes += 1u;          // lane slots, not visits: tools/r02_trace_scan.py group util
-#else
     if (COUNT) cnt.nodes += go ? 1u : 0u;
-#endif
     const unsigned axis = nd.x & 3u;
     const bool leaf = axis == 3u;
     const float split = __uint_as_float(nd.x);                                 // perturbed split, B10
@@ -706,40 +508,11 @@ RT_DEV void kd_step_flat(Trav &tv, bool desc, const DevScene &sc, uint2 RT_L *ld
 template <bool COUNT>
 RT_DEV void leaf_test_flat(Trav &tv, bool leafw, const DevScene &sc, TravCounters &cnt) {
     // leaf-ordered records (DevScene::ltris): primitive li of this leaf sits 3 * li float4s behind the leaf's first
-#ifdef RT_PROBE_UTIL
-    if (COUNT) cnt.tris += 1u;
-#endif
-#if (RT_STEP_REGION & 2)
-    if (leafw) {                                                               // one predicated region (see kdp_step)
-        const float4 RT_G *gt = RT_GPTR(const float4, sc.ltris) + (size_t(tv.ly) + 3u * tv.li);
-        const float4 q0 = gt[0], q1 = gt[1], q2 = gt[2];
-#ifndef RT_PROBE_UTIL
-        if (COUNT) { cnt.tris += 1u; cnt.leaf_refs += tv.ln_ != 1u ? 1u : 0u; }
-#endif
-        tv.li += 1u;
-        const V3 p1 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
-        const V3 s1 = cross3(tv.d, e2);
-        const float divisor = dot3(s1, e1);
-        const float invDivisor = 1.f / divisor;
-        const V3 dd = tv.o - p1;
-        const float b1 = dot3(dd, s1) * invDivisor;
-        const V3 s2 = cross3(dd, e1);
-        const float b2 = dot3(tv.d, s2) * invDivisor;
-        const float t = dot3(e2, s2) * invDivisor;
-        const bool miss = (divisor == 0.f) | (b1 < 0.f) | (b1 > 1.f) | (b2 < 0.f) | (b1 + b2 > 1.f) | (t < tv.mint) | (t > tv.maxt);
-        if (!miss) {
-            if (tv.any) { tv.hit_prim = 0; tv.active = false; }                // kdtree.cpp:432-434
-            else { tv.hit_prim = int(__float_as_uint(q2.w)); tv.maxt = t; tv.b1 = b1; tv.b2 = b2; }   // primitive.cpp:120
-        }
-    }
-#else
     const bool single = tv.ln_ == 1u;
-    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
+    float4 q0, q1, q2; undef_f4(q0); undef_f4(q1); undef_f4(q2);
     if (leafw) { const float4 RT_G *gt = RT_GPTR(const float4, sc.ltris) + (size_t(tv.ly) + 3u * tv.li); q0 = gt[0]; q1 = gt[1]; q2 = gt[2]; }
     const unsigned prim = __float_as_uint(q2.w);
-#ifndef RT_PROBE_UTIL
     if (COUNT) { cnt.tris += leafw ? 1u : 0u; cnt.leaf_refs += (leafw && !single) ? 1u : 0u; }
-#endif
     tv.li += leafw ? 1u : 0u;
     const V3 p1 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
     const V3 s1 = cross3(tv.d, e2);
@@ -759,7 +532,6 @@ RT_DEV void leaf_test_flat(Trav &tv, bool leafw, const DevScene &sc, TravCounter
     tv.b1 = keep ? b1 : tv.b1;
     tv.b2 = keep ? b2 : tv.b2;
     tv.active = stop ? false : tv.active;
-#endif
 }
 template <int NS>
 RT_DEV void kd_pop_flat(Trav &tv, bool done, const uint2 RT_L *lds_stack, const uint2 RT_G *spill, unsigned n_threads, unsigned gtid) {
@@ -803,64 +575,9 @@ template <bool COUNT, int NS>
 RT_DEV void kdp_step(Trav &tv, bool desc, const DevScene &sc, PairStack st, unsigned n_threads, unsigned gtid, TravCounters &cnt) {
     const bool dead = desc && !tv.any && tv.maxt < tv.tmin;                    // kdtree.cpp:330
     const bool go = desc && !dead;
-#ifdef RT_PROBE_UTIL
-    if (COUNT) cnt.nodes += 1u;          // lane slots, not visits: tools/r02_trace_scan.py group util
-#else
     if (COUNT) cnt.nodes += go ? 1u : 0u;
-#endif
     tv.active = dead ? false : tv.active;
     const bool leaf = (tv.cx & 3u) == 3u;                                      // only ever a root that is a leaf
-#if (RT_STEP_REGION & 1)
-    // ONE predicated region for the lanes that really step (the others keep their registers: no dummy operands, no "x = stepping ? new : x"
-    // selects); inside it the code is still straight-line with selects
-    if (go && !leaf) {
-        const unsigned axis = tv.cx & 3u;
-        const float split = __uint_as_float(tv.cx);                            // perturbed split, B10
-        const float oa = comp(tv.o, int(axis)), da = comp(tv.d, int(axis)), ia = comp(tv.inv, int(axis));
-        const float tplane = (split - oa) * ia;
-        const bool belowFirst = (oa < split) | ((oa == split) & (da >= 0.f));
-        const bool only_first = (tplane > tv.tmax) | (tplane <= 0.f);
-        const bool only_second = !only_first & (tplane < tv.tmin);
-        const bool both = !only_first & !only_second;
-        const bool c_above = belowFirst ? only_second : !only_second;         // the child the traversal continues in
-        const unsigned idx = tv.cy & 0x3fffffffu, fb = (tv.cy >> 30) & 1u, fa = tv.cy >> 31;
-        const bool two = (c_above ? fa : fb) != 0u;                            // that child's pair sits in this node's block
-        const uint4 RT_G *p = RT_GPTR(const uint4, sc.tpairs) + idx;
-        const uint4 A = p[0];
-        uint4 B = A;
-        if (two) B = p[c_above ? 1u + fb : 1u];
-        const unsigned c_x = c_above ? A.z : A.x, c_y = c_above ? A.w : A.y;
-        const unsigned f_x = c_above ? A.x : A.z, f_y = c_above ? A.y : A.w;
-        if (both) kdp_push<COUNT, NS>(tv, st, f_x, f_y, tv.tmax, n_threads, gtid, cnt);
-        const float tmax1 = both ? tplane : tv.tmax;
-        tv.cx = c_x; tv.cy = c_y; tv.tmax = tmax1;
-        if (two) {                                                             // the chosen child is interior and its pair is B
-            const unsigned axis2 = c_x & 3u;
-            const float split2 = __uint_as_float(c_x);
-            const float oa2 = comp(tv.o, int(axis2)), da2 = comp(tv.d, int(axis2)), ia2 = comp(tv.inv, int(axis2));
-            const float tplane2 = (split2 - oa2) * ia2;
-            const bool belowFirst2 = (oa2 < split2) | ((oa2 == split2) & (da2 >= 0.f));
-            const bool only_first2 = (tplane2 > tmax1) | (tplane2 <= 0.f);
-            const bool only_second2 = !only_first2 & (tplane2 < tv.tmin);
-            const bool both2 = !only_first2 & !only_second2;
-            const bool g_above = belowFirst2 ? only_second2 : !only_second2;
-            const unsigned g_x = g_above ? B.z : B.x, g_y = g_above ? B.w : B.y;
-            const unsigned h_x = g_above ? B.x : B.z, h_y = g_above ? B.y : B.w;
-            if (both2) kdp_push<COUNT, NS>(tv, st, h_x, h_y, tmax1, n_threads, gtid, cnt);
-#ifndef RT_PROBE_UTIL
-            if (COUNT) cnt.nodes += 1u;
-#endif
-            tv.cx = g_x; tv.cy = g_y; tv.tmax = both2 ? tplane2 : tmax1;
-        }
-        if (RT_TRACE_FOLD && (tv.cx & 3u) == 3u) {                             // a leaf child is entered in the step that selects it
-#ifndef RT_PROBE_UTIL
-            if (COUNT) cnt.nodes += 1u;
-#endif
-            tv.at_leaf = true; tv.li = 0u; tv.ln_ = tv.cx >> 2; tv.ly = tv.cy;
-        }
-    }
-    if (go && leaf) { tv.at_leaf = true; tv.li = 0u; tv.ln_ = tv.cx >> 2; tv.ly = tv.cy; }
-#else
     const unsigned axis = tv.cx & 3u;
     const bool interior = go && !leaf;
     // ---- level 1: decided from the words in hand
@@ -871,10 +588,10 @@ RT_DEV void kdp_step(Trav &tv, bool desc, const DevScene &sc, PairStack st, unsi
     const bool only_first = (tplane > tv.tmax) | (tplane <= 0.f);
     const bool only_second = !only_first & (tplane < tv.tmin);
     const bool both = interior & !only_first & !only_second;
-    const bool c_above = belowFirst ? only_second : !only_second;             // the child the traversal continues in
+    const bool c_above = !(belowFirst ^ only_second);                          // the child the traversal continues in: belowFirst ? only_second : !only_second
     const unsigned idx = tv.cy & 0x3fffffffu, fb = (tv.cy >> 30) & 1u, fa = tv.cy >> 31;
     const bool two = interior && (c_above ? fa : fb) != 0u;                    // that child's pair sits in this node's block
-    uint4 A = make_uint4(3u, 0u, 3u, 0u), B = A;
+    uint4 A, B; undef_u4(A); undef_u4(B);
     if (interior) {
         const uint4 RT_G *p = RT_GPTR(const uint4, sc.tpairs) + idx;
         A = p[0];
@@ -893,56 +610,27 @@ RT_DEV void kdp_step(Trav &tv, bool desc, const DevScene &sc, PairStack st, unsi
     const bool only_first2 = (tplane2 > tmax1) | (tplane2 <= 0.f);
     const bool only_second2 = !only_first2 & (tplane2 < tv.tmin);
     const bool both2 = two & !only_first2 & !only_second2;
-    const bool g_above = belowFirst2 ? only_second2 : !only_second2;
+    const bool g_above = !(belowFirst2 ^ only_second2);
     const unsigned g_x = g_above ? B.z : B.x, g_y = g_above ? B.w : B.y;
     const unsigned h_x = g_above ? B.x : B.z, h_y = g_above ? B.y : B.w;
     if (both2) kdp_push<COUNT, NS>(tv, st, h_x, h_y, tmax1, n_threads, gtid, cnt);
-#ifndef RT_PROBE_UTIL
     if (COUNT) cnt.nodes += two ? 1u : 0u;
-#endif
     tv.cx = interior ? (two ? g_x : c_x) : tv.cx;
     tv.cy = interior ? (two ? g_y : c_y) : tv.cy;
     tv.tmax = interior ? (both2 ? tplane2 : tmax1) : tv.tmax;
     // The chosen child's words are in hand, so a leaf child is entered in this very step (the reference's next iteration re-checks
     // maxt < tmin with unchanged values, kdtree.cpp:330, and then is in the leaf); `leaf` itself is only ever a root that is a leaf.
-    const bool enter = RT_TRACE_FOLD ? go && (tv.cx & 3u) == 3u : go && leaf;
-#ifndef RT_PROBE_UTIL
-    if (COUNT && RT_TRACE_FOLD) cnt.nodes += (interior && enter) ? 1u : 0u;
-#endif
+    const bool enter = go && (tv.cx & 3u) == 3u;
+    if (COUNT) cnt.nodes += (interior && enter) ? 1u : 0u;
     tv.at_leaf = enter ? true : tv.at_leaf;
     tv.li = enter ? 0u : tv.li;
     tv.ln_ = enter ? (tv.cx >> 2) : tv.ln_;
     tv.ly = enter ? tv.cy : tv.ly;
-#endif
 }
 template <bool COUNT, int NS>
 RT_DEV void kdp_pop(Trav &tv, bool done, PairStack st, unsigned n_threads, unsigned gtid, TravCounters &cnt) {
-#if (RT_STEP_REGION & 4)
-    if (done) {
-        tv.at_leaf = false;
-        if (tv.sp > 0) {
-            --tv.sp;
-            const unsigned r = (unsigned(tv.sp) % NS) * RT_BLOCK + threadIdx.x;
-            const volatile uint2 RT_L *px = (const volatile uint2 RT_L *)st.xy + r;
-            const volatile float RT_L *pt = (const volatile float RT_L *)st.tm + r;
-            unsigned ex = px->x, ey = px->y; float et = *pt;
-            if (tv.sp < tv.sbase) { const uint4 e = st.spill[size_t(tv.sp) * n_threads + gtid]; ex = e.x; ey = e.y; et = __uint_as_float(e.z); tv.sbase = tv.sp; }
-            tv.cx = ex; tv.cy = ey; tv.tmin = tv.tmax; tv.tmax = et;
-            // the popped node's words are in hand: the reference's next iteration checks maxt < tmin (kdtree.cpp:330) and, for a leaf, is in it
-            if (RT_TRACE_FOLD) {
-                if (!tv.any && tv.maxt < tv.tmin) tv.active = false;
-                else if ((ex & 3u) == 3u) {
-#ifndef RT_PROBE_UTIL
-                    if (COUNT) cnt.nodes += 1u;
-#endif
-                    tv.at_leaf = true; tv.li = 0u; tv.ln_ = ex >> 2; tv.ly = ey;
-                }
-            }
-        } else tv.active = false;
-    }
-#else
     const bool pop = done && tv.sp > 0;
-    unsigned ex = 0, ey = 0; float et = 0.f;
+    unsigned ex, ey; float et; asm("" : "=v"(ex), "=v"(ey), "=v"(et));
     if (pop) {
         --tv.sp;
         const unsigned r = (unsigned(tv.sp) % NS) * RT_BLOCK + threadIdx.x;
@@ -956,25 +644,16 @@ RT_DEV void kdp_pop(Trav &tv, bool done, PairStack st, unsigned n_threads, unsig
     tv.tmin = pop ? tv.tmax : tv.tmin;
     tv.tmax = pop ? et : tv.tmax;
     // the popped node's words are in hand: the reference's next iteration checks maxt < tmin (kdtree.cpp:330) and, for a leaf, is in it
-    const bool dead = RT_TRACE_FOLD && pop && !tv.any && tv.maxt < tv.tmin;
-    const bool enter = RT_TRACE_FOLD && pop && !dead && (ex & 3u) == 3u;
-#ifndef RT_PROBE_UTIL
+    const bool dead = pop && !tv.any && tv.maxt < tv.tmin;
+    const bool enter = pop && !dead && (ex & 3u) == 3u;
     if (COUNT) cnt.nodes += enter ? 1u : 0u;
-#endif
     tv.at_leaf = done ? enter : tv.at_leaf;
     tv.li = enter ? 0u : tv.li;
     tv.ln_ = enter ? (ex >> 2) : tv.ln_;
     tv.ly = enter ? ey : tv.ly;
     tv.active = (done && (!pop || dead)) ? false : tv.active;
-#endif
 }
 
-#ifndef RT_TRACE_POP_IN_LOOP
-#define RT_TRACE_POP_IN_LOOP 0
-#endif
-#ifndef RT_TRACE_LEAF_GO
-#define RT_TRACE_LEAF_GO 65       // leave the descent steps early once this many lanes hold an untested primitive (65 = never)
-#endif
 template <bool COUNT, int ACCEL, bool EXT, int NS, bool PAIRS_OK = true, int DSTEPS = RT_TRACE_DSTEPS>
 RT_DEV void trace_round(Trav &tv, bool busy, const DevScene &sc, uint2 RT_L *lds_stack, float RT_L *lds_tm, uint2 RT_G *spill, unsigned n_threads, unsigned gtid, TravCounters &cnt,
                         int leaf_min = RT_TRACE_LEAF_MIN) {
@@ -983,21 +662,11 @@ RT_DEV void trace_round(Trav &tv, bool busy, const DevScene &sc, uint2 RT_L *lds
     if (ACCEL == RT_ACCEL_GRID) {
         if (busy && tv.active && !tv.at_leaf) grid_enter_voxel<COUNT>(tv, sc, cnt);
     } else if (PAIRS) {
-        // RT_TRACE_POP_IN_LOOP: a lane leaves a finished (or empty) leaf inside the descent loop instead of at the end of the round
 #pragma unroll 1
         for (int k = 0; k < DSTEPS; ++k) {
             const bool desc = busy && tv.active && !tv.at_leaf;
-            const bool fin = RT_TRACE_POP_IN_LOOP && busy && tv.active && tv.at_leaf && tv.li >= tv.ln_;
-            if (!__any(desc || fin)) break;
-#ifdef RT_PROBE_UTIL
-            if (COUNT) { cnt.leaf_refs += (busy && tv.active) ? 0u : 1u; cnt.spills += (busy && tv.active && tv.at_leaf && tv.li < tv.ln_) ? 1u : 0u; }
-#endif
-            if (__any(desc)) kdp_step<COUNT, NS>(tv, desc, sc, pst, n_threads, gtid, cnt);
-            if (RT_TRACE_POP_IN_LOOP) {
-                const bool done = busy && tv.active && tv.at_leaf && tv.li >= tv.ln_;
-                if (__any(done)) kdp_pop<COUNT, NS>(tv, done, pst, n_threads, gtid, cnt);
-            }
-            if (RT_TRACE_LEAF_GO < 65 && __popcll(__ballot(busy && tv.active && tv.at_leaf && tv.li < tv.ln_)) >= RT_TRACE_LEAF_GO) break;
+            if (!__any(desc)) break;
+            kdp_step<COUNT, NS>(tv, desc, sc, pst, n_threads, gtid, cnt);
         }
     } else {
 #pragma unroll 1
@@ -1027,10 +696,4 @@ template <int ACCEL>
 RT_DEV void accel_begin(Trav &tv, const DevScene &sc, const Ray &r, bool any) {
     if (ACCEL == RT_ACCEL_GRID) grid_begin(tv, sc, r, any); else trav_begin(tv, sc, r, any);
 }
-template <bool COUNT, int ACCEL, bool EXT>
-RT_DEV void accel_step(Trav &tv, const DevScene &sc, uint2 RT_L *lds_stack, uint2 RT_G *spill, unsigned n_threads, unsigned gtid,
-                       TravCounters &cnt) {
-    if (ACCEL == RT_ACCEL_GRID) grid_step<COUNT, EXT>(tv, sc, cnt); else trav_step<COUNT, EXT>(tv, sc, lds_stack, spill, n_threads, gtid, cnt);
-}
-
 }  // namespace rt

@@ -94,3 +94,17 @@ def test_prebuilt_accelerator_gives_the_same_scene(pkg, scenes, tmp_path):
             bad[3, 1] = len(refs) + 7                                         # a voxel list beyond the reference array
         with pytest.raises(pkg.RtError):
             pkg.DeviceScene(ps, prebuilt=(bad, refs, info))
+        # the claims the device sizes scratch from are checked, not trusted: a tree deeper than its max_depth says (the
+        # spill area of the traversal stack is sized from it), bounds / voxel widths that are not finite
+        dup = lambda i: type(i).from_buffer_copy(bytes(i))
+        if accel == "kdtree":
+            shallow = dup(info); shallow.max_depth = 3
+            with pytest.raises(pkg.RtError, match="deeper"):
+                pkg.DeviceScene(ps, prebuilt=(nodes, refs, shallow))
+        else:
+            nanw = dup(info); nanw.grid_inv_width[1] = float("nan")
+            with pytest.raises(pkg.RtError, match="voxel widths"):
+                pkg.DeviceScene(ps, prebuilt=(nodes, refs, nanw))
+        nanb = dup(info); nanb.bounds[4] = float("inf")
+        with pytest.raises(pkg.RtError, match="bounds"):
+            pkg.DeviceScene(ps, prebuilt=(nodes, refs, nanb))
