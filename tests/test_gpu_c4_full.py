@@ -84,7 +84,7 @@ def test_10m_trace_bit_exact_with_identical_work_counters(pkg, oracle, soup10m):
 def test_c4_frame_properties_at_the_stated_film_size(pkg, soup10m):
     """2048 x 2048 film (2049 x 2049 sample extent), path depth 8, material mix, 4 of the 256 samples per pixel."""
     ps, ds = soup10m
-    ds.set_counting(True); ds.reset_counters(); ds.clear_film(); ds.render(); a = ds.film_accum(); ca = ds.counters()
+    ds.set_counting(True); ds.reset_counters(); ds.bind_film(); ds.render(); a = ds.film_accum(); ca = ds.counters()
     ds.reset_counters(); ds.clear_film(); ds.render(); a2 = ds.film_accum(); ca2 = ds.counters()
     ds.set_counting(False); ds.clear_film(); ds.render(); a3 = ds.film_accum(); st = ds.last_stats()      # the timed kernel (what bench.py times on c4full)
     assert st["pipeline"] == 0

@@ -229,3 +229,23 @@ def test_exr_assemble_merges_crop_windows(pkg, tmp_path):
     assert meta == dict(total_res=(40, 30), offset=(0, 0))
     assert np.array_equal(rgb, full.astype(np.float16).astype(np.float32)) and np.array_equal(a, fa.astype(np.float16).astype(np.float32))
     assert abs(pkg.assemble_exr(paths[:2], out) - 0.5) < 1e-6 and np.all(pkg.read_exr(out)[0][15:] == 0)
+
+
+def test_bench_reports_a_stale_profile_as_stale(pkg, tmp_path):
+    """roofline.traffic / valu_issue come from committed rocprofv3 summaries; each carries the code_id (sha256 of the
+    device code objects) of the library that was profiled, and bench.py prints the counters only when the library it loaded has the same one."""
+    import importlib.util, json
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    cid = pkg.code_id()
+    assert len(cid) == 16 and cid == pkg.code_id()
+    prof = {"code_id": cid, "hbm_bytes_per_launch_fetch_doubled": 2e9, "hbm_bytes_per_launch_uncorrected": 1e9,
+            "pmc": {"SQ_INSTS_VALU": 5.1e9}, "derived": {"VALUBusy_percent": 50.0, "VALUUtilization_percent_active_lanes": 70.0, "L2_hit_rate": 0.5}}
+    json.dump(prof, open(tmp_path / "latest_w_render_kernel.json", "w"))
+    out = {"roofline": {"traffic": None, "kernel_ms": 10.0}}
+    bench.attach_profile(out, "w", 4e9, cid, profiles_dir=str(tmp_path))
+    assert out["roofline"]["traffic"] == 2e9 and 0 < out["roofline"]["valu_issue"]["frac"] <= 1.0      # 5.1e9 inst / 1.02e12 per s = 5 ms of 10
+    out = {"roofline": {"traffic": None, "kernel_ms": 10.0}}
+    bench.attach_profile(out, "w", 4e9, "0123456789abcdef", profiles_dir=str(tmp_path))                # another library: nothing is printed but the reason
+    assert out["roofline"]["traffic"] is None and "valu_issue" not in out["roofline"] and "stale" in out["roofline"]["traffic_source"]

@@ -1,52 +1,82 @@
-"""Turn gpurun_out/prof_<tag>/ (tools/profile_r.sh) into the committed profiles/ artefacts:
-   profiles/<name>_kernel_stats.csv, profiles/<name>_pmc_summary.json, profiles/<name>_render_kernel.json
-   and the profiles/latest_<workload>_render_kernel.json symlink bench.py reads `roofline.traffic` from.
-   usage: python tools/publish_profile.py <tag> <name> <workload> "<description>" """
-import csv, json, os, shutil, sys
+"""Summarise gpurun_out/prof_<round>_<tag>/ (tools/profile.sh) into summary.json there: per kernel {calls, total / average ms} from
+--kernel-trace --stats and per-kernel PMC sums PER FRAME (the bench command renders 1 counted + 1 warm-up + 3 timed frames = 5).
+`--publish` also writes profiles/<round>_<tag>{_kernel_stats.csv,_summary.json} and, for the workload's dominant timed kernel,
+profiles/<round>_<tag>_render_kernel.json -- what bench.py reads `roofline.traffic` / `valu_issue` from through the latest_<workload>
+symlink.  Every published file carries `code_id` = pbrt_v1_amd.code_id() of the library that was profiled (sha256 of its device code):
+bench.py prints the counters only when the library it has loaded has the same one.
+usage: python tools/publish_profile.py <round> <tag> [--publish]"""
+import csv, glob, json, os, shutil, sys
+from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag, name, workload, desc = sys.argv[1:5]
-src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
-summ = json.load(open(os.path.join(src, "summary.json")))
-shutil.copy(os.path.join(src, "trace", "t_kernel_stats.csv"), os.path.join(ROOT, "profiles", name + "_kernel_stats.csv"))
-json.dump(summ, open(os.path.join(ROOT, "profiles", name + "_pmc_summary.json"), "w"), indent=1)
-rows = [r for r in csv.DictReader(open(os.path.join(src, "trace", "t_kernel_stats.csv")))]
-timed = [r for r in rows if "render_kernel<false" in r["Name"]][0]          # the timed (non-counting) instantiation
-kname = timed["Name"].split("(")[0].replace("void ", "")
-def pick(sub, counter):
-    for k, d in summ.get(sub, {}).items():
-        if "render_kernel<false" in k and counter in d:
-            return d[counter]["mean"]
-    return None
-fetch, write = pick("pmc_fetch", "FETCH_SIZE"), pick("pmc_write", "WRITE_SIZE")
-sq = {c: pick("pmc_sq", c) for c in ("SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU",
-                                      "SQ_THREAD_CYCLES_VALU", "SQ_WAIT_INST_ANY", "SQ_INSTS_VMEM_RD")}
-gui, hit, miss = pick("pmc_l2", "GRBM_GUI_ACTIVE"), pick("pmc_l2", "TCC_HIT_sum"), pick("pmc_l2", "TCC_MISS_sum")
-out = {
-    "round": 1, "workload": desc, "kernel": kname,
-    "command": "rocprofv3 --kernel-trace --stats / --pmc <counters> --output-format csv -- python bench.py --steps 3 --warmup 1 "
-               "--no-cpu-baseline --workload %s (tools/profile_r.sh; FETCH_SIZE, WRITE_SIZE, SQ_*, TCC_* each in its own pass)" % workload,
-    "avg_kernel_ms_kernel_trace": round(float(timed["AverageNs"]) / 1e6, 3), "calls": int(timed["Calls"]),
-    "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
-    "hbm_bytes_per_launch_uncorrected": (fetch + write) * 1024.0 if fetch is not None and write is not None else None,
-    "hbm_bytes_per_launch_fetch_doubled": (2 * fetch + write) * 1024.0 if fetch is not None and write is not None else None,
-    "note_traffic": "MI355X_MICROARCH.md HBM section: bytes = (FETCH_SIZE + WRITE_SIZE)*1024; on gfx950 FETCH_SIZE under-reports wide "
-                    "coalesced reads by 2x (other widths uncalibrated), hence the second figure.",
-    "sq": sq, "GRBM_GUI_ACTIVE_sum_over_8_XCD": gui, "TCC_HIT_sum": hit, "TCC_MISS_sum": miss,
-}
-d = {}
-if gui and sq["SQ_ACTIVE_INST_VALU"]:
-    d["VALUBusy_percent"] = 100.0 * sq["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (gui / 8)
-    d["VALUBusy_formula"] = "gfx94x derived-metric formula: 100*SQ_ACTIVE_INST_VALU*4/(1024 SIMDs)/(GRBM_GUI_ACTIVE/8 XCDs)"
-    d["clock_GHz"] = gui / 8 / (float(timed["AverageNs"]))
-if sq["SQ_THREAD_CYCLES_VALU"] and sq["SQ_ACTIVE_INST_VALU"]:
-    d["VALUUtilization_percent_active_lanes"] = 100.0 * sq["SQ_THREAD_CYCLES_VALU"] / (sq["SQ_ACTIVE_INST_VALU"] * 64 * 4) * 4
-if hit is not None and miss is not None and hit + miss:
-    d["L2_hit_rate"] = hit / (hit + miss)
-out["derived"] = d
-fn = os.path.join(ROOT, "profiles", name + "_render_kernel.json")
-json.dump(out, open(fn, "w"), indent=1)
-link = os.path.join(ROOT, "profiles", "latest_%s_render_kernel.json" % workload)
-if os.path.lexists(link):
-    os.remove(link)
-os.symlink(os.path.basename(fn), link)
-print(json.dumps(out, indent=1))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry
+rnd, tag = sys.argv[1], sys.argv[2]
+publish = "--publish" in sys.argv[3:]
+src = os.path.join(ROOT, "gpurun_out", "prof_%s_%s" % (rnd, tag))
+wl = tag.split("_pipe")[0]
+FRAMES = 5
+code_id = entry.load_package().code_id()
+out = {"workload": wl, "round": rnd, "code_id": code_id,
+       "command": "rocprofv3 --kernel-trace --stats | --pmc <group> (one group per run) -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --workload " + wl,
+       "frames_per_run": FRAMES, "kernels": {}, "pmc_per_frame": {}}
+KERNELS = ("render_kernel", "pipe_trace", "pipe_shade", "pipe_vertex", "pipe_march", "film_slot", "film_march", "film_gather", "derive_")
+for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        n = r["Name"].split("(")[0].replace("void ", "")
+        if any(k in n for k in KERNELS):
+            out["kernels"][n] = {"calls": int(r["Calls"]), "total_ms": round(float(r["TotalDurationNs"]) / 1e6, 3), "avg_ms": round(float(r["AverageNs"]) / 1e6, 4),
+                                 "ms_per_frame_all_calls": round(float(r["TotalDurationNs"]) / 1e6 / FRAMES, 3)}
+acc = defaultdict(lambda: defaultdict(float))
+for f in glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        n = r.get("Kernel_Name", "?").split("(")[0].replace("void ", "")
+        if any(k in n for k in KERNELS):
+            acc[n][r["Counter_Name"]] += float(r["Counter_Value"])
+for n, d in acc.items():
+    timed = "<false" in n
+    film = "film_" in n                                                                       # the film gather runs once in every frame
+    out["pmc_per_frame"][n] = {c: v / (FRAMES if film else FRAMES - 1 if timed else 1) for c, v in d.items()}     # the counting twin renders one frame, the timed kernel four
+    p = out["pmc_per_frame"][n]
+    dv = {}
+    if "FETCH_SIZE" in p and "WRITE_SIZE" in p:
+        dv["fabric_bytes_lower_bound"] = (p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024
+        dv["fabric_bytes_fetch_doubled"] = (2 * p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024
+    if p.get("TCC_HIT_sum", 0) + p.get("TCC_MISS_sum", 0) > 0:
+        dv["L2_hit_rate"] = p["TCC_HIT_sum"] / (p["TCC_HIT_sum"] + p["TCC_MISS_sum"])
+        dv["L2_misses_per_frame"] = p["TCC_MISS_sum"]
+    if p.get("SQ_ACTIVE_INST_VALU") and p.get("GRBM_GUI_ACTIVE"):
+        # profiles/valu_issue_calibration.json: SQ_ACTIVE_INST_VALU counts 1 per full-rate instruction (2 per quarter-rate one), a wave64 instruction
+        # occupies its SIMD-32 for 2 cycles; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        dv["VALUBusy_percent"] = 100.0 * p["SQ_ACTIVE_INST_VALU"] * 2 / 1024 / (p["GRBM_GUI_ACTIVE"] / 8)
+    if p.get("SQ_THREAD_CYCLES_VALU") and p.get("SQ_ACTIVE_INST_VALU"):
+        dv["lanes_active_percent"] = 100.0 * p["SQ_THREAD_CYCLES_VALU"] / (p["SQ_ACTIVE_INST_VALU"] * 64)
+    if p.get("SQ_LDS_BANK_CONFLICT") and p.get("SQ_ACTIVE_INST_LDS"):
+        dv["LDS_bank_conflict_cycles_per_active_LDS_cycle"] = p["SQ_LDS_BANK_CONFLICT"] / p["SQ_ACTIVE_INST_LDS"]
+    out["pmc_per_frame"][n]["derived"] = dv
+json.dump(out, open(os.path.join(src, "summary.json"), "w"), indent=1)
+print(json.dumps(out, indent=1)[:5000])
+
+if publish:
+    prof = os.path.join(ROOT, "profiles")
+    for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
+        shutil.copy(f, os.path.join(prof, "%s_%s_kernel_stats.csv" % (rnd, tag)))
+    json.dump(out, open(os.path.join(prof, "%s_%s_summary.json" % (rnd, tag)), "w"), indent=1)
+    # dominant timed kernel = the timed (COUNT=false) kernel with the most time per frame
+    timed = {n: k for n, k in out["kernels"].items() if "<false" in n and any(x in n for x in ("render_kernel", "pipe_trace", "pipe_march"))}
+    name = max(timed, key=lambda n: timed[n]["total_ms"])
+    p = dict(out["pmc_per_frame"][name]); d = p.pop("derived")
+    frames_timed = FRAMES - 1
+    rk = {"round": rnd, "workload": wl, "kernel": name, "code_id": code_id, "command": out["command"],
+          "ms_per_frame_kernel_trace": round(timed[name]["total_ms"] / frames_timed, 3), "calls": timed[name]["calls"],
+          "FETCH_SIZE_KB": p["FETCH_SIZE"], "WRITE_SIZE_KB": p["WRITE_SIZE"],
+          "hbm_bytes_per_launch_uncorrected": d["fabric_bytes_lower_bound"], "hbm_bytes_per_launch_fetch_doubled": d["fabric_bytes_fetch_doubled"],
+          "note_traffic": "per FRAME (all launches of the kernel in one frame); MI355X_MICROARCH.md HBM section: bytes = (FETCH_SIZE + WRITE_SIZE)*1024; "
+                          "FETCH_SIZE tallies 64 B per fabric read request (profiles/r01_fetch_size_calibration.txt), hence the doubled upper bound",
+          "pmc": p,
+          "derived": {"VALUBusy_percent": d.get("VALUBusy_percent"), "VALUUtilization_percent_active_lanes": d.get("lanes_active_percent"),
+                      "L2_hit_rate": d.get("L2_hit_rate"), "L2_misses_per_frame": d.get("L2_misses_per_frame")}}
+    json.dump(rk, open(os.path.join(prof, "%s_%s_render_kernel.json" % (rnd, tag)), "w"), indent=1)
+    if tag == wl:
+        link = os.path.join(prof, "latest_%s_render_kernel.json" % wl)
+        if os.path.lexists(link): os.remove(link)
+        os.symlink("%s_%s_render_kernel.json" % (rnd, wl), link)
