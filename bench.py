@@ -58,6 +58,11 @@ def workload(name: str):
         text = scenes.cornell_scene(xres=160, yres=120, integrator="path", maxdepth=5, xsamples=2, ysamples=2, jitter=True, pixel_filter="mitchell", soup_tris=3000)
         label = "test frame: Cornell + 3000-triangle soup, path, 160x120 @ 4 spp"
         crop = (0.4, 0.6, 0.4, 0.6)
+    elif name == "t8":                  # tests/test_multirank_gpu.py: C4's kind of frame (material mix, path depth 8) at a size 8 ranks on one GPU render in seconds;
+        text = scenes.cornell_scene(xres=640, yres=426, integrator="path", maxdepth=8, xsamples=2, ysamples=2, jitter=True, pixel_filter="mitchell",   # 426 rows: not a multiple of 8
+                                    soup_tris=3000, soup_materials=True)
+        label = "test frame: Cornell + 3000-triangle soup, matte/glass/mirror mix, path depth 8, 640x426 @ 4 spp"
+        crop = (0.4, 0.6, 0.4, 0.6)
     elif name == "c1":
         text = scenes.cornell_scene(xres=512, yres=512, integrator="whitted", xsamples=1, ysamples=1, jitter=False,
                                     pixel_filter="box")
@@ -282,7 +287,8 @@ def run_workload(name, args, pkg, torch, dist, world, rank, device_index, steps,
     rays_local = cnt["closest_rays"] + cnt["any_rays"]
     if os.environ.get("PBRT_BENCH_COUNTERS"):
         print("COUNTERS " + json.dumps({k: int(v) for k, v in cnt.items()}), file=sys.stderr, flush=True)
-    k_ms_local = float(np.mean([st["trace_ms"] for st in stats]))
+    # the traversal kernels of the frame: rt::render_kernel, or the rt::pipe_trace_kernel (+ rt::pipe_march_kernel, which traces the marches' shadow rays) launches summed
+    k_ms_local = float(np.mean([st["trace_ms"] + st.get("march_ms", 0.0) for st in stats]))
     render_ms_local = float(np.mean([st["render_ms"] for st in stats]))
     tot = torch.tensor([float(rays_local), float(cnt["camera_rays"])], dtype=torch.float64, device="cuda")
     tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -327,7 +333,10 @@ def run_workload(name, args, pkg, torch, dist, world, rank, device_index, steps,
                        "rng": "counter-based keyed RNG, seed 0"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 5), "traffic": None,
-                         "kernel": ("rt::pipe_trace_kernel<COUNT=false,...> (persistent trace waves of the queue pipeline; all %d launches of a frame summed)" % stats[-1]["iterations"])
+                         "kernel": (("rt::pipe_trace_kernel<COUNT=false,...> + rt::pipe_march_kernel<COUNT=false,...> (the traversal kernels of the queue pipeline with a medium; all %d launch pairs of a frame summed: trace %.1f ms, march %.1f ms)"
+                                     % (stats[-1]["iterations"], float(np.mean([st["trace_ms"] for st in stats])), float(np.mean([st.get("march_ms", 0.0) for st in stats]))))
+                                    if stats[-1].get("march_ms", 0.0) > 0 else
+                                    "rt::pipe_trace_kernel<COUNT=false,...> (persistent trace waves of the queue pipeline; all %d launches of a frame summed)" % stats[-1]["iterations"])
                                    if pipeline else "rt::render_kernel<COUNT=false,...> (persistent megakernel)",
                          "kernel_ms": round(k_ms, 3),
                          # the same bytes over ALL kernels of the frame's render part (megakernel: the same kernel; pipeline: shade passes + trace

@@ -298,6 +298,7 @@ typedef struct RtRenderStats {
     uint32_t slots;
     float shade_ms;            /* queue pipeline: the shade launches summed */
     int32_t bands;             /* megakernel: 1 (one launch per frame); pipeline: 0 */
+    float march_ms;            /* queue pipeline with a medium: the ray-march launches summed (rt::pipe_march_kernel: the marches' shadow rays are traced inside it) */
 } RtRenderStats;
 /* ImageFilm::WriteImage's normalisation (image.cpp:157-203) of ANY 5-plane accumulator in device memory (planes of n floats each), e.g. the
  * rows of the film a rank owns after a reduce-scatter; rgb[n][3] and alpha[n] stay on the device.  Asynchronous on the scene's stream. */

@@ -34,7 +34,7 @@ HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-msse2", "-mfpmath=sse",
 
 
 HIP_UNITS = ("rt_kernels.hip", "rt_trace.hip", "rt_mega_w.hip", "rt_mega_d.hip", "rt_mega_p.hip", "rt_pipe_w.hip", "rt_pipe_d.hip",
-             "rt_pipe_p.hip", "rt_pipe_v.hip", "kd_build.cpp", "grid_build.cpp")
+             "rt_pipe_p.hip", "rt_pipe_v.hip", "rt_march.hip", "kd_build.cpp", "grid_build.cpp")
 
 
 def build(force: bool = False, verbose: bool = False, defines=(), jobs: int | None = None) -> None:
@@ -130,7 +130,7 @@ class RtPrebuiltAccel(C.Structure):
 
 class RtRenderStats(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("render_ms", C.c_float), ("trace_ms", C.c_float), ("gather_ms", C.c_float),
-                ("pipeline", C.c_int32), ("iterations", C.c_int32), ("timed_iterations", C.c_int32), ("slots", C.c_uint32), ("shade_ms", C.c_float), ("bands", C.c_int32)]
+                ("pipeline", C.c_int32), ("iterations", C.c_int32), ("timed_iterations", C.c_int32), ("slots", C.c_uint32), ("shade_ms", C.c_float), ("bands", C.c_int32), ("march_ms", C.c_float)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -436,8 +436,98 @@ RT_DEV void estimate_direct_begin(const DevScene &sc, Lane &ln, int light, float
     ln.stage = ST_ED_BSDF;
 }
 
+// ---- the volume integrators: EmissionIntegrator::Li emission.cpp:60-95 / SingleScattering::Li single.cpp:57-116 along `ray`, then
+// Scene::Li's T * Lo + Lv with the integrator's Transmittance (scene.cpp:120-126, emission.cpp:47-59).  One function for the megakernel's
+// stages (state parked in HBM between calls) and the march kernel of the queue pipeline (state in registers): same operations in the same order.
+// `begin`: start the march (ST_VOL_BEGIN); otherwise resume after the shadow ray of step m.i (ST_VOL_STEP: ln.tv holds its result).
+// Returns true with the next step's shadow ray set up (ln.has_ray, ln.pend, ln.stage = ST_VOL_STEP), false when the level is complete
+// (ln.L = T * L + Lv, ln.stage = ST_POP).  samp[(3 * a + b) * st]: the march's LatinHypercube(samp, N, 3) table (single.cpp:76-77).
+struct March { int i, N; float t0, step; V3 Tr, p, Lv; };
+// The head of the march: clip against the medium, step count and size, the scatter offset, the LatinHypercube table (3 N draws, then 3 N
+// dependent swaps through memory: run where thousands of marches start side by side -- the shade pass of the queue pipeline, or the megakernel's
+// lanes -- never inside the persistent march kernel, where one lane's table would stall its wave for ~6 N memory round trips).  N = 0: nothing to march.
+RT_DEV void march_begin(const DevScene &sc, const DevFrame &fr, Lane &ln, const Ray &ray, March &m, float RT_G *samp, size_t st) {
+    const RtVolume &vol = sc.vol;
+    const bool single = fr.volume_integrator == RT_VOLUME_SINGLE;
+    int N; float t0, t1, step; V3 p;
+    if (!vol_intersect(vol, ray.o, ray.d, ray.mint, ray.maxt, t0, t1) || (t1 - t0) == 0.f) { N = 0; step = 0.f; p = ray.o; }
+    else {
+        N = int(ceilf((t1 - t0) / fr.step_size));
+        step = (t1 - t0) / N;
+        p = ray.o + ray.d * t0;
+        t0 += dim_value(fr, ln, fr.one_d[fr.n1d - 1], 0, 0) * step;              // scatterSampleOffset
+        if (single) {                                                          // LatinHypercube(samp, N, 3), sampling.cpp:98-113
+            if (N > fr.vol_nmax) { N = fr.vol_nmax; }                           // cannot happen: vol_nmax bounds the box diagonal
+            const float delta = 1.f / N;
+            for (int a = 0; a < N; ++a) for (int b = 0; b < 3; ++b) samp[size_t(3 * a + b) * st] = (a + ln.rng.next_float()) * delta;
+            for (int b = 0; b < 3; ++b) for (int a = 0; a < N; ++a) {
+                const int other = int(ln.rng.next_u32() % uint32_t(N));
+                const float tmp = samp[size_t(3 * a + b) * st]; samp[size_t(3 * a + b) * st] = samp[size_t(3 * other + b) * st]; samp[size_t(3 * other + b) * st] = tmp;
+            }
+        }
+    }
+    m.i = 0; m.N = N; m.t0 = t0; m.step = step; m.Tr = mk3(1.f); m.p = p; m.Lv = mk3(0.f);
+}
+// The steps.  `resume`: ln.tv holds the result of the shadow ray of step m.i.  Returns true with the next step's shadow ray set up (ln.has_ray,
+// ln.pend, ln.stage = ST_VOL_STEP), false when the level is complete (ln.L = T * L + Lv, ln.stage = ST_POP).
+template <bool COUNT, bool EXT, bool DEFER>
+RT_DEV bool march_steps(const DevScene &sc, const DevFrame &fr, Lane &ln, const Ray &ray, March &m, const float RT_G *samp, size_t st, bool resume, unsigned *c_any) {
+    const RtVolume &vol = sc.vol;
+    const bool single = fr.volume_integrator == RT_VOLUME_SINGLE;
+    int i = m.i; const int N = m.N; float t0 = m.t0; const float step = m.step; V3 Tr = m.Tr, p = m.p, Lv = m.Lv;
+    const V3 w = -ray.d;
+    if (resume) {
+        if (COUNT) ++*c_any;
+        if (ln.tv.hit_prim < 0)                                                // vis.Unoccluded: Ld = L * vis.Transmittance(scene)
+            Lv = Lv + ln.pend * scene_transmittance<true>(sc, ln, ln.tv.o, ln.tv.d, ln.tv.mint, ln.tv.maxt);
+        ++i; t0 += step;
+    }
+    while (i < N) {
+        const V3 pPrev = p; p = ray.o + ray.d * t0;
+        (void)ln.rng.next_float();                                             // Tau's offset argument
+        const V3 stepT = vol_transmittance(vol, pPrev, p - pPrev, 0.f, 1.f);
+        Tr = Tr * stepT;
+        if (lum_y(Tr) < 1e-3) {
+            if (ln.rng.next_float() > .5f) break;
+            Tr = div_s(Tr, .5f);
+        }
+        const bool in = vol_inside(vol, p);
+        Lv = Lv + Tr * (in ? mat_color(vol.le) : mk3(0.f));
+        if (single) {
+            const V3 ss = in ? mat_color(vol.sigma_s) : mk3(0.f);
+            const int nLights = int(sc.n_lights);
+            if (!is_black(ss) && nLights > 0) {
+                const int lightNum = min(int(floorf(samp[size_t(3 * i) * st] * nLights)), nLights - 1);
+                const float u1 = samp[size_t(3 * i + 1) * st], u2 = samp[size_t(3 * i + 2) * st];
+                LightRef Lt = RT_LIGHT(sc, lightNum);
+                V3 wo, L, sd; float pdf, smax;
+                if (light_is_delta(Lt)) { L = delta_light_sample(Lt, p, wo, sd, smax); pdf = 1.f; }
+                else {
+                    V3 ns; V3 ps = area_sample_point<EXT>(sc, Lt, p, u1, u2, ln.rng, ns);
+                    wo = normalize3(ps - p); pdf = area_light_pdf<EXT>(sc, Lt, p, wo); L = area_L(Lt, ns, -wo);
+                    sd = ps - p; smax = 1.f - RT_RAY_EPSILON;
+                }
+                if (!is_black(L) && pdf > 0.f) {
+                    const float costheta = dot3(w, -wo);                       // PhaseHG volume.cpp:44-48
+                    const float phase = in ? 1.f / (4.f * RT_PI) * (1.f - vol.g * vol.g) / powf(1.f + vol.g * vol.g - 2.f * vol.g * costheta, 1.5f) : 0.f;
+                    ln.pend = div_s((((Tr * ss) * phase) * L) * float(nLights), pdf);
+                    m.i = i; m.t0 = t0; m.Tr = Tr; m.p = p; m.Lv = Lv;
+                    launch_ray<DEFER>(ln, sc, p, sd, RT_RAY_EPSILON, smax, true, ST_VOL_STEP);
+                    return true;
+                }
+            }
+        }
+        ++i; t0 += step;
+    }
+    Lv = Lv * step;
+    const V3 T = vol_transmittance(vol, ray.o, ray.d, ray.mint, ray.maxt);      // sample != NULL: no draw
+    ln.L = T * ln.L + Lv;
+    ln.stage = ST_POP;
+    return false;
+}
+
 // The body of ONE stage.  Returns when the lane has a ray in flight or has changed stage.
-template <bool COUNT, int INTEG, bool VOL, bool EXT, int STAGE, bool DEFER = false>
+template <bool COUNT, int INTEG, bool VOL, bool EXT, int STAGE, bool DEFER = false, bool PARK = false>
 RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigned gtid,
                        unsigned *c_closest, unsigned *c_any, unsigned *c_bad) {
     if constexpr (STAGE == ST_VERTEX) {
@@ -646,94 +736,29 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
         return;
     }
     if constexpr (VOL && (STAGE == ST_VOL_BEGIN || STAGE == ST_VOL_STEP)) {
-        // Scene::Li = T * Lo + Lv (scene.cpp:120-126): EmissionIntegrator::Li emission.cpp:60-95 /
-        // SingleScattering::Li single.cpp:57-116 along this level's ray, then its Transmittance (emission.cpp:47-59)
-        const RtVolume &vol = sc.vol;
+        // Scene::Li = T * Lo + Lv (scene.cpp:120-126): the volume integrator along this level's ray.  The march's state is parked in HBM scratch
+        // (vol_state[13][thread or slot]) while a step's shadow ray is traced (megakernel) or until rt::pipe_march_kernel picks the slot up
+        // (queue pipeline, PARK: only the head of the march runs here, the slot stays in ST_VOL_STEP without a ray = "parked")
         const Ray ray = vol_load_ray(fr, ln.fsp, gtid);
-        const bool single = fr.volume_integrator == RT_VOLUME_SINGLE;
         const size_t st = fr.n_threads;
         float RT_G *vs = RT_GPTR(float, fr.vol_state) + gtid;
         float RT_G *samp = RT_GPTR(float, fr.vol_samp) + gtid;
-        int i, N; float t0, step; V3 Tr, p, Lv;
-        const V3 w = -ray.d;
-        bool marching = true;
+        March m;
+        bool park;
         if (STAGE == ST_VOL_BEGIN) {
-            float t1;
-            if (!vol_intersect(vol, ray.o, ray.d, ray.mint, ray.maxt, t0, t1) || (t1 - t0) == 0.f) { marching = false; Lv = mk3(0.f); N = 0; i = 0; step = 0.f; Tr = mk3(1.f); p = ray.o; }
-            else {
-                N = int(ceilf((t1 - t0) / fr.step_size));
-                step = (t1 - t0) / N;
-                Tr = mk3(1.f); p = ray.o + ray.d * t0; Lv = mk3(0.f); i = 0;
-                t0 += dim_value(fr, ln, fr.one_d[fr.n1d - 1], 0, 0) * step;          // scatterSampleOffset
-                if (single) {                                                      // LatinHypercube(samp, N, 3), sampling.cpp:98-113
-                    if (N > fr.vol_nmax) { N = fr.vol_nmax; }                       // cannot happen: vol_nmax bounds the box diagonal
-                    const float delta = 1.f / N;
-                    for (int a = 0; a < N; ++a) for (int b = 0; b < 3; ++b) samp[size_t(3 * a + b) * st] = (a + ln.rng.next_float()) * delta;
-                    for (int b = 0; b < 3; ++b) for (int a = 0; a < N; ++a) {
-                        const int other = int(ln.rng.next_u32() % uint32_t(N));
-                        const float tmp = samp[size_t(3 * a + b) * st]; samp[size_t(3 * a + b) * st] = samp[size_t(3 * other + b) * st]; samp[size_t(3 * other + b) * st] = tmp;
-                    }
-                }
-            }
+            march_begin(sc, fr, ln, ray, m, samp, st);
+            if (PARK) { ln.stage = ST_VOL_STEP; park = true; }
+            else park = march_steps<COUNT, EXT, DEFER>(sc, fr, ln, ray, m, samp, st, false, c_any);
         } else {                                                                   // resume after the step's shadow ray
-            if (COUNT) ++*c_any;
-            i = __float_as_int(vs[0]); N = __float_as_int(vs[st]); t0 = vs[2 * st]; step = vs[3 * st];
-            Tr = mk3(vs[4 * st], vs[5 * st], vs[6 * st]); p = mk3(vs[7 * st], vs[8 * st], vs[9 * st]); Lv = mk3(vs[10 * st], vs[11 * st], vs[12 * st]);
-#ifdef RT_DEBUG_PIXEL
-            if (int(floorf(ln.image_x)) == fr.dbg_x && int(floorf(ln.image_y)) == fr.dbg_y)
-                printf("VOL resume w %u i %d N %d hit %d pend %g %g %g Lv %g %g %g Tr %g %g %g L %g %g %g fsp %d\n", ln.work, i, N, ln.tv.hit_prim, ln.pend.x, ln.pend.y, ln.pend.z, Lv.x, Lv.y, Lv.z, Tr.x, Tr.y, Tr.z, ln.L.x, ln.L.y, ln.L.z, ln.fsp);
-#endif
-            if (ln.tv.hit_prim < 0)                                                // vis.Unoccluded: Ld = L * vis.Transmittance(scene)
-                Lv = Lv + ln.pend * scene_transmittance<VOL>(sc, ln, ln.tv.o, ln.tv.d, ln.tv.mint, ln.tv.maxt);
-            ++i; t0 += step;
+            m.i = __float_as_int(vs[0]); m.N = __float_as_int(vs[st]); m.t0 = vs[2 * st]; m.step = vs[3 * st];
+            m.Tr = mk3(vs[4 * st], vs[5 * st], vs[6 * st]); m.p = mk3(vs[7 * st], vs[8 * st], vs[9 * st]); m.Lv = mk3(vs[10 * st], vs[11 * st], vs[12 * st]);
+            park = march_steps<COUNT, EXT, DEFER>(sc, fr, ln, ray, m, samp, st, true, c_any);
         }
-        while (marching && i < N) {
-            const V3 pPrev = p; p = ray.o + ray.d * t0;
-            (void)ln.rng.next_float();                                             // Tau's offset argument
-            const V3 stepT = vol_transmittance(vol, pPrev, p - pPrev, 0.f, 1.f);
-            Tr = Tr * stepT;
-            if (lum_y(Tr) < 1e-3) {
-                if (ln.rng.next_float() > .5f) break;
-                Tr = div_s(Tr, .5f);
-            }
-            const bool in = vol_inside(vol, p);
-            Lv = Lv + Tr * (in ? mat_color(vol.le) : mk3(0.f));
-            if (single) {
-                const V3 ss = in ? mat_color(vol.sigma_s) : mk3(0.f);
-                const int nLights = int(sc.n_lights);
-                if (!is_black(ss) && nLights > 0) {
-                    const int lightNum = min(int(floorf(samp[size_t(3 * i) * st] * nLights)), nLights - 1);
-                    const float u1 = samp[size_t(3 * i + 1) * st], u2 = samp[size_t(3 * i + 2) * st];
-                    LightRef Lt = RT_LIGHT(sc, lightNum);
-                    V3 wo, L, sd; float pdf, smax;
-                    if (light_is_delta(Lt)) { L = delta_light_sample(Lt, p, wo, sd, smax); pdf = 1.f; }
-                    else {
-                        V3 ns; V3 ps = area_sample_point<EXT>(sc, Lt, p, u1, u2, ln.rng, ns);
-                        wo = normalize3(ps - p); pdf = area_light_pdf<EXT>(sc, Lt, p, wo); L = area_L(Lt, ns, -wo);
-                        sd = ps - p; smax = 1.f - RT_RAY_EPSILON;
-                    }
-                    if (!is_black(L) && pdf > 0.f) {
-                        const float costheta = dot3(w, -wo);                       // PhaseHG volume.cpp:44-48
-                        const float phase = in ? 1.f / (4.f * RT_PI) * (1.f - vol.g * vol.g) / powf(1.f + vol.g * vol.g - 2.f * vol.g * costheta, 1.5f) : 0.f;
-                        ln.pend = div_s((((Tr * ss) * phase) * L) * float(nLights), pdf);
-                        vs[0] = __int_as_float(i); vs[st] = __int_as_float(N); vs[2 * st] = t0; vs[3 * st] = step;
-                        vs[4 * st] = Tr.x; vs[5 * st] = Tr.y; vs[6 * st] = Tr.z; vs[7 * st] = p.x; vs[8 * st] = p.y; vs[9 * st] = p.z;
-                        vs[10 * st] = Lv.x; vs[11 * st] = Lv.y; vs[12 * st] = Lv.z;
-                        launch_ray<DEFER>(ln, sc, p, sd, RT_RAY_EPSILON, smax, true, ST_VOL_STEP);
-                        return;
-                    }
-                }
-            }
-            ++i; t0 += step;
+        if (park) {
+            vs[0] = __int_as_float(m.i); vs[st] = __int_as_float(m.N); vs[2 * st] = m.t0; vs[3 * st] = m.step;
+            vs[4 * st] = m.Tr.x; vs[5 * st] = m.Tr.y; vs[6 * st] = m.Tr.z; vs[7 * st] = m.p.x; vs[8 * st] = m.p.y; vs[9 * st] = m.p.z;
+            vs[10 * st] = m.Lv.x; vs[11 * st] = m.Lv.y; vs[12 * st] = m.Lv.z;
         }
-        Lv = Lv * step;
-        const V3 T = vol_transmittance(vol, ray.o, ray.d, ray.mint, ray.maxt);      // sample != NULL: no draw
-#ifdef RT_DEBUG_PIXEL
-        if (int(floorf(ln.image_x)) == fr.dbg_x && int(floorf(ln.image_y)) == fr.dbg_y)
-            printf("VOL end w %u N %d Lv %g %g %g T %g %g %g L %g %g %g fsp %d\n", ln.work, N, Lv.x, Lv.y, Lv.z, T.x, T.y, T.z, ln.L.x, ln.L.y, ln.L.z, ln.fsp);
-#endif
-        ln.L = T * ln.L + Lv;
-        ln.stage = ST_POP;
         return;
     }
     if constexpr (STAGE == ST_POP) {
@@ -766,15 +791,17 @@ RT_DEV bool stage_in_phase(int stage, int phase) {
     const bool first = stage == ST_VERTEX || stage == ST_DIRECT_NEXT;
     return phase == 0 ? first : !first;
 }
-template <bool COUNT, int INTEG, bool VOL, bool EXT, bool DEFER = false>
+// PARK (queue pipeline with a medium): only the head of a ray march is run here (march_begin) -- the lane then sits in ST_VOL_STEP without a ray
+// and its steps are run by rt::pipe_march_kernel (rt_pipe_march.h), which hands it back in ST_POP.
+template <bool COUNT, int INTEG, bool VOL, bool EXT, bool DEFER = false, bool PARK = false>
 RT_DEV void advance_pass(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigned gtid,
                          unsigned *c_closest, unsigned *c_any, unsigned *c_bad, int phase) {
 #ifdef RT_PROFILE_STAGES
 #define RT_RUN(S) { const unsigned long long m_ = __ballot(!ln.has_ray && ln.stage == S); if (m_) { const unsigned long long t_ = __builtin_readcyclecounter(); \
-        if (!ln.has_ray && ln.stage == S) stage_body<COUNT, INTEG, VOL, EXT, S, DEFER>(sc, fr, ln, gtid, c_closest, c_any, c_bad); \
+        if (!ln.has_ray && ln.stage == S) stage_body<COUNT, INTEG, VOL, EXT, S, DEFER, PARK>(sc, fr, ln, gtid, c_closest, c_any, c_bad); \
         if (__lane_id() == 0) { atomicAdd(fr.counters + 24 + 2 * S, __builtin_readcyclecounter() - t_); atomicAdd(fr.counters + 24 + 2 * S + 1, (unsigned long long)__popcll(m_) | (1ull << 40)); } } }
 #else
-#define RT_RUN(S) if (!ln.has_ray && ln.stage == S) stage_body<COUNT, INTEG, VOL, EXT, S, DEFER>(sc, fr, ln, gtid, c_closest, c_any, c_bad)
+#define RT_RUN(S) if (!ln.has_ray && ln.stage == S) stage_body<COUNT, INTEG, VOL, EXT, S, DEFER, PARK>(sc, fr, ln, gtid, c_closest, c_any, c_bad)
 #endif
     if (phase != 0) {
         RT_RUN(ST_MIS_DONE);
@@ -789,7 +816,7 @@ RT_DEV void advance_pass(const DevScene &sc, const DevFrame &fr, Lane &ln, unsig
         if (INTEG == RT_INTEGRATOR_PATH) { RT_RUN(ST_BOUNCE); }
         else { RT_RUN(ST_SPECULAR); RT_RUN(ST_SPEC_TRANS); }
         RT_RUN(ST_RETURN);
-        if (VOL) { RT_RUN(ST_VOL_STEP); RT_RUN(ST_VOL_BEGIN); }
+        if (VOL) { if (!PARK) RT_RUN(ST_VOL_STEP); RT_RUN(ST_VOL_BEGIN); }
         RT_RUN(ST_POP);
         RT_RUN(ST_FINISH);
     }

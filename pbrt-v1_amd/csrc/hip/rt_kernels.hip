@@ -14,6 +14,7 @@
 #include "rt_render_kernel.h"
 #include "rt_pipeline.h"
 #include "rt_pipe_vertex.h"
+#include "rt_pipe_march.h"
 #include "rt_internal.h"
 #include <cstdio>
 #include <cstdlib>
@@ -568,7 +569,8 @@ static const char *knob(const char *name) {
 // (EXT: powf and the second lobe cost ~17 VGPRs, one wave per SIMD less for DirectLighting).  `variant` keeps round 1's numbering:
 // ((VOL*2 + ACCEL)*2 + COUNT)*3 + INTEG | 24 + (VOL*2 + ACCEL)*3 + INTEG | 36 + (VOL*2 + ACCEL)*3 + INTEG.
 namespace rt { extern const RenderKernelFn g_render_kernels_whitted[16], g_render_kernels_direct[16], g_render_kernels_path[16]; }
-namespace rt { extern const PipeShadeFn g_pipe_shade_whitted[6], g_pipe_shade_direct[6], g_pipe_shade_path[6]; extern const PipeTraceFn g_pipe_trace[8]; extern const PipeShadeFn g_pipe_vertex[3]; }
+namespace rt { extern const PipeShadeFn g_pipe_shade_whitted[6], g_pipe_shade_direct[6], g_pipe_shade_path[6]; extern const PipeTraceFn g_pipe_trace[8]; extern const PipeShadeFn g_pipe_vertex[3];
+               extern const PipeMarchFn g_pipe_march[6]; }
 static RenderKernelFn render_kernel_of(int variant) {
     const RenderKernelFn *t = (variant % 3 == 0) ? g_render_kernels_whitted : (variant % 3 == 1) ? g_render_kernels_direct : g_render_kernels_path;
     return t[variant < 24 ? variant / 3 : variant < 36 ? 8 + (variant - 24) / 3 : 12 + (variant - 36) / 3];
@@ -625,10 +627,10 @@ struct RtScene {
     // queue pipeline (rt_pipeline.h)
     PipePool pool{}; unsigned pool_cap = 0; int pool_vec = 0; PipePool *dev_pool = nullptr;
     unsigned *h_qcount = nullptr;                       // page-locked mirror of pool.q_count (termination test)
-    unsigned trace_grids[8] = {0};
-    std::vector<hipEvent_t> pipe_ev;                    // [2 * RT_PIPE_TIMED] around the trace launches, [.. + RT_PIPE_QN / 4] batch fences
+    unsigned trace_grids[8] = {0}, march_grids[6] = {0};
+    std::vector<hipEvent_t> pipe_ev;                    // [6 * RT_PIPE_TIMED]: per iteration, around the trace, the shade and the march launch
     std::vector<hipEvent_t> pipe_fence;
-    bool last_pipeline = false; int pipe_iters = 0, pipe_timed = 0; unsigned pipe_slots = 0;
+    bool last_pipeline = false, last_marches = false; int pipe_iters = 0, pipe_timed = 0; unsigned pipe_slots = 0;
     float4 *trace_buf = nullptr; size_t trace_cap = 0;   // rt_trace_*: rays (2 x float4) and hits, reused across calls
     int n_cus = 0;
     unsigned *trace_qc = nullptr;
@@ -671,10 +673,9 @@ template <class T> struct NoInitAlloc : std::allocator<T> {
 };
 typedef std::vector<float4, NoInitAlloc<float4>> LeafRecords;
 
-static void build_leaf_order(const std::vector<Node> &nodes, const std::vector<uint32_t> &leaf_refs, const std::vector<DevTri> &tris,
-                             std::vector<Node> &tnodes, LeafRecords &ltris) {
+// pass 1 (sequential, arithmetic only): where every leaf's run starts; returns the array's size in float4 units
+static size_t leaf_order_offsets(const std::vector<Node> &nodes, std::vector<Node> &tnodes) {
     tnodes = nodes;
-    // pass 1 (sequential, arithmetic only): where every leaf's run starts
     size_t off = 0;                                       // float4 units (16 B); a line is 8 units
     for (size_t i = 0; i < nodes.size(); ++i) {
         const Node &n = nodes[i];
@@ -684,44 +685,48 @@ static void build_leaf_order(const std::vector<Node> &nodes, const std::vector<u
         const size_t units = size_t(np) * 3;
         const size_t lines_here = (off % 8 + units + 7) / 8, lines_min = (units + 7) / 8;
         if (lines_here > lines_min) off = (off + 7) / 8 * 8;
-        tnodes[i].y = uint32_t(off);                     // (a run beyond 2^32 units is refused by the caller through ltris.size())
+        tnodes[i].y = uint32_t(off);                     // (a run beyond 2^32 units is refused by the caller)
         off += units;
     }
-    if (off >= (size_t(1) << 32)) { ltris.resize(off); return; }                   // refused by the caller (size check); contents irrelevant
-    ltris.resize(off ? off : 8);
-    if (!off) for (size_t i = 0; i < 8; ++i) ltris[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    // pass 2 (parallel over node ranges: 10 M triangles are 250 M nodes and 200 M records): copy the records
-    const unsigned hw = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
-    const size_t nthreads = nodes.size() < (size_t(1) << 20) ? 1 : hw;
-    auto fill = [&](size_t lo, size_t hi) {
-        // where the run of the last non-empty leaf before node `lo` ends: the units between it and this range's first run are alignment padding
-        size_t prev_end = 0;
-        for (size_t j = lo; j-- > 0;) {
-            const Node &m = nodes[j];
-            if ((m.x & 3u) == 3u && (m.x >> 2)) { prev_end = size_t(tnodes[j].y) + size_t(m.x >> 2) * 3; break; }
+    return off ? off : 8;
+}
+// pass 2 on the host (the reference form of rt::derive_leaf_records_kernel below: PBRT_HIP_VERIFY_DERIVED compares the two byte for byte)
+static void leaf_order_fill_host(const std::vector<Node> &nodes, const std::vector<Node> &tnodes, const std::vector<uint32_t> &leaf_refs,
+                                 const std::vector<DevTri> &tris, LeafRecords &ltris, size_t units) {
+    ltris.resize(units);
+    std::memset((void *)ltris.data(), 0, units * sizeof(float4));
+    for (size_t i = 0; i < nodes.size(); ++i) {
+        const Node &n = nodes[i];
+        if ((n.x & 3u) != 3u) continue;
+        const uint32_t np = n.x >> 2;
+        float4 *dst = ltris.data() + tnodes[i].y;
+        for (uint32_t k = 0; k < np; ++k) {
+            const uint32_t prim = np == 1 ? n.y : leaf_refs[n.y + k];
+            float4 q2 = tris[prim].q2; std::memcpy(&q2.w, &prim, 4);
+            dst[3 * k] = tris[prim].q0; dst[3 * k + 1] = tris[prim].q1; dst[3 * k + 2] = q2;
         }
-        for (size_t i = lo; i < hi; ++i) {
-            const Node &n = nodes[i];
-            if ((n.x & 3u) != 3u) continue;
-            const uint32_t np = n.x >> 2;
-            if (np == 0) continue;
-            for (size_t u = prev_end; u < size_t(tnodes[i].y); ++u) ltris[u] = make_float4(0.f, 0.f, 0.f, 0.f);    // padding before an aligned run
-            prev_end = size_t(tnodes[i].y) + size_t(np) * 3;
-            float4 *dst = ltris.data() + tnodes[i].y;
-            for (uint32_t k = 0; k < np; ++k) {
-                const uint32_t prim = np == 1 ? n.y : leaf_refs[n.y + k];
-                float4 q2 = tris[prim].q2; std::memcpy(&q2.w, &prim, 4);
-                dst[3 * k] = tris[prim].q0; dst[3 * k + 1] = tris[prim].q1; dst[3 * k + 2] = q2;
-            }
-        }
-    };
-    if (nthreads == 1) fill(0, nodes.size());
-    else {
-        std::vector<std::thread> pool;
-        for (size_t t = 0; t < nthreads; ++t) pool.emplace_back(fill, nodes.size() * t / nthreads, nodes.size() * (t + 1) / nthreads);
-        for (auto &th : pool) th.join();
     }
 }
+// pass 2 on the device (round 4): one thread per node copies its leaf's primitives out of the mesh-order records that are in HBM anyway.  The
+// 12 GB of leaf-ordered records of a 10 M-triangle scene were filled by 64 host threads (5.2 s) and uploaded (2.4 s) by every rank; now they
+// never exist on the host.  (The alignment padding between runs is zeroed by a memset before the launch.)
+namespace rt {
+__global__ void derive_leaf_records_kernel(const uint2 *__restrict__ nodes, const uint2 *__restrict__ tnodes, const unsigned *__restrict__ leaf_refs,
+                                           const DevTri *__restrict__ tris, float4 *__restrict__ ltris, size_t n_nodes) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const uint2 n = nodes[i];
+    if ((n.x & 3u) != 3u) return;
+    const unsigned np = n.x >> 2;
+    float4 *dst = ltris + tnodes[i].y;
+    for (unsigned k = 0; k < np; ++k) {
+        const unsigned prim = np == 1u ? n.y : leaf_refs[n.y + k];
+        const DevTri t = tris[prim];
+        float4 q2 = t.q2; q2.w = __uint_as_float(prim);
+        dst[3 * k] = t.q0; dst[3 * k + 1] = t.q1; dst[3 * k + 2] = q2;
+    }
+}
+}  // namespace rt
 
 // Triangle::Intersect's frame with the mesh's own uvs (trianglemesh.cpp:248-268 incl. the zero-determinant fallback through
 // CoordinateSystem, geometry.h:324-334) + DifferentialGeometry ctor (shape.cpp:43-50): geometric normal, raw dpdu
@@ -756,15 +761,16 @@ static void host_tri_frame_uv(const float *v, const float *uv, bool flip, float 
 // padding) -- and bits 30 / 31 of every word 1 that points at P say which of the two follow.  The owners are the root and, recursively,
 // the interior grandchildren of an owner; the nodes in between are "members" of their parent's block (flags 0: when a member is reached
 // through a pop it takes a one-level step).  Blocks are emitted depth-first, the below side first, so a subtree stays contiguous.
-static void build_pair_blocks(const std::vector<Node> &tn, std::vector<uint4> &pairs, uint32_t &root_x, uint32_t &root_y) {
-    pairs.clear();
-    if (tn.empty()) { root_x = 3u; root_y = 0u; pairs.push_back(make_uint4(3u, 0u, 3u, 0u)); return; }
-    root_x = tn[0].x;
-    if ((tn[0].x & 3u) == 3u) { root_y = tn[0].y; pairs.push_back(make_uint4(3u, 0u, 3u, 0u)); return; }
+// Two phases: pair_blocks_order() decides where every pair goes (a sequential depth-first walk that looks at the tree's SHAPE only, so it runs
+// beside leaf_order_offsets on another thread), pair_blocks_fill() writes the records (needs the leaves' positions in ltris; 64 threads).
+struct PairBlockOrder { std::vector<uint32_t> order, pos; std::vector<uint8_t> owner; };
+static void pair_blocks_order(const std::vector<Node> &tn, PairBlockOrder &o) {
+    o.order.clear(); o.pos.clear(); o.owner.clear();
+    if (tn.empty() || (tn[0].x & 3u) == 3u) return;
     auto interior = [&](uint32_t n) { return (tn[n].x & 3u) != 3u; };
-    std::vector<uint32_t> order; order.reserve(tn.size() / 2 + tn.size() / 8 + 4);   // parent node of each emitted pair (~0u = padding)
-    std::vector<uint32_t> pos(tn.size(), ~0u);                                // node -> index of its children's pair
-    std::vector<uint8_t> owner(tn.size(), 0);
+    std::vector<uint32_t> &order = o.order; order.reserve(tn.size() / 2 + tn.size() / 8 + 4);   // parent node of each emitted pair (~0u = padding)
+    o.pos.assign(tn.size(), ~0u);                                             // node -> index of its children's pair
+    o.owner.assign(tn.size(), 0);
     std::vector<uint32_t> todo{0u};
     while (!todo.empty()) {
         const uint32_t P = todo.back(); todo.pop_back();
@@ -772,10 +778,10 @@ static void build_pair_blocks(const std::vector<Node> &tn, std::vector<uint4> &p
         const bool bI = interior(b), aI = interior(a);
         const size_t size = 1u + (bI ? 1u : 0u) + (aI ? 1u : 0u);
         if ((order.size() % 4) + size > 4) while (order.size() % 4) order.push_back(~0u);
-        owner[P] = 1;
-        pos[P] = uint32_t(order.size()); order.push_back(P);
-        if (bI) { pos[b] = uint32_t(order.size()); order.push_back(b); }
-        if (aI) { pos[a] = uint32_t(order.size()); order.push_back(a); }
+        o.owner[P] = 1;
+        o.pos[P] = uint32_t(order.size()); order.push_back(P);
+        if (bI) { o.pos[b] = uint32_t(order.size()); order.push_back(b); }
+        if (aI) { o.pos[a] = uint32_t(order.size()); order.push_back(a); }
         // the owners below: interior children of the members; pushed so that below(below(P)) is placed next
         const uint32_t mem[2] = {a, b};
         const bool memI[2] = {aI, bI};
@@ -786,11 +792,20 @@ static void build_pair_blocks(const std::vector<Node> &tn, std::vector<uint4> &p
             if (interior(mb)) todo.push_back(mb);
         }
     }
-    if (order.size() >= (size_t(1) << 30)) { pairs.clear(); return; }
+}
+// `tn`: the nodes with a leaf's word 1 = its position in ltris (interior nodes as in the tree: same shape as pair_blocks_order saw)
+static void pair_blocks_fill(const std::vector<Node> &tn, const PairBlockOrder &o, std::vector<uint4> &pairs, uint32_t &root_x, uint32_t &root_y) {
+    pairs.clear();
+    if (tn.empty()) { root_x = 3u; root_y = 0u; pairs.push_back(make_uint4(3u, 0u, 3u, 0u)); return; }
+    root_x = tn[0].x;
+    if ((tn[0].x & 3u) == 3u) { root_y = tn[0].y; pairs.push_back(make_uint4(3u, 0u, 3u, 0u)); return; }
+    const std::vector<uint32_t> &order = o.order;
+    if (order.size() >= (size_t(1) << 30)) return;
+    auto interior = [&](uint32_t n) { return (tn[n].x & 3u) != 3u; };
     auto word1 = [&](uint32_t n) -> uint32_t {
         if (!interior(n)) return tn[n].y;                                     // leaf: position of its primitives in ltris
-        uint32_t y = pos[n];
-        if (owner[n]) y |= (interior(n + 1u) ? 1u << 30 : 0u) | (interior(tn[n].y) ? 1u << 31 : 0u);
+        uint32_t y = o.pos[n];
+        if (o.owner[n]) y |= (interior(n + 1u) ? 1u << 30 : 0u) | (interior(tn[n].y) ? 1u << 31 : 0u);
         return y;
     };
     pairs.resize(order.size());
@@ -878,7 +893,7 @@ static int render_pipeline(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, int
     }
     if (!s->pool.q_count) HIPCHK(hipMalloc((void **)&s->pool.q_count, size_t(RT_PIPE_QN) * RT_QC_STRIDE * sizeof(unsigned)));
     PipePool pl = s->pool;
-    pl.n_slots = n_slots; pl.ray_d = pl.ray_o + n_slots; pl.q_d = pl.q_o + size_t(2) * n_slots;
+    pl.n_slots = n_slots; pl.ray_d = pl.ray_o + n_slots; pl.q_d = pl.q_o + size_t(2) * n_slots; pl.q_march = pl.q_slot + size_t(2) * n_slots;
     if (by_vertex) pl.ray_d = pl.q_o;                                       // directions [3][n_slots] (the compacted ray copies are not used)
     // per-slot scratch of the state machine: recursion frames (whitted / directlighting), volume march state
     if (integ != RT_INTEGRATOR_PATH) {
@@ -891,7 +906,7 @@ static int render_pipeline(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, int
     }
     fr.frames = s->frames; fr.n_threads = n_slots;
     if (s->pipe_ev.empty()) {
-        s->pipe_ev.resize(4 * RT_PIPE_TIMED); s->pipe_fence.resize(RT_PIPE_QN / RT_PIPE_BATCH);
+        s->pipe_ev.resize(6 * RT_PIPE_TIMED); s->pipe_fence.resize(RT_PIPE_QN / RT_PIPE_BATCH);
         for (auto &e : s->pipe_ev) HIPCHK(hipEventCreate(&e));
         for (auto &e : s->pipe_fence) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
@@ -901,6 +916,10 @@ static int render_pipeline(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, int
     const int tk = (s->accel_kind == RT_ACCEL_GRID ? 4 : 0) + (s->counting ? (s->has_ext ? 1 : 3) : (s->has_ext ? 2 : 0));
     const PipeTraceFn trace = g_pipe_trace[tk];
     const unsigned trace_grid = s->trace_grids[tk];
+    // frames with a medium: the march kernel (rt_pipe_march.h) runs the ray marches the shade pass parked
+    const bool marches = s->volume.present;
+    const int mk = (s->accel_kind == RT_ACCEL_GRID ? 3 : 0) + f;
+    const unsigned march_grid = s->march_grids[mk];
     HIPCHK(hipMemcpyAsync(s->dev_frame, &fr, sizeof(DevFrame), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemcpyAsync(s->dev_pool, &pl, sizeof(PipePool), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemsetAsync(s->work_counter, 0, sizeof(unsigned long long), s->stream));
@@ -915,18 +934,27 @@ static int render_pipeline(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, int
             const unsigned qi = unsigned(iter % RT_PIPE_QN);
             PipeLaunch pk{}; pk.qi = qi; pk.slot_base = 0; pk.q_base = 0;
             HIPCHK(hipMemsetAsync(pl.q_count + size_t(RT_QC_STRIDE) * qi, 0, RT_QC_STRIDE * sizeof(unsigned), s->stream));
-            if (iter < RT_PIPE_TIMED) HIPCHK(hipEventRecord(s->pipe_ev[4 * iter + 2], s->stream));
+            if (iter < RT_PIPE_TIMED) HIPCHK(hipEventRecord(s->pipe_ev[6 * iter + 2], s->stream));
             hipLaunchKernelGGL(shade, dim3(n_slots / RT_BLOCK), dim3(RT_BLOCK), 0, s->stream, (const DevScene *)s->dev_scene,
                                (const DevFrame *)s->dev_frame, (const PipePool *)s->dev_pool, pk);
-            if (iter < RT_PIPE_TIMED) HIPCHK(hipEventRecord(s->pipe_ev[4 * iter + 3], s->stream));
+            if (iter < RT_PIPE_TIMED) HIPCHK(hipEventRecord(s->pipe_ev[6 * iter + 3], s->stream));
             TraceJob job{};
             job.q_o = pl.q_o; job.q_d = pl.q_d; job.q_slot = pl.q_slot; job.q_count = pl.q_count + size_t(RT_QC_STRIDE) * qi; job.hit = pl.hit;
             job.n_slots = n_slots; job.q_base = pk.q_base; job.spill = s->spill; job.n_threads = s->n_threads; job.counters = s->counters;
             if (by_vertex) { job.by_slot = 1; job.q_o = pl.ray_o; job.q_d = pl.ray_d; }
-            if (iter < RT_PIPE_TIMED) HIPCHK(hipEventRecord(s->pipe_ev[4 * iter], s->stream));
+            if (iter < RT_PIPE_TIMED) HIPCHK(hipEventRecord(s->pipe_ev[6 * iter], s->stream));
             hipLaunchKernelGGL(trace, dim3(trace_grid), dim3(RT_BLOCK), 0, s->stream, (const DevScene *)s->dev_scene, job);
-            if (iter < RT_PIPE_TIMED) HIPCHK(hipEventRecord(s->pipe_ev[4 * iter + 1], s->stream));
-            HIPCHK(hipMemcpyAsync(s->h_qcount + size_t(RT_QC_STRIDE) * qi, pl.q_count + size_t(RT_QC_STRIDE) * qi, (RT_QC_ANY + 1) * sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
+            if (iter < RT_PIPE_TIMED) HIPCHK(hipEventRecord(s->pipe_ev[6 * iter + 1], s->stream));
+            if (marches) {
+                MarchJob mj{};
+                mj.q_march = pl.q_march; mj.q_count = pl.q_count + size_t(RT_QC_STRIDE) * qi;
+                mj.spill = s->spill; mj.n_threads = s->n_threads; mj.counters = s->counters;
+                if (iter < RT_PIPE_TIMED) HIPCHK(hipEventRecord(s->pipe_ev[6 * iter + 4], s->stream));
+                hipLaunchKernelGGL(g_pipe_march[mk], dim3(march_grid), dim3(RT_BLOCK), 0, s->stream, (const DevScene *)s->dev_scene, (const DevFrame *)s->dev_frame,
+                                   (const PipePool *)s->dev_pool, mj);
+                if (iter < RT_PIPE_TIMED) HIPCHK(hipEventRecord(s->pipe_ev[6 * iter + 5], s->stream));
+            }
+            HIPCHK(hipMemcpyAsync(s->h_qcount + size_t(RT_QC_STRIDE) * qi, pl.q_count + size_t(RT_QC_STRIDE) * qi, (RT_QC_MARCH + 1) * sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(s->pipe_fence[batch % (RT_PIPE_QN / RT_PIPE_BATCH)], s->stream));
@@ -934,12 +962,13 @@ static int render_pipeline(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, int
             HIPCHK(hipEventSynchronize(s->pipe_fence[(batch - 1) % (RT_PIPE_QN / RT_PIPE_BATCH)]));
             for (int k = 0; k < RT_PIPE_BATCH; ++k, ++checked) {
                 const unsigned *q = s->h_qcount + size_t(RT_QC_STRIDE) * (checked % RT_PIPE_QN);
-                if (q[0] + q[RT_QC_ANY] == 0) { done = true; break; }
+                if (q[0] + q[RT_QC_ANY] + q[RT_QC_MARCH] == 0) { done = true; break; }
             }
         }
         ++batch;
         if (iter > max_iters) return fail(RT_ESTATE, "rt_render: the queue pipeline did not terminate");
     }
+    s->last_marches = marches;
     s->pipe_slots = n_slots; s->pipe_iters = checked + 1; s->pipe_timed = std::min(s->pipe_iters, RT_PIPE_TIMED);
     HIPCHK(hipEventRecord(s->ev1, s->stream));
     s->last_pipeline = true;
@@ -1145,38 +1174,60 @@ static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel 
         if ((rc = upload(s, dq.data(), dq.size(), &s->dev.quadrics))) return rc;
     }
     tick("triangle / shading records");
+    // nodes (+ one node of padding: the traversal may fetch node i+1 together with node i) and the leaf lists
+    auto upload_nodes = [&](const std::vector<Node> &v, const uint2 **dev) -> int {
+        void *p = nullptr;
+        HIPCHK(hipMalloc(&p, (v.size() + 1) * sizeof(uint2)));
+        s->allocs.push_back(p);
+        if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(uint2), hipMemcpyHostToDevice));
+        const uint2 pad = make_uint2(3u, 0u);
+        HIPCHK(hipMemcpy((uint2 *)p + v.size(), &pad, sizeof pad, hipMemcpyHostToDevice));
+        *dev = (const uint2 *)p;
+        return RT_OK;
+    };
     const uint2 *nodes_dev = nullptr;
-    {   // one node of padding: the traversal may fetch node i+1 together with node i
-        std::vector<uint2> padded(s->tree.nodes.size() + 1);
-        std::memcpy(padded.data(), s->tree.nodes.data(), s->tree.nodes.size() * sizeof(uint2));
-        padded.back() = make_uint2(3u, 0u);
-        if ((rc = upload(s, padded.data(), padded.size(), &nodes_dev))) return rc;
-    }
+    if ((rc = upload_nodes(s->tree.nodes, &nodes_dev))) return rc;
+    if ((rc = upload(s, s->tree.leaf_refs.data(), s->tree.leaf_refs.size(), &s->dev.leaf_refs))) return rc;
     s->dev.nodes = nodes_dev;
     s->dev.tnodes = nodes_dev;
     if (s->accel_kind == RT_ACCEL_KDTREE) {
-        std::vector<Node> tn; LeafRecords lt;
-        tick("node upload");
-        build_leaf_order(s->tree.nodes, s->tree.leaf_refs, tris, tn, lt);
-        tick("leaf-ordered records");
-        if (lt.size() >= (size_t(1) << 32)) return fail(RT_EINVAL, "rt_scene_create: leaf-ordered triangle array beyond 2^32 float4 units");
-        tn.push_back(Node{3u, 0u});
-        const Node *tdev = nullptr;
-        if ((rc = upload(s, tn.data(), tn.size(), &tdev))) return rc;
-        s->dev.tnodes = reinterpret_cast<const uint2 *>(tdev);
-        if ((rc = upload(s, lt.data(), lt.size(), &s->dev.ltris))) return rc;
-        s->n_leaf_tri_units = lt.size();
-        tn.pop_back();
+        std::vector<Node> tn;
+        tick("node / leaf-list upload");
+        PairBlockOrder pbo;
+        std::thread order_thread([&] { pair_blocks_order(s->tree.nodes, pbo); });      // beside the offsets pass and the uploads below
+        struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{order_thread};
+        const size_t units = leaf_order_offsets(s->tree.nodes, tn);
+        tick("leaf-order offsets");
+        if (units >= (size_t(1) << 32)) return fail(RT_EINVAL, "rt_scene_create: leaf-ordered triangle array beyond 2^32 float4 units");
+        if ((rc = upload_nodes(tn, &s->dev.tnodes))) return rc;
+        {
+            void *p = nullptr;
+            HIPCHK(hipMalloc(&p, units * sizeof(float4)));
+            s->allocs.push_back(p);
+            s->dev.ltris = (const float4 *)p;
+            HIPCHK(hipMemsetAsync(p, 0, units * sizeof(float4), s->stream));
+            const size_t nn = s->tree.nodes.size();
+            if (nn) hipLaunchKernelGGL(derive_leaf_records_kernel, dim3(unsigned((nn + 255) / 256)), dim3(256), 0, s->stream, s->dev.nodes, s->dev.tnodes,
+                                       s->dev.leaf_refs, (const DevTri *)s->dev.tris, (float4 *)p, nn);
+            HIPCHK(hipGetLastError());
+            if (knob("PBRT_HIP_VERIFY_DERIVED")) {             // tests: the device fill against the host fill, byte for byte
+                LeafRecords lt; leaf_order_fill_host(s->tree.nodes, tn, s->tree.leaf_refs, tris, lt, units);
+                std::vector<float4> back(units);
+                HIPCHK(hipStreamSynchronize(s->stream));
+                HIPCHK(hipMemcpy(back.data(), p, units * sizeof(float4), hipMemcpyDeviceToHost));
+                if (std::memcmp(back.data(), lt.data(), units * sizeof(float4)) != 0) return fail(RT_ESTATE, "rt_scene_create: the device-built leaf-ordered records differ from the host fill");
+            }
+        }
+        s->n_leaf_tri_units = units;
+        tick("leaf-ordered records (device)");
         std::vector<uint4> pairs;
-        tick("leaf-order upload");
-        build_pair_blocks(tn, pairs, s->dev.root_x, s->dev.root_y);
+        order_thread.join();
+        pair_blocks_fill(tn, pbo, pairs, s->dev.root_x, s->dev.root_y);
         if (pairs.empty() || pairs.size() >= (size_t(1) << 30)) return fail(RT_EINVAL, "rt_scene_create: pair records beyond 2^30");
         tick("pair blocks");
         if ((rc = upload(s, pairs.data(), pairs.size(), &s->dev.tpairs))) return rc;
         tick("pair upload");
     }
-    if ((rc = upload(s, s->tree.leaf_refs.data(), s->tree.leaf_refs.size(), &s->dev.leaf_refs))) return rc;
-
     // materials (OrenNayar constants: reflection.h:268-277)
     std::vector<DevMaterial> mats(d->n_materials);
     for (uint32_t i = 0; i < d->n_materials; ++i) {
@@ -1277,6 +1328,12 @@ static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel 
         if (const char *e = knob("PBRT_HIP_TRACE_BLOCKS_PER_CU")) per_cu = std::min(per_cu, std::max(1, std::atoi(e)));   // occupancy experiments
         s->trace_grids[k] = unsigned(prop.multiProcessorCount) * unsigned(per_cu < 1 ? 1 : per_cu);
         if (s->trace_grids[k] * RT_BLOCK > s->n_threads) s->n_threads = s->trace_grids[k] * RT_BLOCK;      // the spill area is shared
+    }
+    for (int k = 0; k < 6; ++k) {
+        int per_cu = 0;
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)g_pipe_march[k], RT_BLOCK, 0));
+        s->march_grids[k] = unsigned(prop.multiProcessorCount) * unsigned(per_cu < 1 ? 1 : per_cu);
+        if (s->march_grids[k] * RT_BLOCK > s->n_threads) s->n_threads = s->march_grids[k] * RT_BLOCK;
     }
     HIPCHK(hipMalloc((void **)&s->spill, size_t(s->spill_depth) * s->n_threads * sizeof(uint4)));     // uint4 entries in the pair form, uint2 otherwise
     HIPCHK(hipMalloc((void **)&s->dev_pool, sizeof(PipePool)));
@@ -1839,12 +1896,13 @@ int rt_last_render_stats(RtScene *s, RtRenderStats *out) {
     if (s->last_pipeline) {
         out->iterations = s->pipe_iters; out->timed_iterations = s->pipe_timed;
         float sum = 0.f;
-        float sum2 = 0.f;
+        float sum2 = 0.f, sum3 = 0.f;
         for (int i = 0; i < s->pipe_timed; ++i) {
-            float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, s->pipe_ev[4 * i], s->pipe_ev[4 * i + 1])); sum += ms;
-            HIPCHK(hipEventElapsedTime(&ms, s->pipe_ev[4 * i + 2], s->pipe_ev[4 * i + 3])); sum2 += ms;
+            float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, s->pipe_ev[6 * i], s->pipe_ev[6 * i + 1])); sum += ms;
+            HIPCHK(hipEventElapsedTime(&ms, s->pipe_ev[6 * i + 2], s->pipe_ev[6 * i + 3])); sum2 += ms;
+            if (s->last_marches) { HIPCHK(hipEventElapsedTime(&ms, s->pipe_ev[6 * i + 4], s->pipe_ev[6 * i + 5])); sum3 += ms; }
         }
-        out->trace_ms = sum; out->shade_ms = sum2;
+        out->trace_ms = sum; out->shade_ms = sum2; out->march_ms = sum3;
         out->slots = s->pipe_slots;
     } else out->trace_ms = out->render_ms;
     out->bands = s->last_pipeline ? 0 : 1;

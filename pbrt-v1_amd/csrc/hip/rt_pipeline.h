@@ -52,6 +52,7 @@ struct PipePool {
     float4 *hit;                  // [n_slots] {prim, t, b1, b2} written by the trace kernel
     float4 *q_o, *q_d;            // [2][n_slots] compacted queues: closest-hit rays in [0, n), any-hit rays in [n_slots, n_slots + m)
     unsigned *q_slot;             // [2][n_slots] slot of each queued ray
+    unsigned *q_march;            // [n_slots] frames with a medium: the slots parked in ST_VOL_STEP, whose ray march rt::pipe_march_kernel runs
     unsigned *q_count;            // [iterations][RT_QC_STRIDE]: n closest at +0, consumer head at +RT_QC_HEAD, n any at +RT_QC_ANY
                                   // (three different 64-byte lines: each is the target of one kernel's atomics)
     unsigned long long *wave_work; // [n_slots / 64][2] {next, end}: the chunk of camera samples a wave of the shade kernel owns
@@ -66,6 +67,8 @@ struct PipeLaunch {
 #define RT_QC_STRIDE 64
 #define RT_QC_HEAD 16
 #define RT_QC_ANY 32
+#define RT_QC_MARCH 48            // number of parked marches of the iteration, the march kernel's consumer head behind it
+#define RT_QC_MHEAD 56
 #define RT_WORK_CHUNK 128         // camera samples a shade wave takes from the global work counter at a time
 
 // ---- slot state <-> Lane ----------------------------------------------------------------------------------------
@@ -86,11 +89,10 @@ RT_DEV void pipe_load(const PipePool &pl, const DevFrame &fr, unsigned slot, Lan
         ln.L = mk3(0.f); ln.thr = mk3(1.f);
         return;
     }
-    if (ln.stage == ST_VOL_STEP) {                               // a ray march waiting for a step's shadow ray: the surface vertex is dead (the march
-        const float4 a2 = st[2 * n], a8 = st[8 * n], a9 = st[9 * n];   // state lives in fr.vol_state); only L, the pending contribution and the ids are live
+    if (ln.stage == ST_POP) {                                  // back from rt::pipe_march_kernel: Scene::Li of this level is complete in L; everything else the
+        const float4 a2 = st[2 * n];                           // slot needs from here on is in the control planes (fsp == 0) or in its recursion frame (frame_pop)
         ln.L = mk3(a2.x, a2.y, a2.z);
         { const unsigned ml = __float_as_uint(a2.w); ln.v.mat = int(ml & 0xffffu); ln.v.light = int(ml >> 16) - 1; }
-        ln.pend = mk3(a8.w, a9.x, a9.y);
         ln.thr = mk3(1.f);
         return;
     }
@@ -122,14 +124,12 @@ RT_DEV void pipe_store(const PipePool &pl, unsigned slot, const Lane &ln) {
     st[n] = make_float4(__uint_as_float(ln.dim_base), __uint_as_float(ln.rng.ctr), __uint_as_float(ctl), ln.alpha);
     if (ln.stage == ST_EXIT) return;
     st[2 * n] = make_float4(ln.L.x, ln.L.y, ln.L.z, __uint_as_float(unsigned(ln.v.mat) | (unsigned(ln.v.light + 1) << 16)));
-    const bool slim = ln.stage == ST_VOL_STEP;                // see pipe_load: a slot waiting inside a ray march stores only what the march needs
-    if (!slim) st[3 * n] = make_float4(ln.thr.x, ln.thr.y, ln.thr.z, __uint_as_float(unsigned(ln.li) | (unsigned(ln.lj) << 16)));
-    if (!slim) {
+    if (ln.stage == ST_VOL_STEP) return;                       // parked for the march kernel: the surface vertex is dead (see pipe_load)
+    st[3 * n] = make_float4(ln.thr.x, ln.thr.y, ln.thr.z, __uint_as_float(unsigned(ln.li) | (unsigned(ln.lj) << 16)));
     st[4 * n] = make_float4(ln.v.p.x, ln.v.p.y, ln.v.p.z, __int_as_float(ln.cur_light));
     st[5 * n] = make_float4(ln.v.nn.x, ln.v.nn.y, ln.v.nn.z, ln.bs1);
     st[6 * n] = make_float4(ln.v.sn.x, ln.v.sn.y, ln.v.sn.z, ln.bs2);
     st[7 * n] = make_float4(ln.v.wo.x, ln.v.wo.y, ln.v.wo.z, ln.bcs);
-    }
     st[8 * n] = make_float4(ln.Ld.x, ln.Ld.y, ln.Ld.z, ln.pend.x);
     if (INTEG == RT_INTEGRATOR_DIRECT) {
         st[9 * n] = make_float4(ln.pend.y, ln.pend.z, ln.Ld_light.x, ln.Ld_light.y);
@@ -139,11 +139,8 @@ RT_DEV void pipe_store(const PipePool &pl, unsigned slot, const Lane &ln) {
 }
 
 // ---- shade: everything between two rays of a path, for every slot ---------------------------------------------------
-#ifndef RT_SHADE_VOL_WAVES
-#define RT_SHADE_VOL_WAVES 3      // waves per SIMD the shade kernels of a frame with a medium are held to (they allocate ~195 VGPRs on their own = 2 waves; a pass is a chain of dependent loads, so the third wave pays: C5 353 -> 328 ms; 4 spills: 388)
-#endif
 template <bool COUNT, int INTEG, bool VOL, bool EXT>
-__global__ __launch_bounds__(RT_BLOCK, (VOL && !COUNT) ? RT_SHADE_VOL_WAVES : 1) void pipe_shade_kernel(const DevScene *__restrict__ scp, const DevFrame *__restrict__ frp,
+__global__ __launch_bounds__(RT_BLOCK, 1) void pipe_shade_kernel(const DevScene *__restrict__ scp, const DevFrame *__restrict__ frp,
                                                                const PipePool *__restrict__ plp, PipeLaunch pk) {
     const DevScene &sc = *scp;
     const DevFrame &fr = *frp;
@@ -155,8 +152,8 @@ __global__ __launch_bounds__(RT_BLOCK, (VOL && !COUNT) ? RT_SHADE_VOL_WAVES : 1)
     ln.li = ln.lj = 0; ln.cur_light = 0; ln.Ld = ln.Ld_light = ln.L_all = ln.pend = mk3(0.f); ln.bs1 = ln.bs2 = ln.bcs = 0.f;
     pipe_load<INTEG, EXT>(pl, fr, slot, ln);
     if (!__syncthreads_or(ln.stage != ST_EXIT)) return;
-    __shared__ unsigned blk_cnt[2], blk_base[2];
-    if (threadIdx.x < 2) blk_cnt[threadIdx.x] = 0u;
+    __shared__ unsigned blk_cnt[3], blk_base[3];
+    if (threadIdx.x < 3) blk_cnt[threadIdx.x] = 0u;
     // this wave's chunk of the work list (wave-uniform): 64 K waves hammering ONE counter cost more than the shading itself
     // (measured: 1.1 ms per pass, ~0.15 ms of it arithmetic); a wave now goes to the global counter once per RT_WORK_CHUNK samples
     unsigned long long RT_G *ww = RT_GPTR(unsigned long long, pl.wave_work) + size_t(slot >> 6) * 2;
@@ -172,7 +169,7 @@ __global__ __launch_bounds__(RT_BLOCK, (VOL && !COUNT) ? RT_SHADE_VOL_WAVES : 1)
     }
     unsigned c_cam = 0, c_closest = 0, c_any = 0, c_bad = 0;
     do {
-        advance_pass<COUNT, INTEG, VOL, EXT, true>(sc, fr, ln, slot, &c_closest, &c_any, &c_bad, -1);
+        advance_pass<COUNT, INTEG, VOL, EXT, true, true>(sc, fr, ln, slot, &c_closest, &c_any, &c_bad, -1);
         const unsigned long long want = __ballot(!ln.has_ray && ln.stage == ST_FETCH);
         if (want) {                                                     // work fetch from the wave's chunk
             const unsigned n_want = unsigned(__popcll(want));
@@ -203,24 +200,30 @@ __global__ __launch_bounds__(RT_BLOCK, (VOL && !COUNT) ? RT_SHADE_VOL_WAVES : 1)
             if (have < n_want) { w_next = fresh + (n_want - have); w_end = fresh + RT_WORK_CHUNK; }
             else w_next += n_want;
         }
-    } while (__any(!ln.has_ray && ln.stage != ST_EXIT));
+    } while (__any(!ln.has_ray && ln.stage != ST_EXIT && !(VOL && ln.stage == ST_VOL_STEP)));      // (a slot in ST_VOL_STEP without a ray is parked for the march kernel)
     if (lane == 0) { ww[0] = w_next; ww[1] = w_end; }
     // ---- enqueue: ballot compaction per ray kind inside the wave, LDS atomics inside the workgroup, ONE global atomic per
     // workgroup and kind (the two counters sit on different cache lines)
     {
         unsigned RT_G *qc = RT_GPTR(unsigned, pl.q_count) + size_t(pk.qi) * RT_QC_STRIDE;
         const unsigned long long mc = __ballot(ln.has_ray && !ln.tv.any), ma = __ballot(ln.has_ray && ln.tv.any);
-        unsigned wc = 0, wa = 0;
+        const bool parked = VOL && !ln.has_ray && ln.stage == ST_VOL_STEP;
+        const unsigned long long mm = __ballot(parked);
+        unsigned wc = 0, wa = 0, wm = 0;
         __syncthreads();                                                // blk_cnt zeroed
         if (lane == 0) {
             if (mc) wc = atomicAdd(&blk_cnt[0], unsigned(__popcll(mc)));
             if (ma) wa = atomicAdd(&blk_cnt[1], unsigned(__popcll(ma)));
+            if (VOL && mm) wm = atomicAdd(&blk_cnt[2], unsigned(__popcll(mm)));
         }
         __syncthreads();
         if (threadIdx.x == 0 && blk_cnt[0]) blk_base[0] = atomicAdd((unsigned *)qc, blk_cnt[0]);
         if (threadIdx.x == 64 && blk_cnt[1]) blk_base[1] = atomicAdd((unsigned *)(qc + RT_QC_ANY), blk_cnt[1]);
+        if (VOL && threadIdx.x == 128 && blk_cnt[2]) blk_base[2] = atomicAdd((unsigned *)(qc + RT_QC_MARCH), blk_cnt[2]);
         __syncthreads();
         wc = __shfl(wc, 0) + blk_base[0]; wa = __shfl(wa, 0) + blk_base[1];
+        const unsigned wm0 = VOL ? __shfl(wm, 0) + blk_base[2] : 0u;
+        if (VOL && parked) RT_GPTR(unsigned, pl.q_march)[size_t(pk.q_base) + wm0 + __popcll(mm & ((1ull << lane) - 1ull))] = slot;
         if (ln.has_ray) {
             const unsigned long long below = (1ull << lane) - 1ull;
             const size_t q = size_t(pk.q_base) + (ln.tv.any ? size_t(pl.n_slots) + wa + __popcll(ma & below) : size_t(wc) + __popcll(mc & below));

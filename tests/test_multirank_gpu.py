@@ -108,3 +108,27 @@ def test_prebuilt_accelerator_gives_the_same_scene(pkg, scenes, tmp_path):
         nanb = dup(info); nanb.bounds[4] = float("inf")
         with pytest.raises(pkg.RtError, match="bounds"):
             pkg.DeviceScene(ps, prebuilt=(nodes, refs, nanb))
+
+
+def test_eight_ranks_on_one_gpu_rehearsal(pkg, tmp_path):
+    """The shape of the driver's 8-GPU run, rehearsed on the one GPU this box has: 8 ranks launched by torch.distributed.run
+    share GPU 0 over gloo; local rank 0 builds the accelerator and publishes it under /dev/shm, the other seven attach it
+    (rt_scene_create_prebuilt); 2-D tiles dealt round-robin; row-wise reduce-scatter with a film height that is NOT a multiple of the world
+    size (426 rows: 54 per rank, the last rank's padded), per-rank resolve, all-gather.  The frame is the single-rank frame, every camera
+    sample is rendered exactly once, and the tiles balance the ranks: max / mean of the per-rank ray counts <= 1.05."""
+    if pkg.device_count() < 1:
+        pytest.fail("no HIP device visible")
+    env = dict(os.environ, PBRT_BENCH_BACKEND="gloo", PBRT_BENCH_SAME_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one, eight = str(tmp_path / "one.npz"), str(tmp_path / "eight.npz")
+    base = ["--steps", "1", "--warmup", "0", "--workload", "t8", "--no-cpu-baseline", "--no-extra", "--tile-2d", "16", "--merge", "reduce_scatter"]
+    j1 = _bench(["--gpus", "1", "--dump-film", one] + base, env)
+    j8 = _bench(["--gpus", "8", "--dump-film", eight] + base, env, nproc=8, timeout=1500)
+    assert j8["n_gpus"] == 8 and len(j8["per_rank"]) == 8
+    assert j8["config"]["camera_samples_per_frame"] == j1["config"]["camera_samples_per_frame"] == 644 * 430 * 4      # mitchell 2 x 2: the sample extent reaches 2 pixels beyond the film
+    assert abs(j8["config"]["rays_per_frame"] - j1["config"]["rays_per_frame"]) <= 2e-4 * j1["config"]["rays_per_frame"] + 8
+    rays = np.array([r["rays"] for r in j8["per_rank"]], np.float64)
+    assert rays.min() > 0 and rays.max() / rays.mean() <= 1.05, rays
+    a, b = np.load(one), np.load(eight)
+    assert a["rgb"].shape == (426, 640, 3)
+    assert np.allclose(a["rgb"], b["rgb"], rtol=2e-5, atol=2e-6) and np.allclose(a["alpha"], b["alpha"], rtol=2e-5, atol=2e-6)
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("pbrt_hip_accel_")]
