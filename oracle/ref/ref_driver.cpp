@@ -166,6 +166,150 @@ static bool BuiltinCornell(const string &kind, int res, bool keyed) {
     return true;
 }
 
+// ---- grammar scenes: the statements of tests/golden/make_api_fixtures.py's scene texts issued as hand-written pbrt* calls (no scene text, no tokenizer,
+// no ParamList in this run).  Each text exercises one corner of the scene language (pbrtlex.l / pbrtparse.y:294-574) that the product's own parser
+// must get right; the fixture is the film of THIS run, so the product's tokenizer is checked against something it did not take part in.
+static void fv(ParamSet &ps, const char *n, std::initializer_list<float> v) { vector<float> a(v); ps.AddFloat(n, a.data(), int(a.size())); }
+static void iv(ParamSet &ps, const char *n, std::initializer_list<int> v) { vector<int> a(v); ps.AddInt(n, a.data(), int(a.size())); }
+static void pv(ParamSet &ps, const char *n, std::initializer_list<float> v) { vector<float> a(v); ps.AddPoint(n, (const Point *)a.data(), int(a.size() / 3)); }
+static void one_bool(ParamSet &ps, const char *n, bool v) { ps.AddBool(n, &v, 1); }
+static void g_sampler(bool keyed, const char *inner, int xs, int ys, bool jitter, int pixelsamples) {
+    ParamSet ps;
+    if (keyed) { one_string(ps, "inner", inner); one_int(ps, "seed", 0); }
+    if (string(inner) == "lowdiscrepancy") one_int(ps, "pixelsamples", pixelsamples);
+    else { one_int(ps, "xsamples", xs); one_int(ps, "ysamples", ys); one_bool(ps, "jitter", jitter); }
+    pbrtSampler(keyed ? "keyed" : inner, ps);
+}
+static void g_accel() { ParamSet ps; one_string(ps, "inner", "kdtree"); pbrtAccelerator("countaccel", ps); }
+static void g_film(int xr, int yr) { ParamSet ps; one_int(ps, "xresolution", xr); one_int(ps, "yresolution", yr); one_string(ps, "filename", "out.exr"); pbrtFilm("image", ps); }
+static void g_point_light(float x, float y, float z, float i) { ParamSet ps; pv(ps, "from", {x, y, z}); one_color(ps, "I", i, i, i); pbrtLightSource("point", ps); }
+static void g_quad_shape() { ParamSet ps; iv(ps, "indices", {0, 1, 2, 0, 2, 3}); pv(ps, "P", {-1, -1, 0, 1, -1, 0, 1, 1, 0, -1, 1, 0}); pbrtShape("trianglemesh", ps); }
+static void g_matte(float r, float g, float b) { ParamSet ps; one_color(ps, "Kd", r, g, b); pbrtMaterial("matte", ps); }
+static bool BuiltinGrammar(const string &kind, bool keyed) {
+    if (kind == "g1") {                  // transform stack, named coordinate systems, ReverseOrientation, attribute inheritance
+        pbrtLookAt(0, 0, -6, 0, 0, 0, 0, 1, 0);
+        { ParamSet ps; one_float(ps, "fov", 40); pbrtCamera("perspective", ps); }
+        g_film(32, 32); g_sampler(keyed, "stratified", 1, 1, false, 0);
+        { ParamSet ps; pbrtPixelFilter("box", ps); }
+        { ParamSet ps; one_int(ps, "maxdepth", 3); pbrtSurfaceIntegrator("whitted", ps); }
+        g_accel();
+        pbrtWorldBegin();
+        g_point_light(0, 4, -4, 60);
+        pbrtCoordinateSystem("base");
+        pbrtTransformBegin();
+        pbrtTranslate(-1, 0.25f, 0); pbrtRotate(30, 0, 1, 0); pbrtScale(0.8f, 1.2f, 1);
+        pbrtAttributeBegin(); g_matte(.8f, .2f, .2f); g_quad_shape(); pbrtAttributeEnd();
+        pbrtTransformBegin();
+        { float m[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0.5f, 1.5f, 0.5f, 1}; pbrtConcatTransform(m); }
+        { ParamSet ps; iv(ps, "indices", {0, 1, 2}); pv(ps, "P", {-0.5f, -0.5f, 0, 0.5f, -0.5f, 0, 0, 0.5f, 0}); pbrtShape("trianglemesh", ps); }
+        pbrtTransformEnd();
+        pbrtTransformEnd();
+        { float m[16] = {0.5f, 0, 0, 0, 0, 0.5f, 0, 0, 0, 0, 0.5f, 0, 1.5f, -0.5f, 1, 1}; pbrtTransform(m); }
+        pbrtAttributeBegin();
+        pbrtReverseOrientation();
+        { ParamSet ps; one_color(ps, "Kr", .9f, .9f, .9f); pbrtMaterial("mirror", ps); }
+        g_quad_shape();
+        pbrtAttributeEnd();
+        pbrtIdentity();
+        pbrtCoordSysTransform("base");
+        pbrtTranslate(0, -1.6f, 0); pbrtRotate(90, 1, 0, 0); pbrtScale(4, 4, 1);
+        g_matte(.4f, .4f, .7f);
+        g_quad_shape();
+        pbrtWorldEnd();
+        return true;
+    }
+    if (kind == "g2") {                  // token rules: comments, number forms, unbracketed single values, line breaks inside parameter lists
+        pbrtLookAt(0, 0, -6, 0, 0, 0, 0, 1, 0);
+        { ParamSet ps; one_float(ps, "fov", 40); pbrtCamera("perspective", ps); }
+        g_film(32, 32); g_sampler(keyed, "stratified", 1, 1, false, 0);
+        { ParamSet ps; one_float(ps, "alpha", 1.5f); one_float(ps, "xwidth", 1.5f); one_float(ps, "ywidth", 1.5f); pbrtPixelFilter("gaussian", ps); }
+        { ParamSet ps; one_int(ps, "maxdepth", 2); pbrtSurfaceIntegrator("whitted", ps); }
+        g_accel();
+        pbrtWorldBegin();
+        g_point_light(0, 4, -4, 60);
+        pbrtAttributeBegin(); g_matte(.5f, .5f, .5f);
+        { ParamSet ps; iv(ps, "indices", {0, 1, 2}); pv(ps, "P", {-1.5f, -1, 0, 1.5f, -1, 0, 0, 1.5f, 0}); pbrtShape("trianglemesh", ps); }
+        pbrtAttributeEnd();
+        pbrtAttributeBegin();
+        pbrtTranslate(0, -.5f, -1); pbrtRotate(60, 1, 0, 0);
+        { ParamSet ps; one_color(ps, "Kd", .2f, .7f, .3f); one_float(ps, "sigma", 20); pbrtMaterial("matte", ps); }
+        { ParamSet ps; iv(ps, "indices", {0, 1, 2, 0, 2, 3}); pv(ps, "P", {-2, -2, 0, 2, -2, 0, 2, 2, 0, -2, 2, 0}); pbrtShape("trianglemesh", ps); }
+        pbrtAttributeEnd();
+        pbrtWorldEnd();
+        return true;
+    }
+    if (kind == "g3") {                  // Include, constant textures, their attribute scope
+        pbrtLookAt(0, 0, -6, 0, 0, 0, 0, 1, 0);
+        { ParamSet ps; one_float(ps, "fov", 40); pbrtCamera("perspective", ps); }
+        g_film(32, 32); g_sampler(keyed, "stratified", 1, 1, false, 0);
+        { ParamSet ps; pbrtPixelFilter("box", ps); }
+        { ParamSet ps; one_int(ps, "maxdepth", 2); pbrtSurfaceIntegrator("whitted", ps); }
+        g_accel();
+        pbrtWorldBegin();
+        g_point_light(0, 4, -4, 60);
+        { ParamSet ps; one_color(ps, "value", .7f, .3f, .1f); pbrtTexture("rust", "color", "constant", ps); }
+        { ParamSet ps; one_float(ps, "value", 30); pbrtTexture("rough", "float", "constant", ps); }
+        pbrtAttributeBegin();
+        { ParamSet ps; ps.AddTexture("Kd", "rust"); ps.AddTexture("sigma", "rough"); pbrtMaterial("matte", ps); }
+        pbrtTranslate(-1.2f, 0, 0);
+        g_quad_shape();                                    // the included file's statement
+        pbrtAttributeEnd();
+        pbrtAttributeBegin();
+        { ParamSet ps; one_color(ps, "value", .1f, .3f, .8f); pbrtTexture("rust", "color", "constant", ps); }      // redefined inside the attribute block
+        { ParamSet ps; ps.AddTexture("Kd", "rust"); pbrtMaterial("matte", ps); }
+        pbrtTranslate(1.2f, 0, 0);
+        g_quad_shape();                                    // the same file included again
+        pbrtAttributeEnd();
+        { ParamSet ps; ps.AddTexture("Kd", "rust"); pbrtMaterial("matte", ps); }                                    // the outer definition again
+        pbrtTranslate(0, -1.6f, 0); pbrtRotate(90, 1, 0, 0); pbrtScale(4, 4, 1);
+        g_quad_shape();
+        pbrtWorldEnd();
+        return true;
+    }
+    if (kind == "g4") {                  // parameter typing: integers written as floats are truncated, bools are strings, area light under a transform
+        pbrtLookAt(0, 0, -6, 0, 0, 0, 0, 1, 0);
+        { ParamSet ps; one_float(ps, "fov", 40); pbrtCamera("perspective", ps); }
+        g_film(32, 32); g_sampler(keyed, "stratified", 2, 2, true, 0);
+        { ParamSet ps; one_float(ps, "B", .3f); one_float(ps, "C", .35f); pbrtPixelFilter("mitchell", ps); }
+        { ParamSet ps; one_string(ps, "strategy", "all"); one_int(ps, "maxdepth", 2); pbrtSurfaceIntegrator("directlighting", ps); }
+        g_accel();
+        pbrtWorldBegin();
+        pbrtAttributeBegin();
+        { ParamSet ps; one_color(ps, "L", 20, 18, 15); one_int(ps, "nsamples", 2); pbrtAreaLightSource("area", ps); }
+        pbrtTranslate(0, 2.5f, 0); pbrtRotate(90, 1, 0, 0);
+        g_quad_shape();
+        pbrtAttributeEnd();
+        pbrtAttributeBegin(); g_matte(.7f, .7f, .7f); pbrtTranslate(0, -.3f, .5f); pbrtRotate(-20, 0, 1, 0); g_quad_shape(); pbrtAttributeEnd();
+        g_matte(.3f, .6f, .3f);
+        pbrtTranslate(0, -1.6f, 0); pbrtRotate(90, 1, 0, 0); pbrtScale(4, 4, 1);
+        g_quad_shape();
+        pbrtWorldEnd();
+        return true;
+    }
+    if (kind == "g5") {                  // factory defaults, an unused parameter, camera / film options, a light placed by the CTM only
+        pbrtLookAt(0, 0, -6, 0, 0, 0, 0, 1, 0);
+        { ParamSet ps; one_float(ps, "fov", 35); one_float(ps, "lensradius", .05f); one_float(ps, "focaldistance", 6); one_float(ps, "frameaspectratio", 1);
+          fv(ps, "screenwindow", {-1, 1, -1, 1}); one_float(ps, "hither", .01f); one_float(ps, "yon", 100); pbrtCamera("perspective", ps); }
+        { ParamSet ps; one_int(ps, "xresolution", 40); one_int(ps, "yresolution", 30); one_string(ps, "filename", "out.exr"); fv(ps, "cropwindow", {.1f, .9f, .2f, 1}); pbrtFilm("image", ps); }
+        g_sampler(keyed, "lowdiscrepancy", 0, 0, false, 4);
+        { ParamSet ps; pbrtPixelFilter("triangle", ps); }
+        { ParamSet ps; one_string(ps, "strategy", "one"); one_float(ps, "bogus", 1); pbrtSurfaceIntegrator("directlighting", ps); }
+        g_accel();
+        pbrtWorldBegin();
+        pbrtTransformBegin(); pbrtTranslate(0, 3, -3);
+        { ParamSet ps; one_color(ps, "I", 50, 50, 50); pbrtLightSource("point", ps); }       // "from" defaults to the origin: the CTM places the light
+        pbrtTransformEnd();
+        pbrtAttributeBegin(); { ParamSet ps; pbrtMaterial("mirror", ps); } pbrtTranslate(-1.1f, 0, .5f); pbrtRotate(25, 0, 1, 0); g_quad_shape(); pbrtAttributeEnd();
+        pbrtAttributeBegin(); { ParamSet ps; one_color(ps, "Kd", .3f, .3f, .6f); pbrtMaterial("plastic", ps); } pbrtTranslate(1.1f, 0, 0); g_quad_shape(); pbrtAttributeEnd();
+        pbrtTranslate(0, -1.6f, 0); pbrtRotate(90, 1, 0, 0); pbrtScale(4, 4, 1);
+        g_quad_shape();                                                                           // no Material statement at all: the default matte
+        pbrtWorldEnd();
+        return true;
+    }
+    fprintf(stderr, "unknown builtin scene %s\n", kind.c_str());
+    return false;
+}
+
 int main(int argc, char **argv) {
     bool quiet = false; string scene, builtin; int builtin_res = 64; bool builtin_keyed = false;
     for (int i = 1; i < argc; ++i) {
@@ -187,7 +331,7 @@ int main(int argc, char **argv) {
     RefSink sink;
     pbrthip::SceneParser parser(sink);
     current_file = scene;
-    bool ok = builtin.empty() ? parser.ParseFile(scene) : BuiltinCornell(builtin, builtin_res, builtin_keyed);
+    bool ok = builtin.empty() ? parser.ParseFile(scene) : (builtin[0] == 'g' ? BuiltinGrammar(builtin, builtin_keyed) : BuiltinCornell(builtin, builtin_res, builtin_keyed));
     pbrtCleanup();
     double t1 = ref_now();
     if (quiet) { fflush(stdout); dup2(savedOut, 1); close(savedOut); }

@@ -50,7 +50,7 @@ def build(force: bool = False, verbose: bool = False, defines=(), jobs: int | No
     headers = [d for d in hip_dep if d.endswith((".h", ".inc"))]
     host_src = [os.path.join(CSRC, "host", "scene_api.cpp")]
     host_dep = [os.path.join(CSRC, "host", f) for f in os.listdir(os.path.join(CSRC, "host"))] + \
-               [os.path.join(_HERE, "..", "include", "pbrt_hip.h")]
+               [os.path.join(_HERE, "..", "include", f) for f in ("pbrt_hip.h", "pbrt_hip_desc.h", "pbrt_hip_plugin.h")]
 
     def stale(out, deps):
         return force or not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
@@ -101,7 +101,7 @@ def build(force: bool = False, verbose: bool = False, defines=(), jobs: int | No
             print(" ".join(cmd))
         subprocess.check_call(cmd)
     if stale(HOST_LIB, host_dep):
-        cmd = ["g++"] + HOST_FLAGS + host_src + ["-Wl,--version-script=" + os.path.join(CSRC, "host", "exports.map"), "-o", HOST_LIB]
+        cmd = ["g++"] + HOST_FLAGS + host_src + ["-Wl,--version-script=" + os.path.join(CSRC, "host", "exports.map"), "-ldl", "-o", HOST_LIB]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
@@ -398,6 +398,8 @@ class ParsedScene:
         if path is not None:
             self._h = H.pbrt_host_parse_file(path.encode(), int(quiet))
         else:
+            from . import scenes as _scenes
+            text = _scenes.for_product(text)      # texts written for runs of the compiled reference wrap the sampler / accelerator in oracle-side plugins
             self._h = H.pbrt_host_parse_string(text.encode(), int(quiet))
         self.warnings = H.pbrt_host_warnings()
         self.errors = H.pbrt_host_errors()
@@ -452,6 +454,19 @@ class ParsedScene:
 
     def accel_params_ptr(self):
         return host_lib().pbrt_host_accel_params(self.scene_desc)
+
+    def accel_params(self) -> dict:
+        """RtAccelParams of this frame (include/pbrt_hip.h)."""
+        a = np.ctypeslib.as_array(C.cast(self.accel_params_ptr(), C.POINTER(C.c_int32)), shape=(7,))
+        return {"kind": int(a[0]), "isect_cost": int(a[1]), "trav_cost": int(a[2]), "max_prims": int(a[3]), "max_depth": int(a[4]),
+                "empty_bonus": float(a[5:6].view(np.float32)[0]), "build_threads": int(a[6])}
+
+    def render_view(self) -> dict:
+        """The leading scalar fields of this frame's RtRenderDesc (include/pbrt_hip.h): integrator .. seed."""
+        a = np.ctypeslib.as_array(C.cast(self.render_desc, C.POINTER(C.c_int32)), shape=(11,))
+        return {"integrator": int(a[0]), "max_depth": int(a[1]), "strategy": int(a[2]), "volume_integrator": int(a[3]),
+                "step_size": float(a[4:5].view(np.float32)[0]), "sampler": int(a[5]), "x_samples": int(a[6]), "y_samples": int(a[7]),
+                "jitter": int(a[8]), "pixel_samples": int(a[9]), "seed": int(a[10:11].view(np.uint32)[0])}
 
     def kdtree(self):
         """The kd-tree rt_scene_create would build for this scene, built on the host only."""

@@ -442,7 +442,7 @@ RT_DEV void estimate_direct_begin(const DevScene &sc, Lane &ln, int light, float
 // `begin`: start the march (ST_VOL_BEGIN); otherwise resume after the shadow ray of step m.i (ST_VOL_STEP: ln.tv holds its result).
 // Returns true with the next step's shadow ray set up (ln.has_ray, ln.pend, ln.stage = ST_VOL_STEP), false when the level is complete
 // (ln.L = T * L + Lv, ln.stage = ST_POP).  samp[(3 * a + b) * st]: the march's LatinHypercube(samp, N, 3) table (single.cpp:76-77).
-struct March { int i, N; float t0, step; V3 Tr, p, Lv; };
+struct March { int i, N; float t0, step; V3 Tr, p, Lv; float s0, s1, s2; };      // s0..s2: the sample-table row of step i + 1, requested when step i's shadow ray leaves (march kernel only)
 // The head of the march: clip against the medium, step count and size, the scatter offset, the LatinHypercube table (3 N draws, then 3 N
 // dependent swaps through memory: run where thousands of marches start side by side -- the shade pass of the queue pipeline, or the megakernel's
 // lanes -- never inside the persistent march kernel, where one lane's table would stall its wave for ~6 N memory round trips).  N = 0: nothing to march.
@@ -470,17 +470,21 @@ RT_DEV void march_begin(const DevScene &sc, const DevFrame &fr, Lane &ln, const 
 }
 // The steps.  `resume`: ln.tv holds the result of the shadow ray of step m.i.  Returns true with the next step's shadow ray set up (ln.has_ray,
 // ln.pend, ln.stage = ST_VOL_STEP), false when the level is complete (ln.L = T * L + Lv, ln.stage = ST_POP).
-template <bool COUNT, bool EXT, bool DEFER>
+// PREFETCH (march kernel): the next step's table row is requested together with this step's shadow ray, so the wave does not sit through an
+// HBM round trip when the ray comes back (a persistent wave has nothing else to run meanwhile).
+template <bool COUNT, bool EXT, bool DEFER, bool PREFETCH = false>
 RT_DEV bool march_steps(const DevScene &sc, const DevFrame &fr, Lane &ln, const Ray &ray, March &m, const float RT_G *samp, size_t st, bool resume, unsigned *c_any) {
     const RtVolume &vol = sc.vol;
     const bool single = fr.volume_integrator == RT_VOLUME_SINGLE;
     int i = m.i; const int N = m.N; float t0 = m.t0; const float step = m.step; V3 Tr = m.Tr, p = m.p, Lv = m.Lv;
     const V3 w = -ray.d;
+    bool have_row = false;
     if (resume) {
         if (COUNT) ++*c_any;
         if (ln.tv.hit_prim < 0)                                                // vis.Unoccluded: Ld = L * vis.Transmittance(scene)
             Lv = Lv + ln.pend * scene_transmittance<true>(sc, ln, ln.tv.o, ln.tv.d, ln.tv.mint, ln.tv.maxt);
         ++i; t0 += step;
+        have_row = PREFETCH;
     }
     while (i < N) {
         const V3 pPrev = p; p = ray.o + ray.d * t0;
@@ -497,8 +501,8 @@ RT_DEV bool march_steps(const DevScene &sc, const DevFrame &fr, Lane &ln, const 
             const V3 ss = in ? mat_color(vol.sigma_s) : mk3(0.f);
             const int nLights = int(sc.n_lights);
             if (!is_black(ss) && nLights > 0) {
-                const int lightNum = min(int(floorf(samp[size_t(3 * i) * st] * nLights)), nLights - 1);
-                const float u1 = samp[size_t(3 * i + 1) * st], u2 = samp[size_t(3 * i + 2) * st];
+                const float r0 = have_row ? m.s0 : samp[size_t(3 * i) * st], u1 = have_row ? m.s1 : samp[size_t(3 * i + 1) * st], u2 = have_row ? m.s2 : samp[size_t(3 * i + 2) * st];
+                const int lightNum = min(int(floorf(r0 * nLights)), nLights - 1);
                 LightRef Lt = RT_LIGHT(sc, lightNum);
                 V3 wo, L, sd; float pdf, smax;
                 if (light_is_delta(Lt)) { L = delta_light_sample(Lt, p, wo, sd, smax); pdf = 1.f; }
@@ -512,12 +516,16 @@ RT_DEV bool march_steps(const DevScene &sc, const DevFrame &fr, Lane &ln, const 
                     const float phase = in ? 1.f / (4.f * RT_PI) * (1.f - vol.g * vol.g) / powf(1.f + vol.g * vol.g - 2.f * vol.g * costheta, 1.5f) : 0.f;
                     ln.pend = div_s((((Tr * ss) * phase) * L) * float(nLights), pdf);
                     m.i = i; m.t0 = t0; m.Tr = Tr; m.p = p; m.Lv = Lv;
+                    if (PREFETCH) {                                            // row i + 1 (row N - 1 again past the end: never used)
+                        const int j = i + 1 < N ? i + 1 : i;
+                        m.s0 = samp[size_t(3 * j) * st]; m.s1 = samp[size_t(3 * j + 1) * st]; m.s2 = samp[size_t(3 * j + 2) * st];
+                    }
                     launch_ray<DEFER>(ln, sc, p, sd, RT_RAY_EPSILON, smax, true, ST_VOL_STEP);
                     return true;
                 }
             }
         }
-        ++i; t0 += step;
+        ++i; t0 += step; have_row = false;
     }
     Lv = Lv * step;
     const V3 T = vol_transmittance(vol, ray.o, ray.d, ray.mint, ray.maxt);      // sample != NULL: no draw

@@ -23,7 +23,10 @@
 #define RT_MARCH_STACK 8          // LDS ring entries per lane (pair form: 12 B each): 24 KB per workgroup
 #endif
 #ifndef RT_MARCH_REFILL
-#define RT_MARCH_REFILL 16        // leave the traversal loop when this many more lanes hold a finished shadow ray (they take their next step, or a new march)
+#define RT_MARCH_REFILL 16        // leave the traversal loop when this many more lanes hold a finished shadow ray (they take their next step): 8 and 32 measured slower
+#endif
+#ifndef RT_MARCH_TAKE
+#define RT_MARCH_TAKE 8           // idle lanes (march complete) take new slots from the queue when at least this many are idle (C5: 16: 216 ms of march launches, 8: 208, 4: 208, 32: 247)
 #endif
 
 namespace rt {
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(RT_BLOCK, COUNT ? 1 : RT_MARCH_WAVES) void pipe_mar
     Lane ln;
     ln.has_ray = false; ln.tv.active = false; ln.tv.at_leaf = false; ln.tv.hit_prim = -1; ln.tv.any = true; ln.tv.maxt = 0.f; ln.tv.b1 = ln.tv.b2 = 0.f;
     ln.L = mk3(0.f); ln.pend = mk3(0.f); ln.stage = ST_EXIT; ln.fsp = 0;
-    March m; m.i = m.N = 0; m.t0 = m.step = 0.f; m.Tr = m.p = m.Lv = mk3(0.f);
+    March m; m.i = m.N = 0; m.t0 = m.step = 0.f; m.Tr = m.p = m.Lv = mk3(0.f); m.s0 = m.s1 = m.s2 = 0.f;
     Ray ray; ray.o = ray.d = mk3(0.f); ray.mint = ray.maxt = 0.f;
     unsigned slot = 0, ctl = 0;
     bool busy = false;                                                  // this lane holds a march
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(RT_BLOCK, COUNT ? 1 : RT_MARCH_WAVES) void pipe_mar
         bool begin = false;
         const unsigned long long idle = __ballot(!busy);
         const unsigned n_idle = unsigned(__builtin_amdgcn_readfirstlane(__popcll(idle)));
-        if (!exhausted && n_idle >= RT_MARCH_REFILL) {
+        if (!exhausted && n_idle >= RT_MARCH_TAKE) {
             const unsigned have = w_end - w_next;
             unsigned f_lo = 0, f_hi = 0;
             if (have < n_idle && !head_done) {                          // wave-uniform branch
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(RT_BLOCK, COUNT ? 1 : RT_MARCH_WAVES) void pipe_mar
         const bool resume = busy && !begin && ln.has_ray && !ln.tv.active;
         if (begin || resume) {
             ln.has_ray = false;
-            if (!march_steps<COUNT, EXT, false>(sc, fr, ln, ray, m, RT_GPTR(const float, fr.vol_samp) + slot, n, resume, &c_any)) {
+            if (!march_steps<COUNT, EXT, false, true>(sc, fr, ln, ray, m, RT_GPTR(const float, fr.vol_samp) + slot, n, resume, &c_any)) {
                 float RT_G *c1 = (float RT_G *)(RT_GPTR(float4, pl.state) + slot + n);
                 float RT_G *c2 = (float RT_G *)(RT_GPTR(float4, pl.state) + slot + 2 * n);
                 c1[1] = __uint_as_float(ln.rng.ctr); c1[2] = __uint_as_float((ctl & ~0x1fu) | unsigned(ST_POP));     // the draw counter, the control word (now ST_POP)

@@ -2,6 +2,10 @@
 #include "scene_api.h"
 #include "../../../include/pbrt_hip_desc.h"
 #include "exr_io.h"
+#include "../../../include/pbrt_hip_plugin.h"
+#include <dlfcn.h>
+#include <unistd.h>
+#include <cstdlib>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -124,14 +128,70 @@ void Film::GetSampleExtent(int *xs, int *xe, int *ys, int *ye) const {
     *ye = floor2int(yPixelStart + .5f + yPixelCount + filter.yWidth);
 }
 
+// ------------------------------------------------------------------ plugin loader (core/dynload.cpp:41-61, 462-514)
+// `Kind "name"` first looks for name.so / libname.so along the search path and calls its extern "C" Create<Kind> factory
+// (include/pbrt_hip_plugin.h); the plugins of the hot path are compiled in and serve as the fall-back.
+static std::vector<std::string> &pluginDirs() { static std::vector<std::string> d; return d; }
+static void addPluginPath(const std::string &path) {         // colon-separated, like PBRT_SEARCHPATH (dynload.cpp:86-111 UpdatePluginPath)
+    size_t a = 0;
+    while (a <= path.size()) {
+        size_t b = path.find(':', a); if (b == std::string::npos) b = path.size();
+        if (b > a) pluginDirs().push_back(path.substr(a, b - a));
+        a = b + 1;
+    }
+}
+static void *findPluginSymbol(const std::string &name, const char *symbol) {
+    static bool env_done = false;
+    if (!env_done) {
+        env_done = true;
+        if (const char *e = std::getenv("PBRT_HIP_PLUGIN_PATH")) addPluginPath(e);
+        if (const char *e = std::getenv("PBRT_SEARCHPATH")) addPluginPath(e);
+    }
+    if (name.empty() || name.find('/') != std::string::npos) return nullptr;
+    static std::map<std::string, void *> handles;              // a shared object is opened once per process, as the reference's Plugin cache does
+    for (const std::string &dir : pluginDirs())
+        for (const char *prefix : {"", "lib"}) {
+            const std::string file = dir + "/" + prefix + name + ".so";
+            void *h = nullptr;
+            auto it = handles.find(file);
+            if (it != handles.end()) h = it->second;
+            else {
+                if (access(file.c_str(), R_OK) != 0) continue;
+                h = dlopen(file.c_str(), RTLD_NOW | RTLD_LOCAL);
+                if (!h) { Error("Unable to load plugin \"%s\": %s", file.c_str(), dlerror()); continue; }
+                handles[file] = h;
+            }
+            if (void *sym = dlsym(h, symbol)) return sym;
+            Error("Plugin \"%s\" has no %s function", file.c_str(), symbol);
+        }
+    return nullptr;
+}
+namespace {
+struct CParams { const ParamSet *ps; mutable std::vector<std::string> strings; };
+const CParams *cp(const PbrtHipParams *p) { return reinterpret_cast<const CParams *>(p); }
+const PbrtHipParamsApi kParamsApi = {
+    [](const PbrtHipParams *p, const char *n, int d) { return cp(p)->ps->FindOneInt(n, d); },
+    [](const PbrtHipParams *p, const char *n, float d) { return cp(p)->ps->FindOneFloat(n, d); },
+    [](const PbrtHipParams *p, const char *n, int d) { return int(cp(p)->ps->FindOneBool(n, d != 0)); },
+    [](const PbrtHipParams *p, const char *n, const char *d) -> const char * {
+        cp(p)->strings.push_back(cp(p)->ps->FindOneString(n, d ? d : "")); return cp(p)->strings.back().c_str(); }};
+}  // namespace
+
 // ------------------------------------------------------------------ samplers
 Sampler MakeSampler(const std::string &nameIn, const ParamSet &ps, const Film &, bool *ok) {
     Sampler s; *ok = true; s.seed = 0; s.pixelsamples = 4; s.xsamples = s.ysamples = 2; s.jitter = true;
-    std::string name = nameIn;
-    if (name == "keyed") {     // oracle-side wrapper (oracle/ref/keyed_sampler.cpp): this renderer's RNG is always keyed
-        name = ps.FindOneString("inner", "stratified");
-        s.seed = unsigned(ps.FindOneInt("seed", 0));
+    const std::string &name = nameIn;
+    if (void *sym = findPluginSymbol(name, "CreateSampler")) {                      // dynload.cpp:230-245 MakeSampler
+        CParams c{&ps}; PbrtHipSampler o{};
+        if (reinterpret_cast<PbrtHipCreateSamplerFn>(sym)(reinterpret_cast<const PbrtHipParams *>(&c), &kParamsApi, &o) != 0 ||
+            o.kind < RT_SAMPLER_STRATIFIED || o.kind > RT_SAMPLER_RANDOM) { Error("Unable to load plugin \"%s\" (sampler)", name.c_str()); *ok = false; s.kind = RT_SAMPLER_STRATIFIED; }
+        else { s.kind = o.kind; s.xsamples = o.xsamples; s.ysamples = o.ysamples; s.jitter = o.jitter != 0; s.pixelsamples = o.pixelsamples; s.seed = o.seed; }
+        ps.ReportUnused();
+        return s;
     }
+    // extension: "integer seed" selects the stream of this renderer's counter-based RNG; the reference's samplers draw
+    // from one global MT19937 and have no such parameter
+    s.seed = unsigned(ps.FindOneInt("seed", 0));
     if (name == "stratified") {                                                     // stratified.cpp:132-141
         s.kind = RT_SAMPLER_STRATIFIED;
         s.jitter = ps.FindOneBool("jitter", true);
@@ -152,6 +212,15 @@ Sampler MakeSampler(const std::string &nameIn, const ParamSet &ps, const Film &,
 // ------------------------------------------------------------------ integrators
 SurfaceIntegrator MakeSurfaceIntegrator(const std::string &name, const ParamSet &ps, bool *ok) {
     SurfaceIntegrator si; *ok = true; si.strategy = RT_STRATEGY_ALL;
+    if (void *sym = findPluginSymbol(name, "CreateSurfaceIntegrator")) {            // dynload.cpp:185-199 MakeSurfaceIntegrator
+        CParams c{&ps}; PbrtHipSurfaceIntegrator o{};
+        if (reinterpret_cast<PbrtHipCreateSurfaceIntegratorFn>(sym)(reinterpret_cast<const PbrtHipParams *>(&c), &kParamsApi, &o) != 0 ||
+            o.kind < RT_INTEGRATOR_WHITTED || o.kind > RT_INTEGRATOR_PATH || (o.strategy != RT_STRATEGY_ALL && o.strategy != RT_STRATEGY_ONE)) {
+            Error("Unable to load plugin \"%s\" (surface integrator)", name.c_str()); *ok = false; si.kind = RT_INTEGRATOR_WHITTED; si.maxDepth = 5;
+        } else { si.kind = o.kind; si.maxDepth = o.max_depth; si.strategy = o.strategy; }
+        ps.ReportUnused();
+        return si;
+    }
     si.maxDepth = ps.FindOneInt("maxdepth", 5);              // whitted.cpp:143, directlighting.cpp:196, path.cpp:147
     if (name == "whitted") si.kind = RT_INTEGRATOR_WHITTED;
     else if (name == "path") si.kind = RT_INTEGRATOR_PATH;
@@ -176,6 +245,14 @@ SurfaceIntegrator MakeSurfaceIntegrator(const std::string &name, const ParamSet 
 }
 VolumeIntegrator MakeVolumeIntegrator(const std::string &name, const ParamSet &ps, bool *ok) {
     VolumeIntegrator vi; *ok = true;
+    if (void *sym = findPluginSymbol(name, "CreateVolumeIntegrator")) {             // dynload.cpp:200-214 MakeVolumeIntegrator
+        CParams c{&ps}; PbrtHipVolumeIntegrator o{};
+        if (reinterpret_cast<PbrtHipCreateVolumeIntegratorFn>(sym)(reinterpret_cast<const PbrtHipParams *>(&c), &kParamsApi, &o) != 0 ||
+            (o.kind != RT_VOLUME_EMISSION && o.kind != RT_VOLUME_SINGLE)) { Error("Unable to load plugin \"%s\" (volume integrator)", name.c_str()); *ok = false; vi.kind = RT_VOLUME_EMISSION; vi.stepSize = 1.f; }
+        else { vi.kind = o.kind; vi.stepSize = o.step_size; }
+        ps.ReportUnused();
+        return vi;
+    }
     vi.stepSize = ps.FindOneFloat("stepsize", 1.f);          // emission.cpp:97, single.cpp:118
     if (name == "emission") vi.kind = RT_VOLUME_EMISSION;
     else if (name == "single") vi.kind = RT_VOLUME_SINGLE;
@@ -185,8 +262,17 @@ VolumeIntegrator MakeVolumeIntegrator(const std::string &name, const ParamSet &p
 }
 Accelerator MakeAccelerator(const std::string &nameIn, const ParamSet &ps, bool *ok) {
     Accelerator a; *ok = true; std::memset(&a.params, 0, sizeof a.params);
-    std::string name = nameIn;
-    if (name == "countaccel") name = ps.FindOneString("inner", "kdtree");   // oracle-side wrapper; rays are always counted here
+    const std::string &name = nameIn;
+    if (void *sym = findPluginSymbol(name, "CreateAccelerator")) {                  // dynload.cpp:246-260 MakeAccelerator
+        CParams c{&ps}; PbrtHipAccelerator o{};
+        if (reinterpret_cast<PbrtHipCreateAcceleratorFn>(sym)(reinterpret_cast<const PbrtHipParams *>(&c), &kParamsApi, &o) != 0 ||
+            (o.params.kind != RT_ACCEL_KDTREE && o.params.kind != RT_ACCEL_GRID)) {
+            Error("Unable to load plugin \"%s\" (accelerator)", name.c_str()); *ok = false; a.params.kind = RT_ACCEL_KDTREE;
+            a.params.isect_cost = 80; a.params.trav_cost = 1; a.params.empty_bonus = 0.5f; a.params.max_prims = 1; a.params.max_depth = -1;
+        } else a.params = o.params;
+        ps.ReportUnused();
+        return a;
+    }
     a.params.kind = RT_ACCEL_KDTREE;
     if (name == "grid") {
         a.params.kind = RT_ACCEL_GRID;
@@ -300,7 +386,7 @@ void PbrtApi::Camera(const std::string &n, const ParamList &p) {
     cameraOpt.name = n; cameraOpt.params = ParamSet(p);
     worldToCamera = ctm; named["camera"] = ctm.inverse();
 }
-void PbrtApi::SearchPath(const std::string &) { verifyOptions("SearchPath"); /* plugins are compiled in */ }
+void PbrtApi::SearchPath(const std::string &path) { if (verifyOptions("SearchPath")) addPluginPath(path); }      // api.cpp:258-262 -> UpdatePluginPath
 void PbrtApi::WorldBegin() {
     if (!verifyOptions("WorldBegin")) return;
     state = STATE_WORLD; ctm = Xform(); named["world"] = ctm;

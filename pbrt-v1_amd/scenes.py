@@ -212,8 +212,8 @@ def options_block(xres=512, yres=512, integrator="whitted", integrator_params=""
                   keyed=False, count=False, seed=0, crop=None, fov=39.3, lensradius=0.0,
                   focaldistance=1e30, volume_integrator=None, film_name="out.exr") -> str:
     """Options block.  ``keyed``/``count`` wrap the sampler/accelerator in the oracle-side helper
-    plugins (oracle/ref/keyed_sampler.cpp, count_accel.cpp); the MI355X host accepts and
-    ignores the wrappers (its RNG is always keyed, its rays are always counted)."""
+    plugins (oracle/ref/keyed_sampler.cpp, count_accel.cpp) for runs of the compiled reference; for_product() below
+    turns such a text into what the MI355X host is given (its RNG is always keyed, its rays are always counted)."""
     out = ["LookAt 278 273 -800  278 273 0  0 1 0\n"]
     cam = 'Camera "perspective" "float fov" [%s]' % repr(float(fov))
     if lensradius > 0:
@@ -245,6 +245,21 @@ def options_block(xres=512, yres=512, integrator="whitted", integrator_params=""
     else:
         out.append('Accelerator "%s" %s\n' % (accelerator, accel_params))
     return "".join(out)
+
+
+def for_product(text: str) -> str:
+    """The scene text the product's host library parses: the oracle-side helper plugins of a reference run are unwrapped --
+    `Sampler "keyed" "string inner" ["X"] "integer seed" [n] ...` becomes `Sampler "X" "integer seed" [n] ...` (the seed of the
+    counter-based RNG is a parameter of the product's own samplers) and `Accelerator "countaccel" "string inner" ["Y"] ...`
+    becomes `Accelerator "Y" ...`.  libpbrt_host.so knows neither name (VERDICT r03 weak #11)."""
+    import re
+    i = text.find("WorldBegin")                              # the options block only: a world can be a gigabyte of triangles
+    head = text if i < 0 else text[:i]
+    new = re.sub(r'Sampler\s+"keyed"\s+"string inner"\s*\[\s*"(\w+)"\s*\]', r'Sampler "\1"', head)
+    new = re.sub(r'Accelerator\s+"countaccel"\s+"string inner"\s*\[\s*"(\w+)"\s*\]', r'Accelerator "\1"', new)
+    if new == head:
+        return text
+    return new if i < 0 else new + text[i:]
 
 
 def cornell_scene(soup_tris: int = 0, soup_seed: int = 12345, soup_materials=False,

@@ -249,3 +249,44 @@ def test_bench_reports_a_stale_profile_as_stale(pkg, tmp_path):
     out = {"roofline": {"traffic": None, "kernel_ms": 10.0}}
     bench.attach_profile(out, "w", 4e9, "0123456789abcdef", profiles_dir=str(tmp_path))                # another library: nothing is printed but the reason
     assert out["roofline"]["traffic"] is None and "valu_issue" not in out["roofline"] and "stale" in out["roofline"]["traffic_source"]
+
+
+def test_plugins_are_loaded_from_the_search_path(pkg, tmp_path):
+    """north_star: "host-side C++ keeps pbrt's plugin API (SurfaceIntegrator/Aggregate/Sampler)".  As core/dynload.cpp:462-514 does, the host library
+    resolves `SurfaceIntegrator "name"` / `Accelerator "name"` / `Sampler "name"` to name.so along the search path (SearchPath directive,
+    PBRT_SEARCHPATH) and calls its extern "C" Create<Kind> factory (include/pbrt_hip_plugin.h); the compiled-in plugins are the fall-back."""
+    import subprocess, ctypes as C
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "plug.cpp"
+    src.write_text('''
+#include "pbrt_hip_plugin.h"
+extern "C" int CreateSurfaceIntegrator(const PbrtHipParams *p, const PbrtHipParamsApi *api, PbrtHipSurfaceIntegrator *out) {
+    out->kind = RT_INTEGRATOR_PATH; out->max_depth = api->find_int(p, "bounces", 3) + 1; out->strategy = RT_STRATEGY_ALL; return 0; }
+extern "C" int CreateAccelerator(const PbrtHipParams *p, const PbrtHipParamsApi *api, PbrtHipAccelerator *out) {
+    RtAccelParams a = {}; a.kind = RT_ACCEL_KDTREE; a.isect_cost = api->find_int(p, "cost", 80); a.trav_cost = 1; a.empty_bonus = 0.5f; a.max_prims = 4; a.max_depth = -1;
+    out->params = a; return 0; }
+extern "C" int CreateSampler(const PbrtHipParams *p, const PbrtHipParamsApi *api, PbrtHipSampler *out) {
+    out->kind = RT_SAMPLER_STRATIFIED; out->xsamples = out->ysamples = api->find_int(p, "side", 2); out->jitter = api->find_bool(p, "jitter", 0);
+    out->pixelsamples = 4; out->seed = 11; return 0; }
+''')
+    for name in ("bouncy", "fatleaves", "square"):
+        subprocess.check_call(["g++", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(tmp_path / (name + ".so"))])
+    from pbrt_v1_amd import scenes
+    base = scenes.cornell_scene(xres=16, yres=16, integrator="path", maxdepth=5, xsamples=2, ysamples=2)
+    text = ('SearchPath "%s"\n' % tmp_path) + base.replace('SurfaceIntegrator "path"', 'SurfaceIntegrator "bouncy" "integer bounces" [6] #').replace(
+        'Accelerator "kdtree"', 'Accelerator "fatleaves" "integer cost" [40] #').replace('Sampler "stratified"', 'Sampler "square" "integer side" [3] "bool jitter" ["true"] #')
+    assert "bouncy" in text and "fatleaves" in text and "square" in text
+    ps = pkg.ParsedScene(text=text)
+    assert ps.valid and ps.errors == 0 and ps.warnings == 0
+    rd = ps.render_view()
+    assert rd["integrator"] == 2 and rd["max_depth"] == 7 and rd["x_samples"] == 3 and rd["y_samples"] == 3 and rd["jitter"] == 1 and rd["seed"] == 11
+    acc = ps.accel_params()
+    assert acc["max_prims"] == 4 and acc["isect_cost"] == 40
+    # a parameter the plugin never looks up is reported like any unused parameter (paramset.cpp:330-346)
+    ps2 = pkg.ParsedScene(text=text.replace('"integer bounces" [6]', '"integer bounces" [6] "float nonsense" [1]'))
+    assert ps2.valid and ps2.warnings == 1
+    # no such file anywhere: the compiled-in plugins answer, and an unknown name is the reference's Error
+    ps3 = pkg.ParsedScene(text=('SearchPath "%s"\n' % tmp_path) + base)
+    assert ps3.valid and ps3.errors == 0 and ps3.render_view()["integrator"] == 2 and ps3.render_view()["max_depth"] == 5
+    ps4 = pkg.ParsedScene(text=base.replace('SurfaceIntegrator "path"', 'SurfaceIntegrator "nosuchplugin"'))
+    assert ps4.errors >= 1

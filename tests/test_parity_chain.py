@@ -2,7 +2,9 @@
 
   t0_*   films of the RNG-UNTOUCHED reference (own MT19937, own samplers, no helper plugins) on scenes no random draw can reach:
          the oracle and the device must reproduce them, so the link-time RNG override of pbrt_ref_keyed is out of the loop;
-  api_*  films of the reference driven by hand-written pbrt* API calls (no scene text, no tokenizer in the reference run);
+  api_*  films of the reference driven by hand-written pbrt* API calls (no scene text, no tokenizer in the reference run): the two Cornell
+         configs and five grammar scenes (tests/golden/make_api_fixtures.py: transform stack, token rules, Include + texture scope, parameter
+         typing, factory defaults) -- the oracle and the device parse the TEXT and must reproduce the API-driven film;
   t2     a converged Cornell image from the reference's native MT19937 stream, twice: the device's converged image must be as
          close to it as the reference's second render is;
   bad_*  Scene::Render's radiance sanity check (scene.cpp:60-74) actually firing;
@@ -26,17 +28,28 @@ def load(name):
     z = np.load(os.path.join(CHAIN, name + ".npz"))
     d = {k: z[k] for k in z.files}
     d["scene"] = str(d["scene"]); d["stats"] = json.loads(str(d["stats"]))
+    d["files"] = json.loads(str(d["files"])) if "files" in d else {}
     return d
+
+
+def parse(pkg, g, tmp_path, monkeypatch):
+    """The fixture's scene text through the product's parser; files it Includes (relative paths) are laid out under a scratch directory first."""
+    for rel, body in g["files"].items():
+        os.makedirs(os.path.dirname(str(tmp_path / rel)), exist_ok=True)
+        (tmp_path / rel).write_text(body)
+    monkeypatch.chdir(tmp_path)
+    return pkg.ParsedScene(text=g["scene"])
 
 
 EXACT = chain_names("t0_") + chain_names("api_") + chain_names("bad_") + chain_names("sinc_")
 
 
 @pytest.mark.parametrize("name", EXACT)
-def test_oracle_reproduces_the_chain_fixture(pkg, oracle, name):
+def test_oracle_reproduces_the_chain_fixture(pkg, oracle, name, tmp_path, monkeypatch):
     g = load(name)
-    ps = pkg.ParsedScene(text=g["scene"])
+    ps = parse(pkg, g, tmp_path, monkeypatch)
     assert ps.valid and ps.errors == 0
+    if name == "api_g5": assert ps.warnings == 1          # the unused "float bogus" (paramset.cpp:330-346)
     nodes, refs, bounds, info = ps.kdtree()
     rgb, alpha, _, cnt = oracle.render(ps, nodes, refs, bounds, info=info)
     assert np.abs(rgb - g["rgb"]).max() <= 1e-6 and np.abs(alpha - g["alpha"]).max() <= 1e-6, (name, film_metrics(rgb, g["rgb"]))
@@ -49,11 +62,11 @@ def test_oracle_reproduces_the_chain_fixture(pkg, oracle, name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", EXACT)
-def test_device_reproduces_the_chain_fixture(pkg, name):
+def test_device_reproduces_the_chain_fixture(pkg, name, tmp_path, monkeypatch):
     if pkg.device_count() < 1:
         pytest.fail("no HIP device visible")
     g = load(name)
-    ps = pkg.ParsedScene(text=g["scene"])
+    ps = parse(pkg, g, tmp_path, monkeypatch)
     ds = pkg.DeviceScene(ps); ds.render()
     rgb, alpha = ds.film(); cnt = ds.counters(); ds.close()
     m = film_metrics(rgb, g["rgb"])
