@@ -40,7 +40,7 @@ HIP_UNITS = ("rt_kernels.hip", "rt_trace.hip", "rt_mega_w.hip", "rt_mega_d.hip",
 def build(force: bool = False, verbose: bool = False, defines=(), jobs: int | None = None) -> None:
     """Compile both shared libraries in-tree (hipcc cross-compiles gfx950 without a GPU).  The HIP library is ten translation
     units (the megakernel and the pipeline's shade kernel per integrator, the trace kernel, the C ABI, the two host builders)
-    compiled in parallel and linked; `defines` (-D knobs for tools/perf_sweep.py) force a rebuild into the same place."""
+    compiled in parallel and linked; `defines` (-D knobs; tools/build_variant.py builds variants side by side) force a rebuild into the same place."""
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIB_DIR, exist_ok=True)
     obj_dir = os.path.join(LIB_DIR, "obj")

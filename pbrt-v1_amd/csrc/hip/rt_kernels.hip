@@ -1800,7 +1800,7 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
     HIPCHK(hipEventRecord(s->ev2, s->stream));
     s->have_timing = true;
 #ifdef RT_PROFILE
-    {   // tools/perf_sweep.py 'p': per-wave cycle split of the render kernel (debug builds only)
+    {   // -DRT_PROFILE builds: per-wave cycle split of the render kernel
         unsigned long long v[24];
         HIPCHK(hipStreamSynchronize(s->stream));
         HIPCHK(hipMemcpy(v, s->counters, sizeof v, hipMemcpyDeviceToHost));
