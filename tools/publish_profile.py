@@ -1,5 +1,5 @@
 """Summarise gpurun_out/prof_<round>_<tag>/ (tools/profile.sh) into summary.json there: per kernel {calls, total / average ms} from
---kernel-trace --stats and per-kernel PMC sums PER FRAME (the bench command renders 1 counted + 1 warm-up + 3 timed frames = 5).
+--kernel-trace --stats and per-kernel PMC sums PER FRAME (the bench command renders 1 counted + 1 warm-up + 3 timed + 3 host-hand-over frames = 8).
 `--publish` also writes profiles/<round>_<tag>{_kernel_stats.csv,_summary.json} and, for the workload's dominant timed kernel,
 profiles/<round>_<tag>_render_kernel.json -- what bench.py reads `roofline.traffic` / `valu_issue` from through the latest_<workload>
 symlink.  Every published file carries `code_id` = pbrt_v1_amd.code_id() of the library that was profiled (sha256 of its device code):
@@ -14,7 +14,7 @@ rnd, tag = sys.argv[1], sys.argv[2]
 publish = "--publish" in sys.argv[3:]
 src = os.path.join(ROOT, "gpurun_out", "prof_%s_%s" % (rnd, tag))
 wl = tag.split("_pipe")[0]
-FRAMES = 5
+FRAMES = 8          # bench.py --steps 3 --warmup 1: 1 counted (counting twin) + 1 warm-up + 3 timed + 3 host-hand-over frames
 code_id = entry.load_package().code_id()
 out = {"workload": wl, "round": rnd, "code_id": code_id,
        "command": "rocprofv3 --kernel-trace --stats | --pmc <group> (one group per run) -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --workload " + wl,
