@@ -1314,7 +1314,7 @@ static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel 
     }
     s->n_threads = s->grid * RT_BLOCK;
     s->spill_depth = s->tree.max_depth > RT_TRACE_STACK ? s->tree.max_depth - RT_TRACE_STACK + 1 : 1;     // RT_TRACE_STACK <= RT_STACK_LDS
-    HIPCHK(hipMalloc((void **)&s->work_counter, sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void **)&s->work_counter, 64 * sizeof(unsigned long long)));      // 8 band counters, one 64-byte line each (the pipeline uses the first)
     HIPCHK(hipMalloc((void **)&s->counters, 64 * sizeof(unsigned long long)));        // 8 RtCounters, 16 RT_PROFILE, 2 x 16 RT_PROFILE_STAGES
     HIPCHK(hipMemsetAsync(s->counters, 0, 64 * sizeof(unsigned long long), s->stream));
     HIPCHK(hipMalloc((void **)&s->filter_dev, 256 * sizeof(float)));
@@ -1531,6 +1531,11 @@ static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool nee
         fr.leaf_min = tiny ? 8 : RT_TRACE_LEAF_MIN;          // C2: 50.8 ms at 8, 54.0 at 24 (few fat leaves: waiting for a fuller batch only idles lanes)
         if (const char *e = knob("PBRT_HIP_LEAF_MIN")) fr.leaf_min = std::max(1, std::atoi(e));
         if (const char *e = knob("PBRT_HIP_TRAV_MODE")) fr.trav_mode = std::atoi(e);
+        // XCD bands of the work list (rt_render_kernel.h): frames whose rays stay coherent (Whitted / DirectLighting: camera, shadow and specular rays)
+        // gain from each private L2 holding one band's lines -- C3 13.37 -> 12.62 ms; path frames, whose rays scatter after the first bounce, lose
+        // 5 % (1 M path 62.2 -> 65.5 ms, C4 64.1 -> 67.5; profiles/r04_xcd_bands_scan.txt)
+        fr.xcd_bands = rd->integrator != RT_INTEGRATOR_PATH ? 1 : 0;
+        if (const char *e = knob("PBRT_HIP_XCD_BANDS")) fr.xcd_bands = std::atoi(e) != 0;
         if (const char *e = knob("PBRT_HIP_EXIT_THRESH")) fr.exit_thresh = std::atoi(e);
         fr.dbg_x = fr.dbg_y = -1000000;
         if (const char *e = knob("PBRT_HIP_DEBUG_PIXEL")) std::sscanf(e, "%d,%d", &fr.dbg_x, &fr.dbg_y);
@@ -1788,7 +1793,7 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
         if (s->has_ext && !s->counting) variant = 36 + ((s->volume.present ? 1 : 0) * 2 + (s->accel_kind == RT_ACCEL_GRID ? 1 : 0)) * 3 + rd->integrator;
         if (s->grids[variant] == 0) return fail(RT_ESTATE, "render kernel variant has no resident grid");
         HIPCHK(hipMemcpyAsync(s->dev_frame, &fr, sizeof(DevFrame), hipMemcpyHostToDevice, s->stream));
-        HIPCHK(hipMemsetAsync(s->work_counter, 0, sizeof(unsigned long long), s->stream));
+        HIPCHK(hipMemsetAsync(s->work_counter, 0, 64 * sizeof(unsigned long long), s->stream));
         HIPCHK(hipEventRecord(s->ev0, s->stream));
         hipLaunchKernelGGL(render_kernel_of(variant), dim3(s->grids[variant]), dim3(RT_BLOCK), 0, s->stream,
                            (const DevScene *)s->dev_scene, (const DevFrame *)s->dev_frame);

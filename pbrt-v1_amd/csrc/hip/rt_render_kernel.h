@@ -18,6 +18,12 @@ RT_DEV unsigned long long uniform64(unsigned long long v) {
 }
 
 
+// first work item of band r of n (multiples of the chunk size, so that a chunk never straddles two bands; band n ends at `total`)
+RT_DEV unsigned long long band_lo(unsigned long long total, unsigned r, unsigned n) {
+    if (r >= n) return total;
+    return (total / RT_MEGA_CHUNK) * r / n * RT_MEGA_CHUNK;
+}
+
 // ------------------------------------------------------------------------------------------ kernels
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 1
@@ -68,6 +74,8 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
 #define RT_PF(x)
 #endif
     unsigned long long w_next = 0, w_end = 0;                              // this wave's chunk of the sample list (wave-uniform)
+    const unsigned n_bands = fr.xcd_bands ? 8u : 1u, home = fr.xcd_bands ? (blockIdx.x & 7u) : 0u;
+    unsigned band_shift = 0;                                               // bands this wave has seen the end of
     // phase gating (rt_integrate.h, stage_in_phase): sweeps alternate between the two halves of the path state machine;
     // the first sweep is of the second kind (it contains the work fetch)
     int phase = (INTEG == RT_INTEGRATOR_PATH && fr.phase_sync) ? 1 : -1;
@@ -83,20 +91,35 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
                 // profiles/r02_scan_util3.jsonl), so a wave goes to it once per RT_MEGA_CHUNK samples, not once per fetch.
                 const unsigned n_want = unsigned(__popcll(want));
                 const unsigned long long have = w_end - w_next;
-                unsigned long long fresh = 0;
+                unsigned long long fresh = 0, fresh_end = 0;
                 if (have < n_want) {                                      // wave-uniform branch
                     const int leader = __ffsll((long long)want) - 1;
-                    if (lane == leader) fresh = atomicAdd(fr.work_counter, (unsigned long long)RT_MEGA_CHUNK);
-                    fresh = uniform64(__shfl(fresh, leader));
+                    // XCD bands (round 4): the work list is cut into 8 contiguous bands with their own counters; a wave draws from the band of ITS XCD
+                    // (workgroup i runs on XCD i mod 8) and moves on to the next band when that one is used up.  With one counter the 4096 resident waves
+                    // work on the same ~9 scanlines at any time and all eight private L2s hold the same lines; with bands each L2 holds one band's.
+#pragma unroll 1
+                    while (band_shift < n_bands) {
+                        const unsigned r = (home + band_shift) % n_bands;
+                        const unsigned long long lo = band_lo(fr.total_work, r, n_bands), hi = band_lo(fr.total_work, r + 1u, n_bands);
+                        unsigned long long base = 0;
+                        if (lane == leader) base = atomicAdd(fr.work_counter + 8u * r, (unsigned long long)RT_MEGA_CHUNK);
+                        base = uniform64(__shfl(base, leader));
+                        if (lo + base < hi) { fresh = lo + base; fresh_end = fresh + RT_MEGA_CHUNK < hi ? fresh + RT_MEGA_CHUNK : hi; break; }
+                        ++band_shift;
+                    }
                 }
+                const bool none_left = band_shift >= n_bands;             // every band's counter has passed its end
                 const unsigned long long rk = __popcll(want & ((1ull << lane) - 1ull));
                 const unsigned long long w_mine = rk < have ? w_next + rk : fresh + (rk - have);
-                if (have < n_want) { w_next = fresh + (n_want - have); w_end = fresh + RT_MEGA_CHUNK; }
-                else w_next += n_want;
-                if (!ln.has_ray && ln.stage == ST_FETCH) {
+                const bool got = rk < have || w_mine < fresh_end;          // (a chunk clipped at its band's end serves fewer lanes: the others ask again)
+                if (have < n_want) {
+                    const unsigned long long took = n_want - have < fresh_end - fresh ? n_want - have : fresh_end - fresh;
+                    w_next = fresh + took; w_end = fresh_end;
+                } else w_next += n_want;
+                if (!ln.has_ray && ln.stage == ST_FETCH && !got) { if (none_left) ln.stage = ST_EXIT; }
+                else if (!ln.has_ray && ln.stage == ST_FETCH) {
                     const unsigned long long w = w_mine;
-                    if (w >= fr.total_work) ln.stage = ST_EXIT;
-                    else {
+                    {
                         unsigned long long pixel; int s;
                         if (work_to_sample(fr, w, pixel, s)) {
                             Ray ray;

@@ -28,16 +28,7 @@
 // Per-lane 4-entry mailbox window: measured SLOWER on MI355X (C2 92.9 vs 87.8 ms, 100k-soup path 169 vs 165 ms): the
 // four compares + rotates per candidate cost more VALU than the avoided re-tests save.  Kept as a compile-time knob.
 
-#ifndef RT_NT_LOADS
-#define RT_NT_LOADS 0              // experiment: non-temporal loads for 1 = leaf triangle records, 2 = the second pair record of a step, 4 = the first
-#endif
-
 namespace rt {
-
-typedef float nt_vf4 __attribute__((ext_vector_type(4)));
-typedef unsigned nt_vu4 __attribute__((ext_vector_type(4)));
-RT_DEV float4 nt_load(const float4 RT_G *p) { const nt_vf4 v = __builtin_nontemporal_load((const nt_vf4 RT_G *)p); return make_float4(v.x, v.y, v.z, v.w); }
-RT_DEV uint4 nt_load(const uint4 RT_G *p) { const nt_vu4 v = __builtin_nontemporal_load((const nt_vu4 RT_G *)p); return make_uint4(v.x, v.y, v.z, v.w); }
 
 // A value the compiler must treat as defined without spending an instruction on it: the select-style steps read their load results on
 // every lane and commit them under lane masks, so a lane that did not load needs no particular value -- initialising the eight words of a
@@ -521,11 +512,7 @@ RT_DEV void leaf_test_flat(Trav &tv, bool leafw, const DevScene &sc, TravCounter
     float4 q0, q1, q2; undef_f4(q0); undef_f4(q1); undef_f4(q2);
     if (leafw) {
         const float4 RT_G *gt = RT_GPTR(const float4, sc.ltris) + (size_t(tv.ly) + 3u * tv.li);
-#if (RT_NT_LOADS & 1)
-        q0 = nt_load(gt); q1 = nt_load(gt + 1); q2 = nt_load(gt + 2);
-#else
         q0 = gt[0]; q1 = gt[1]; q2 = gt[2];
-#endif
     }
     const unsigned prim = __float_as_uint(q2.w);
     if (COUNT) { cnt.tris += leafw ? 1u : 0u; cnt.leaf_refs += (leafw && !single) ? 1u : 0u; }
@@ -610,16 +597,8 @@ RT_DEV void kdp_step(Trav &tv, bool desc, const DevScene &sc, PairStack st, unsi
     uint4 A, B; undef_u4(A); undef_u4(B);
     if (interior) {
         const uint4 RT_G *p = RT_GPTR(const uint4, sc.tpairs) + idx;
-#if (RT_NT_LOADS & 4)
-        A = nt_load(p);
-#else
         A = p[0];
-#endif
-#if (RT_NT_LOADS & 2)
-        if (two) B = nt_load(p + (1u + (c_above ? fb : 0u)));
-#else
         if (two) B = p[1u + (c_above ? fb : 0u)];
-#endif
     }
     const unsigned c_x = c_above ? A.z : A.x, c_y = c_above ? A.w : A.y;
     const unsigned f_x = c_above ? A.x : A.z, f_y = c_above ? A.y : A.w;

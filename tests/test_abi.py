@@ -102,6 +102,10 @@ def test_timed_kernels_stay_inside_their_occupancy_step(pkg):
     assert v <= 128, v
     v, spill = vgprs("rt_pipe_v", "pipe_vertex_kernelILb0ELb0EE")                 # the by-vertex shade pass of the path pipeline: 3 waves
     assert v <= 168 and spill == 0, (v, spill)
+    v, spill = vgprs("rt_march", "pipe_march_kernelILb0ELi0ELb0EE")               # the march kernel (round 4): 4 waves; a handful of spilled registers outside its traversal loop
+    assert v <= 128 and spill <= 24, (v, spill)
+    v, spill = vgprs("rt_pipe_d", "pipe_shade_kernelILb0ELi1ELb1ELb0EE")          # the volume shade pass without the march (round 3: 195 on its own, held to 168)
+    assert v <= 168, (v, spill)
     # the film gathers keep their pixel windows in registers: a dynamic window index (or an `if` the compiler turns into a store through a
     # pointer phi) puts them in scratch, 112 B per lane -- seen while writing film_march_kernel
     for frag, cap in (("film_slot_kernelILi2ELi2ELi4EE", 168), ("film_slot_kernelILi2ELi2ELi12EE", 256), ("film_slot_kernelILi1ELi1ELi4EE", 168),
