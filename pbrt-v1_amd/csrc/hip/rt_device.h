@@ -112,6 +112,7 @@ struct DevFrame {
     int phase_sync;             // path integrator: alternate the two halves of the state machine between sweeps (rt_integrate.h)
     int high_occupancy;          // host-side choice of the 5-waves/SIMD kernel flavour (not read by the device)
     int leaf_min;                // batched rounds: keep testing leaf primitives while at least this many lanes hold an untested one
+    int mega_tile;               // megakernel, one shard: the work counter hands the samples out in square tiles of this many pixels (0: scanline order); rt_integrate.h tile_order_to_sample
     int xcd_bands;               // megakernel: 8 bands of the work list with their own counters (work_counter[8 * band]), a wave draws from its XCD's band first
     int trav_mode;               // 2 = the flat traversal round (trace_round), 3 = lock-step rounds with pooled leaf tests (tiny trees with fat leaves; natural-allocation kernels only)
     int pipeline;                // host-side choice: the queue pipeline (rt_pipeline.h) instead of the megakernel (not read by the device)

@@ -238,6 +238,23 @@ RT_DEV bool work_to_sample(const DevFrame &fr, unsigned long long w, unsigned lo
     return pixel < fr.total_pixels;
 }
 
+// Single shard, megakernel (round 4): the ORDER in which the work counter hands out the samples -- square tiles of mega_tile x mega_tile pixels,
+// row-major over the sample extent, clipped at its right and bottom edge (no padding, so no dropped items), a tile's pixels in scanline order, a
+// pixel's samples consecutively.  Everything else keeps addressing a sample by its scanline index pixel * spp + s (ln.work, the sample buffer,
+// rt_samples_read): only which lanes render which samples at the same time changes -- the waves resident on an XCD then work on a compact block of the
+// image instead of a strip one pixel high (their rays meet the same part of the tree: L2).
+RT_DEV void tile_order_to_sample(const DevFrame &fr, unsigned w, unsigned &pixel, int &s) {
+    const unsigned spp = unsigned(fr.spp), T = unsigned(fr.mega_tile);
+    const unsigned W = unsigned(fr.x_end - fr.x_start), H = unsigned(fr.y_end - fr.y_start);
+    const unsigned wp = w / spp; s = int(w - wp * spp);
+    const unsigned row_px = W * T, ty = wp / row_px, rem = wp - ty * row_px;
+    const unsigned h_t = min(T, H - ty * T), full = T * h_t, tiles_x = (W + T - 1u) / T;
+    unsigned tx = rem / full; tx = tx < tiles_x ? tx : tiles_x - 1u;
+    const unsigned rem2 = rem - tx * full, w_t = min(T, W - tx * T);
+    const unsigned qy = rem2 / w_t, qx = rem2 - qy * w_t;
+    pixel = (ty * T + qy) * W + tx * T + qx;
+}
+
 RT_DEV void setup_sample(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigned long long pixel, int s, Ray &ray) {
     const int w = fr.x_end - fr.x_start;
     int px, py;

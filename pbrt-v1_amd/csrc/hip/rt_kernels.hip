@@ -1559,6 +1559,11 @@ static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool nee
             // worth more (C5: L2 misses 5.3 G per frame in 64 x 64 tiles, 6.3 G in scanline order; 328 vs 332 ms).
             fr.tile_w = fr.tile_h = fr.tiles_x = 0; fr.tile_pixels = 1;
             fr.total_work = fr.total_pixels * fr.spp;
+            // The counter hands the scanline-addressed samples out in 32 x 32-pixel blocks (clipped at the extent's edges: no padding, nothing dropped):
+            // C3's kernel 12.68 -> 12.18 ms on top of the XCD bands, the path frames and C2 unchanged (profiles/r04_mega_tile_scan.txt).
+            fr.mega_tile = 32;
+            if (const char *e = knob("PBRT_HIP_MEGA_TILE")) fr.mega_tile = std::max(0, std::atoi(e));
+            if (fr.mega_tile > 4096 || fr.total_work > 0xffffffffull) fr.mega_tile = 0;
         }
         if (fr.trav_mode != 3 || fr.high_occupancy) fr.trav_mode = 2;  // (the high-occupancy kernels carry no pooled-leaf scratch)
     }

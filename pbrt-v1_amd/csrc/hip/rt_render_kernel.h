@@ -121,10 +121,13 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
                     const unsigned long long w = w_mine;
                     {
                         unsigned long long pixel; int s;
-                        if (work_to_sample(fr, w, pixel, s)) {
+                        bool ok;
+                        if (fr.mega_tile > 0) { unsigned px; tile_order_to_sample(fr, unsigned(w), px, s); pixel = px; ok = true; }      // (single shard)
+                        else ok = work_to_sample(fr, w, pixel, s);
+                        if (ok) {
                             Ray ray;
                             setup_sample(sc, fr, ln, pixel, s, ray);
-                            ln.work = uint32_t(w);
+                            ln.work = fr.mega_tile > 0 ? uint32_t(pixel * unsigned(fr.spp) + unsigned(s)) : uint32_t(w);
                             ln.L = mk3(0.f); ln.thr = mk3(1.f); ln.alpha = 0.f; ln.depth = 0; ln.fsp = 0;
                             ln.specular = false;
                             if (COUNT) ++c_cam;
