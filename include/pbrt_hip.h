@@ -153,7 +153,10 @@ typedef struct RtSceneDesc {
 
 /* ---- per-frame description ---- */
 enum { RT_INTEGRATOR_WHITTED = 0, RT_INTEGRATOR_DIRECT = 1, RT_INTEGRATOR_PATH = 2 };
-enum { RT_STRATEGY_ALL = 0, RT_STRATEGY_ONE = 1 };
+enum { RT_STRATEGY_ALL = 0, RT_STRATEGY_ONE = 1, RT_STRATEGY_WEIGHTED = 2 };
+/* RT_STRATEGY_WEIGHTED: WeightedSampleOneLight (transport.cpp:71-122), a recurrence over every shading point of the frame in program order.
+ * rt_render accepts it on one shard (shard_count == 1) for scenes whose lights all draw the same number of random numbers per estimate
+ * (any mix of point / spot / distant / single-triangle / quadric emitters, or only emitters of several triangles) and at most 2048 lights. */
 enum { RT_VOLUME_NONE = 0, RT_VOLUME_EMISSION = 1, RT_VOLUME_SINGLE = 2 };
 enum { RT_SAMPLER_STRATIFIED = 0, RT_SAMPLER_LOWDISCREPANCY = 1, RT_SAMPLER_RANDOM = 2 };
 
@@ -299,6 +302,10 @@ typedef struct RtRenderStats {
     float shade_ms;            /* queue pipeline: the shade launches summed */
     int32_t bands;             /* megakernel: 1 (one launch per frame); pipeline: 0 */
     float march_ms;            /* queue pipeline with a medium: the ray-march launches summed (rt::pipe_march_kernel: the marches' shadow rays are traced inside it) */
+    /* DirectLighting "weighted" (three megakernel passes + the recurrence; render_ms is all of them): the frame's shading points = calls of
+     * WeightedSampleOneLight, and the ms of the count pass, the scan, the survey pass, the recurrence kernel and the frame pass; zeros otherwise */
+    uint64_t weighted_points;
+    float weighted_ms[5];
 } RtRenderStats;
 /* ImageFilm::WriteImage's normalisation (image.cpp:157-203) of ANY 5-plane accumulator in device memory (planes of n floats each), e.g. the
  * rows of the film a rank owns after a reduce-scatter; rgb[n][3] and alpha[n] stay on the device.  Asynchronous on the scene's stream. */

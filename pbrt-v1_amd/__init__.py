@@ -33,7 +33,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-msse2", "-mfpmath=sse", "-fvisibility=hidden", "-fvisibility-inlines-hidden"]
 
 
-HIP_UNITS = ("rt_kernels.hip", "rt_trace.hip", "rt_mega_w.hip", "rt_mega_d.hip", "rt_mega_p.hip", "rt_pipe_w.hip", "rt_pipe_d.hip",
+HIP_UNITS = ("rt_kernels.hip", "rt_trace.hip", "rt_mega_w.hip", "rt_mega_d.hip", "rt_mega_dw.hip", "rt_mega_p.hip", "rt_pipe_w.hip", "rt_pipe_d.hip",
              "rt_pipe_p.hip", "rt_pipe_v.hip", "rt_march.hip", "kd_build.cpp", "grid_build.cpp")
 
 
@@ -130,10 +130,11 @@ class RtPrebuiltAccel(C.Structure):
 
 class RtRenderStats(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("render_ms", C.c_float), ("trace_ms", C.c_float), ("gather_ms", C.c_float),
-                ("pipeline", C.c_int32), ("iterations", C.c_int32), ("timed_iterations", C.c_int32), ("slots", C.c_uint32), ("shade_ms", C.c_float), ("bands", C.c_int32), ("march_ms", C.c_float)]
+                ("pipeline", C.c_int32), ("iterations", C.c_int32), ("timed_iterations", C.c_int32), ("slots", C.c_uint32), ("shade_ms", C.c_float), ("bands", C.c_int32), ("march_ms", C.c_float),
+                ("weighted_points", C.c_uint64), ("weighted_ms", C.c_float * 5)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        return {n: (list(getattr(self, n)) if n == "weighted_ms" else getattr(self, n)) for n, _ in self._fields_}
 
 
 RAY_DTYPE = np.dtype([("o", np.float32, 3), ("d", np.float32, 3), ("mint", np.float32), ("maxt", np.float32)])

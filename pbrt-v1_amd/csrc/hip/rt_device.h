@@ -93,6 +93,8 @@ struct DevScene {
     RtVolume vol;
 };
 
+#define RT_INTEG_DIRECT_WEIGHTED 3    // device-side template value only: DirectLighting with strategy "weighted" (render_kernel family g_render_kernels_weighted)
+
 struct DevFrame {
     int integrator, max_depth, strategy, volume_integrator;
     float step_size;
@@ -132,6 +134,11 @@ struct DevFrame {
     float *vol_rays, *vol_state, *vol_samp;   // volume scratch (rt_integrate.h), null without a volume
     int vol_nmax;
     unsigned n_threads;
+    // DirectLighting "weighted" (WeightedSampleOneLight transport.cpp:71-122; rt_weighted.h): the frame runs as three passes of the megakernel
+    int weighted_phase;             // 0: not a weighted frame, 1: count the shading points of every sample, 2: survey (every light's estimate), 3: the frame proper
+    unsigned *wt_base;              // [total_work + 1]: pass 1 leaves a sample's shading-point count at [work]; scanned in place to the first ordinal
+    float *wt_rec;                  // [point][1 + 2 * n_lights]: the light-number sample, then per light y(Ld) and y(n_lights * Ld)       (pass 2)
+    float2 *wt_pick;                // [point]: the chosen light (int bits) and lightSampleWeight, 0 = the uniform start-up branch       (recurrence kernel)
 };
 
 // Explicit address spaces.  Pointers that live inside DevScene/DevFrame are loaded from memory, so the compiler cannot

@@ -53,6 +53,10 @@ struct Lane {
     V3 L_all;               // UniformSampleAllLights' L     (transport.cpp:36)
     V3 pend;                // contribution added if the ray in flight confirms it
     float bs1, bs2, bcs;    // BSDF-half sample values of the EstimateDirect in flight
+    // --- DirectLighting "weighted" only (RT_INTEG_DIRECT_WEIGHTED kernels; dead in every other instantiation)
+    uint32_t ord;           // ordinal of the sample's next shading point in the frame's program order (DevFrame.wt_base[work] + points so far)
+    uint32_t ctr0;          // survey pass: the RNG counter at the shading point, every light's estimate starts from it
+    float wt_w;             // frame pass: lightSampleWeight of the light in flight (0: uniform start-up branch)
     // --- control
     int stage;
     bool has_ray;
@@ -552,9 +556,12 @@ RT_DEV bool march_steps(const DevScene &sc, const DevFrame &fr, Lane &ln, const 
 }
 
 // The body of ONE stage.  Returns when the lane has a ray in flight or has changed stage.
-template <bool COUNT, int INTEG, bool VOL, bool EXT, int STAGE, bool DEFER = false, bool PARK = false>
+template <bool COUNT, int INTEG_, bool VOL, bool EXT, int STAGE, bool DEFER = false, bool PARK = false>
 RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigned gtid,
                        unsigned *c_closest, unsigned *c_any, unsigned *c_bad) {
+    // RT_INTEG_DIRECT_WEIGHTED: DirectLighting with strategy "weighted", a kernel family of its own so that the all / one kernels keep their code
+    constexpr bool WEIGHTED = INTEG_ == RT_INTEG_DIRECT_WEIGHTED;
+    constexpr int INTEG = WEIGHTED ? int(RT_INTEGRATOR_DIRECT) : INTEG_;
     if constexpr (STAGE == ST_VERTEX) {
         if (COUNT) ++*c_closest;
         const bool hit = ln.tv.hit_prim >= 0;
@@ -591,6 +598,29 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
     }
     if constexpr (STAGE == ST_DIRECT_NEXT) {
         const int nLights = int(sc.n_lights);
+        if constexpr (WEIGHTED) {
+            // WeightedSampleOneLight transport.cpp:71-122, sample offsets of directlighting.cpp:54-64 -- see rt_weighted.h for the three passes
+            if (nLights == 0) { ln.stage = ST_SPECULAR; return; }                                   // directlighting.cpp:106
+            if (fr.weighted_phase == 1) { ++ln.ord; ln.stage = ST_SPECULAR; return; }             // count: the specular tree alone
+            if (fr.weighted_phase == 3 && ln.li > 0) { ln.stage = ST_SPECULAR; return; }
+            if (fr.weighted_phase == 2) {
+                if (ln.li == 0) ln.ctr0 = ln.rng.ctr;
+                if (ln.li >= nLights) { ++ln.ord; ln.stage = ST_SPECULAR; return; }                // (the counter stands where one estimate leaves it)
+                ln.rng.ctr = ln.ctr0;
+            }
+            const float ls1 = dim_value(fr, ln, fr.two_d[0], 0, 0), ls2 = dim_value(fr, ln, fr.two_d[0], 0, 1);
+            ln.bs1 = dim_value(fr, ln, fr.two_d[1], 0, 0); ln.bs2 = dim_value(fr, ln, fr.two_d[1], 0, 1);
+            ln.bcs = dim_value(fr, ln, fr.one_d[1], 0, 0);
+            if (fr.weighted_phase == 2) {
+                if (ln.li == 0) RT_GPTR(float, fr.wt_rec)[size_t(ln.ord) * size_t(1 + 2 * nLights)] = dim_value(fr, ln, fr.one_d[0], 0, 0);
+                estimate_direct_begin<EXT, DEFER>(sc, ln, ln.li, ls1, ls2);
+            } else {
+                const float2 pick = RT_GPTR(const float2, fr.wt_pick)[ln.ord++];
+                ln.li = 1; ln.wt_w = pick.y;
+                estimate_direct_begin<EXT, DEFER>(sc, ln, __float_as_int(pick.x), ls1, ls2);
+            }
+            return;
+        }
         if (INTEG == RT_INTEGRATOR_PATH || (INTEG == RT_INTEGRATOR_DIRECT && fr.strategy == RT_STRATEGY_ONE)) {
             // UniformSampleOneLight transport.cpp:51-70
             if (nLights == 0 || ln.li > 0) { ln.stage = (INTEG == RT_INTEGRATOR_PATH) ? ST_BOUNCE : ST_SPECULAR; return; }
@@ -682,6 +712,19 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
     }
     if constexpr (STAGE == ST_ED_DONE) {
         const int nLights = int(sc.n_lights);
+        if constexpr (WEIGHTED) {
+            if (fr.weighted_phase == 2) {                                       // survey: what L.y() would be had this light been the chosen one
+                float RT_G *rec = RT_GPTR(float, fr.wt_rec) + size_t(ln.ord) * size_t(1 + 2 * nLights) + 1 + 2 * ln.li;
+                rec[0] = lum_y(ln.Ld);                                          // transport.cpp:113 (weighted branch)
+                rec[1] = lum_y(ln.Ld * float(nLights));                         // transport.cpp:95  (start-up branch: L = nLights * EstimateDirect)
+                ++ln.li; ln.stage = ST_DIRECT_NEXT;
+            } else {
+                if (ln.wt_w == 0.f) ln.L = ln.L + ln.Ld * float(nLights);       // UniformSampleOneLight transport.cpp:66-69
+                else ln.L = ln.L + div_s(ln.Ld, ln.wt_w);                       // L /= lightSampleWeight transport.cpp:118
+                ln.stage = ST_SPECULAR;
+            }
+            return;
+        }
         if (INTEG == RT_INTEGRATOR_PATH) {
             ln.L = ln.L + ln.thr * (ln.Ld * float(nLights));                    // path.cpp:99-110
             ln.stage = ST_BOUNCE;
@@ -792,7 +835,8 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
         return;
     }
     if constexpr (STAGE == ST_FINISH) {
-        sample_write(fr, ln, ln.L, ln.alpha, *c_bad);
+        if (WEIGHTED && fr.weighted_phase == 1) RT_GPTR(unsigned, fr.wt_base)[ln.work] = ln.ord;       // (ord started at 0: the sample's shading points)
+        if (!WEIGHTED || fr.weighted_phase == 3) sample_write(fr, ln, ln.L, ln.alpha, *c_bad);
         ln.stage = ST_FETCH;
         return;
     }
@@ -818,15 +862,16 @@ RT_DEV bool stage_in_phase(int stage, int phase) {
 }
 // PARK (queue pipeline with a medium): only the head of a ray march is run here (march_begin) -- the lane then sits in ST_VOL_STEP without a ray
 // and its steps are run by rt::pipe_march_kernel (rt_pipe_march.h), which hands it back in ST_POP.
-template <bool COUNT, int INTEG, bool VOL, bool EXT, bool DEFER = false, bool PARK = false>
+template <bool COUNT, int INTEG_, bool VOL, bool EXT, bool DEFER = false, bool PARK = false>
 RT_DEV void advance_pass(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigned gtid,
                          unsigned *c_closest, unsigned *c_any, unsigned *c_bad, int phase) {
+    constexpr int INTEG = INTEG_ == RT_INTEG_DIRECT_WEIGHTED ? int(RT_INTEGRATOR_DIRECT) : INTEG_;
 #ifdef RT_PROFILE_STAGES
 #define RT_RUN(S) { const unsigned long long m_ = __ballot(!ln.has_ray && ln.stage == S); if (m_) { const unsigned long long t_ = __builtin_readcyclecounter(); \
-        if (!ln.has_ray && ln.stage == S) stage_body<COUNT, INTEG, VOL, EXT, S, DEFER, PARK>(sc, fr, ln, gtid, c_closest, c_any, c_bad); \
+        if (!ln.has_ray && ln.stage == S) stage_body<COUNT, INTEG_, VOL, EXT, S, DEFER, PARK>(sc, fr, ln, gtid, c_closest, c_any, c_bad); \
         if (__lane_id() == 0) { atomicAdd(fr.counters + 24 + 2 * S, __builtin_readcyclecounter() - t_); atomicAdd(fr.counters + 24 + 2 * S + 1, (unsigned long long)__popcll(m_) | (1ull << 40)); } } }
 #else
-#define RT_RUN(S) if (!ln.has_ray && ln.stage == S) stage_body<COUNT, INTEG, VOL, EXT, S, DEFER, PARK>(sc, fr, ln, gtid, c_closest, c_any, c_bad)
+#define RT_RUN(S) if (!ln.has_ray && ln.stage == S) stage_body<COUNT, INTEG_, VOL, EXT, S, DEFER, PARK>(sc, fr, ln, gtid, c_closest, c_any, c_bad)
 #endif
     if (phase != 0) {
         RT_RUN(ST_MIS_DONE);

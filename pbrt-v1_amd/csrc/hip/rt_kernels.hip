@@ -15,6 +15,7 @@
 #include "rt_pipeline.h"
 #include "rt_pipe_vertex.h"
 #include "rt_pipe_march.h"
+#include "rt_weighted.h"
 #include "rt_internal.h"
 #include <cstdio>
 #include <cstdlib>
@@ -568,7 +569,7 @@ static const char *knob(const char *name) {
 // high-occupancy flavour, 12 + VOL*2 + ACCEL for the timed kernels with the glossy (plastic) lobes and quadric slots compiled in
 // (EXT: powf and the second lobe cost ~17 VGPRs, one wave per SIMD less for DirectLighting).  `variant` keeps round 1's numbering:
 // ((VOL*2 + ACCEL)*2 + COUNT)*3 + INTEG | 24 + (VOL*2 + ACCEL)*3 + INTEG | 36 + (VOL*2 + ACCEL)*3 + INTEG.
-namespace rt { extern const RenderKernelFn g_render_kernels_whitted[16], g_render_kernels_direct[16], g_render_kernels_path[16]; }
+namespace rt { extern const RenderKernelFn g_render_kernels_whitted[16], g_render_kernels_direct[16], g_render_kernels_path[16], g_render_kernels_weighted[8]; }
 namespace rt { extern const PipeShadeFn g_pipe_shade_whitted[6], g_pipe_shade_direct[6], g_pipe_shade_path[6]; extern const PipeTraceFn g_pipe_trace[8]; extern const PipeShadeFn g_pipe_vertex[3];
                extern const PipeMarchFn g_pipe_march[6]; }
 static RenderKernelFn render_kernel_of(int variant) {
@@ -610,6 +611,13 @@ struct RtScene {
     float *frames = nullptr; size_t frames_floats = 0;
     unsigned grid = 0, n_threads = 0;
     unsigned grids[48] = {0};          // resident grid per render_kernel<COUNT, INTEG> instantiation
+    unsigned wgrids[8] = {0};          // ... of the DirectLighting "weighted" family (rt_mega_dw.hip)
+    int light_draws = 0;               // RandomFloat()s one EstimateDirect draws: the same for every light (0 / 1), or -1 when the lights differ
+    unsigned *wt_base = nullptr; size_t wt_base_cap = 0; float *wt_rec = nullptr; size_t wt_rec_cap = 0; float2 *wt_pick = nullptr; size_t wt_pick_cap = 0;
+    unsigned long long *wt_sums = nullptr;                     // per-block sums of the point-count scan
+    unsigned long long *wt_total = nullptr;                    // page-locked: the frame's shading points (weighted_scan_top_kernel)
+    unsigned long long wt_points = 0; bool last_weighted = false;
+    hipEvent_t wt_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     DevScene *dev_scene = nullptr; DevFrame *dev_frame = nullptr;   // descriptors in HBM (read with scalar loads)
     float4 *samples = nullptr; size_t samples_cap = 0;          // per-shard sample buffer
     int samples_spp = 1;
@@ -1290,6 +1298,10 @@ static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel 
     }
     if ((rc = upload(s, lights.data(), lights.size(), &s->dev.lights))) return rc;
     if ((rc = upload(s, ltris.data(), ltris.size(), &s->dev.light_tris))) return rc;
+    for (uint32_t i = 0; i < d->n_lights; ++i) {           // ShapeSet::Sample (shape.h:115-121) draws one RandomFloat() when the emitter has several triangles
+        const int draws = (d->lights[i].type == RT_LIGHT_AREA && d->lights[i].quadric_plus1 == 0 && d->lights[i].n_tris > 1) ? 1 : 0;
+        if (i == 0) s->light_draws = draws; else if (draws != s->light_draws) s->light_draws = -1;
+    }
 
     s->dev.n_tris = d->n_tris; s->dev.n_lights = d->n_lights;
     s->dev.accel_kind = s->accel_kind;
@@ -1309,6 +1321,12 @@ static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel 
             if (per_cu < 1) per_cu = 1;
             s->grids[k] = unsigned(prop.multiProcessorCount) * unsigned(per_cu);
             mx = s->grids[k] > mx ? s->grids[k] : mx;
+        }
+        for (int k = 0; k < 8; ++k) {
+            int per_cu = 0;
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)g_render_kernels_weighted[k], RT_BLOCK, 0));
+            s->wgrids[k] = unsigned(prop.multiProcessorCount) * unsigned(per_cu < 1 ? 1 : per_cu);
+            mx = s->wgrids[k] > mx ? s->wgrids[k] : mx;
         }
         s->grid = mx;
     }
@@ -1356,6 +1374,12 @@ int rt_scene_destroy(RtScene *s) {
     if (s->samples) HIPWARN(hipFree(s->samples));
     if (s->resolve_buf) HIPWARN(hipFree(s->resolve_buf));
     if (s->vol_buf) HIPWARN(hipFree(s->vol_buf));
+    if (s->wt_base) HIPWARN(hipFree(s->wt_base));
+    if (s->wt_rec) HIPWARN(hipFree(s->wt_rec));
+    if (s->wt_pick) HIPWARN(hipFree(s->wt_pick));
+    if (s->wt_total) HIPWARN(hipHostFree(s->wt_total));
+    if (s->wt_sums) HIPWARN(hipFree(s->wt_sums));
+    for (hipEvent_t e : s->wt_ev) if (e) HIPWARN(hipEventDestroy(e));
     HIPWARN(hipFree(s->dev_scene)); HIPWARN(hipFree(s->dev_frame));
     HIPWARN(hipFree(s->pool.state)); HIPWARN(hipFree(s->pool.ray_o)); HIPWARN(hipFree(s->pool.hit)); HIPWARN(hipFree(s->pool.q_o));
     HIPWARN(hipFree(s->pool.q_slot)); HIPWARN(hipFree(s->pool.q_count)); HIPWARN(hipFree(s->pool.wave_work)); HIPWARN(hipFree(s->dev_pool));
@@ -1552,6 +1576,7 @@ static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool nee
         if (fr.max_depth > 250 || fr.max_depth < 0) fr.pipeline = 0;     // the slot's control word holds depth in 8 bits
         for (int i = 0; i < fr.n2d; ++i) if (fr.two_d[i].n >= 65535) fr.pipeline = 0;         // ... and the light / sample cursors in 16 bits each
         if (s->dev.n_lights >= 65535u) fr.pipeline = 0;
+        if (rd->integrator == RT_INTEGRATOR_DIRECT && rd->strategy == RT_STRATEGY_WEIGHTED) fr.pipeline = 0;    // three megakernel passes (rt_weighted.h)
         if (fr.shard_count == 1 && !fr.pipeline) {
             // One shard: the tiles partition nothing, and the megakernel then renders the sample extent in scanline order.  2-D tiles pad the extent to
             // whole tiles and every dropped padding item idles a lane for about a ray's time: 64 x 64 tiles cost C3 5 % of its frame
@@ -1694,6 +1719,15 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
     if (rd->max_depth < 0) return fail(RT_EINVAL, "rt_render: negative maxdepth");
     if (!rd->filter_table) return fail(RT_EINVAL, "rt_render: no filter table");
     DevFrame fr; int rc = make_frame(s, rd, fr, true); if (rc) return rc;
+    const bool weighted = rd->integrator == RT_INTEGRATOR_DIRECT && rd->strategy == RT_STRATEGY_WEIGHTED;
+    if (rd->integrator == RT_INTEGRATOR_DIRECT && (rd->strategy < RT_STRATEGY_ALL || rd->strategy > RT_STRATEGY_WEIGHTED)) return fail(RT_EINVAL, "rt_render: unknown direct lighting strategy");
+    if (weighted) {                                           // WeightedSampleOneLight: rt_weighted.h
+        if (fr.shard_count != 1) return fail(RT_EINVAL, "rt_render: strategy \"weighted\" is a recurrence over the whole frame in the sampler's order (transport.cpp:71-122): one shard only");
+        if (s->light_draws < 0) return fail(RT_EINVAL, "rt_render: strategy \"weighted\" needs lights that draw the same number of random numbers per estimate "
+                                                       "(emitters of several triangles draw one, ShapeSet::Sample shape.h:115-121; every other light none): this scene mixes them");
+        if (s->dev.n_lights > 2048u) return fail(RT_EINVAL, "rt_render: strategy \"weighted\" holds the per-light tables of its recurrence in LDS: at most 2048 lights");
+        if (fr.total_work >= 0xffffffffull) return fail(RT_EINVAL, "rt_render: strategy \"weighted\": more than 2^32 - 2 camera samples in the frame");
+    }
     const bool skip_film = knob("PBRT_HIP_DEBUG_NOFILM") != nullptr;   // perf experiments only
     const int grx = int(std::floor(fr.fxw + 0.5f)), gry = int(std::floor(fr.fyw + 0.5f));   // reach of a sample pixel: |x - sx| <= w + .5
     const size_t col_bytes = size_t(fr.spp * 2 + 1) * sizeof(float4);
@@ -1783,6 +1817,7 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
     };
     if (fr.pipeline) {
         rc = render_pipeline(s, rd, fr, vol_levels, vol_nmax, vol_samp_words); if (rc) return rc;
+        s->last_weighted = false;
     } else {
         if (rd->integrator != RT_INTEGRATOR_PATH) {           // recursion frames for whitted / directlighting
             rc = ensure(s, &s->frames, &s->frames_floats, size_t(rd->max_depth + 2) * RT_FRAME_WORDS * s->n_threads); if (rc) return rc;
@@ -1797,6 +1832,54 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
         if (fr.high_occupancy && !s->counting) variant = 24 + ((s->volume.present ? 1 : 0) * 2 + (s->accel_kind == RT_ACCEL_GRID ? 1 : 0)) * 3 + rd->integrator;
         if (s->has_ext && !s->counting) variant = 36 + ((s->volume.present ? 1 : 0) * 2 + (s->accel_kind == RT_ACCEL_GRID ? 1 : 0)) * 3 + rd->integrator;
         if (s->grids[variant] == 0) return fail(RT_ESTATE, "render kernel variant has no resident grid");
+        fr.weighted_phase = 0; fr.wt_base = nullptr; fr.wt_rec = nullptr; fr.wt_pick = nullptr;
+        if (weighted) {
+            // rt_weighted.h: count -> scan -> survey -> recurrence -> the frame.  ev0 .. ev1 bracket all of it (kernel_ms of a weighted frame is the five together)
+            const int wk = ((s->volume.present ? 1 : 0) * 2 + (s->accel_kind == RT_ACCEL_GRID ? 1 : 0)) * 2 + (s->counting ? 1 : 0);
+            const int nL = int(s->dev.n_lights), R = 1 + 2 * nL;
+            if (!s->wt_total) { HIPCHK(hipHostMalloc((void **)&s->wt_total, sizeof(unsigned long long), hipHostMallocDefault)); HIPCHK(hipMalloc((void **)&s->wt_sums, RT_WSCAN_BLOCKS * sizeof(unsigned long long))); for (hipEvent_t &e : s->wt_ev) HIPCHK(hipEventCreate(&e)); }
+            rc = ensure(s, &s->wt_base, &s->wt_base_cap, size_t(fr.total_work) + 1); if (rc) return rc;
+            fr.wt_base = s->wt_base;
+            auto pass = [&](int phase) -> int {
+                fr.weighted_phase = phase;
+                HIPCHK(hipMemcpyAsync(s->dev_frame, &fr, sizeof(DevFrame), hipMemcpyHostToDevice, s->stream));
+                HIPCHK(hipMemsetAsync(s->work_counter, 0, 64 * sizeof(unsigned long long), s->stream));
+                hipLaunchKernelGGL(g_render_kernels_weighted[wk], dim3(s->wgrids[wk]), dim3(RT_BLOCK), 0, s->stream, (const DevScene *)s->dev_scene, (const DevFrame *)s->dev_frame);
+                HIPCHK(hipGetLastError());
+                return RT_OK;
+            };
+            HIPCHK(hipEventRecord(s->ev0, s->stream));
+            if ((rc = pass(1))) return rc;
+            HIPCHK(hipEventRecord(s->wt_ev[0], s->stream));
+            hipLaunchKernelGGL(weighted_scan_sums_kernel, dim3(RT_WSCAN_BLOCKS), dim3(RT_WSCAN_THREADS), 0, s->stream, (const unsigned *)s->wt_base, (unsigned long long)fr.total_work, s->wt_sums);
+            hipLaunchKernelGGL(weighted_scan_top_kernel, dim3(1), dim3(RT_WSCAN_THREADS), 0, s->stream, s->wt_base, (unsigned long long)fr.total_work, s->wt_sums, s->wt_total);
+            hipLaunchKernelGGL(weighted_scan_apply_kernel, dim3(RT_WSCAN_BLOCKS), dim3(RT_WSCAN_THREADS), 0, s->stream, s->wt_base, (unsigned long long)fr.total_work, (const unsigned long long *)s->wt_sums);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(s->wt_ev[1], s->stream));
+            HIPCHK(hipStreamSynchronize(s->stream));
+            const unsigned long long n_points = *s->wt_total;
+            if (n_points >= 0xffffffffull) return fail(RT_EINVAL, "rt_render: strategy \"weighted\": more than 2^32 - 2 shading points in the frame");
+            s->wt_points = n_points;
+            rc = ensure(s, &s->wt_rec, &s->wt_rec_cap, size_t(n_points) * size_t(R) + 1); if (rc) return rc;
+            rc = ensure(s, &s->wt_pick, &s->wt_pick_cap, size_t(n_points) + 1); if (rc) return rc;
+            fr.wt_rec = s->wt_rec; fr.wt_pick = s->wt_pick;
+            if (n_points > 0) {
+                if ((rc = pass(2))) return rc;
+                HIPCHK(hipEventRecord(s->wt_ev[2], s->stream));
+                // LDS of the recurrence kernel: [state | chunk records | chunk picks] within 64 KB
+                const size_t state_f = nL <= 64 ? 0 : size_t((3 * nL + 2) & ~1);
+                int chunk = int((size_t(64) * 1024 / 4 - state_f - 2) / size_t(R + 2));
+                chunk = chunk > 1024 ? 1024 : chunk < 1 ? 1 : chunk;
+                const size_t lds = (state_f + size_t((chunk * R + 1) & ~1) + size_t(chunk) * 2) * sizeof(float);
+                auto rk = nL <= 64 ? weighted_recurrence_lanes_kernel : weighted_recurrence_lds_kernel;      // light i in lane i | tables in LDS, one lane
+                hipLaunchKernelGGL(rk, dim3(1), dim3(64), lds, s->stream, (const float *)s->wt_rec, s->wt_pick, n_points, nL, chunk);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipEventRecord(s->wt_ev[3], s->stream));
+            } else { HIPCHK(hipEventRecord(s->wt_ev[2], s->stream)); HIPCHK(hipEventRecord(s->wt_ev[3], s->stream)); }
+            if ((rc = pass(3))) return rc;
+            HIPCHK(hipEventRecord(s->ev1, s->stream));
+            s->last_pipeline = false; s->last_weighted = true;
+        } else {
         HIPCHK(hipMemcpyAsync(s->dev_frame, &fr, sizeof(DevFrame), hipMemcpyHostToDevice, s->stream));
         HIPCHK(hipMemsetAsync(s->work_counter, 0, 64 * sizeof(unsigned long long), s->stream));
         HIPCHK(hipEventRecord(s->ev0, s->stream));
@@ -1804,7 +1887,8 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
                            (const DevScene *)s->dev_scene, (const DevFrame *)s->dev_frame);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(s->ev1, s->stream));
-        s->last_pipeline = false;
+        s->last_pipeline = false; s->last_weighted = false;
+        }
     }
     if (!skip_film) { rc = launch_gather((const DevFrame *)s->dev_frame, 0, fr.y_pixel_count); if (rc) return rc; }
     HIPCHK(hipEventRecord(s->ev2, s->stream));
@@ -1916,6 +2000,11 @@ int rt_last_render_stats(RtScene *s, RtRenderStats *out) {
         out->slots = s->pipe_slots;
     } else out->trace_ms = out->render_ms;
     out->bands = s->last_pipeline ? 0 : 1;
+    if (s->last_weighted) {
+        out->weighted_points = s->wt_points;
+        hipEvent_t seq[6] = {s->ev0, s->wt_ev[0], s->wt_ev[1], s->wt_ev[2], s->wt_ev[3], s->ev1};
+        for (int i = 0; i < 5; ++i) HIPCHK(hipEventElapsedTime(&out->weighted_ms[i], seq[i], seq[i + 1]));
+    }
     return RT_OK;
 }
 

@@ -128,6 +128,7 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
                             Ray ray;
                             setup_sample(sc, fr, ln, pixel, s, ray);
                             ln.work = fr.mega_tile > 0 ? uint32_t(pixel * unsigned(fr.spp) + unsigned(s)) : uint32_t(w);
+                            if (INTEG == RT_INTEG_DIRECT_WEIGHTED) ln.ord = fr.weighted_phase == 1 ? 0u : RT_GPTR(const unsigned, fr.wt_base)[ln.work];
                             ln.L = mk3(0.f); ln.thr = mk3(1.f); ln.alpha = 0.f; ln.depth = 0; ln.fsp = 0;
                             ln.specular = false;
                             if (COUNT) ++c_cam;
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
     }
 #endif
 
-    if (COUNT) {
+    if (COUNT && !(INTEG == RT_INTEG_DIRECT_WEIGHTED && fr.weighted_phase != 3)) {       // (a weighted frame's count and survey passes are not Scene::Render's rays)
         unsigned long long v[8] = {c_cam, c_closest, c_any, tc.nodes, tc.leaf_refs, tc.tris, c_bad, tc.spills};
 #pragma unroll
         for (int k = 0; k < 8; ++k) {

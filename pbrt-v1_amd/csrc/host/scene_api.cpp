@@ -215,7 +215,7 @@ SurfaceIntegrator MakeSurfaceIntegrator(const std::string &name, const ParamSet 
     if (void *sym = findPluginSymbol(name, "CreateSurfaceIntegrator")) {            // dynload.cpp:185-199 MakeSurfaceIntegrator
         CParams c{&ps}; PbrtHipSurfaceIntegrator o{};
         if (reinterpret_cast<PbrtHipCreateSurfaceIntegratorFn>(sym)(reinterpret_cast<const PbrtHipParams *>(&c), &kParamsApi, &o) != 0 ||
-            o.kind < RT_INTEGRATOR_WHITTED || o.kind > RT_INTEGRATOR_PATH || (o.strategy != RT_STRATEGY_ALL && o.strategy != RT_STRATEGY_ONE)) {
+            o.kind < RT_INTEGRATOR_WHITTED || o.kind > RT_INTEGRATOR_PATH || (o.strategy < RT_STRATEGY_ALL || o.strategy > RT_STRATEGY_WEIGHTED)) {
             Error("Unable to load plugin \"%s\" (surface integrator)", name.c_str()); *ok = false; si.kind = RT_INTEGRATOR_WHITTED; si.maxDepth = 5;
         } else { si.kind = o.kind; si.maxDepth = o.max_depth; si.strategy = o.strategy; }
         ps.ReportUnused();
@@ -229,16 +229,8 @@ SurfaceIntegrator MakeSurfaceIntegrator(const std::string &name, const ParamSet 
         std::string st = ps.FindOneString("strategy", "all");
         if (st == "one") si.strategy = RT_STRATEGY_ONE;
         else if (st == "all") si.strategy = RT_STRATEGY_ALL;
-        else if (st == "weighted") {
-            // WeightedSampleOneLight (transport.cpp:71-122) picks the light from a CDF of exponentially averaged reflected luminances
-            // that every shading point of the frame updates in program order (avgY / overallAvgY members of the integrator,
-            // directlighting.cpp:75-76): each estimate depends on all earlier ones, the first one of the frame seeds the table.
-            // That is a sequential recurrence over ~10^7 shading points with no parallel (or shard-invariant) definition, so it is
-            // refused rather than replaced by a different estimator.
-            Error("Strategy \"weighted\" for direct lighting is a frame-long sequential recurrence (transport.cpp:71-122) and is not on the "
-                  "accelerated path; use \"all\" or \"one\"");
-            *ok = false; si.strategy = RT_STRATEGY_ONE;
-        } else { Warning("Strategy \"%s\" for direct lighting unknown. Using \"all\".", st.c_str()); si.strategy = RT_STRATEGY_ALL; }
+        else if (st == "weighted") si.strategy = RT_STRATEGY_WEIGHTED;   // WeightedSampleOneLight transport.cpp:71-122: rt_render runs it on one shard (include/pbrt_hip.h)
+        else { Warning("Strategy \"%s\" for direct lighting unknown. Using \"all\".", st.c_str()); si.strategy = RT_STRATEGY_ALL; }
     } else { Error("Unable to load plugin \"%s\" (surface integrator)", name.c_str()); *ok = false; si.kind = RT_INTEGRATOR_WHITTED; }
     ps.ReportUnused();
     return si;

@@ -48,6 +48,11 @@ QUADRICS2 = ('AttributeBegin\nMaterial "matte" "color Kd" [.7 .6 .2]\nTranslate 
              'AttributeBegin\nMaterial "plastic" "color Kd" [.2 .3 .7]\nTranslate 300 330 200\nRotate 40 1 0 1\nScale 60 60 60\nShape "hyperboloid" "point p1" [1 0 -1.2] "point p2" [.8 .9 1.1]\nAttributeEnd\n'
              'AttributeBegin\nMaterial "glass" "float index" [1.3]\nReverseOrientation\nTranslate 120 300 160\nRotate 100 0 1 0\nShape "hyperboloid" "point p1" [40 0 0] "point p2" [20 30 70] "float phimax" [270]\nAttributeEnd\n')
 
+# a second emitter of two triangles next to the Cornell ceiling light (each a ShapeSet: one RandomFloat() per light sample) and a second point light
+MESH_EMITTER = ('AttributeBegin\nAreaLightSource "area" "color L" [3 6 12]\nMaterial "matte" "color Kd" [0 0 0]\n'
+                'Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [20 150 100  20 150 300  20 350 300  20 350 100]\nAttributeEnd\n')
+POINT2 = 'LightSource "point" "point from" [100 300 100] "color I" [150000 250000 150000]\n'
+
 def _mesh(mat, xf, **kw):
     return "AttributeBegin\n%s\n%s\n%sAttributeEnd\n" % (mat, xf, scenes.smooth_mesh_text(**kw))
 
@@ -143,6 +148,17 @@ CONFIGS = {
     "ortho_path": dict(xres=32, yres=32, integrator="path", xsamples=2, ysamples=2),
     "env_whitted": dict(xres=48, yres=24, integrator="whitted", world_kwargs=dict(point_light=True)),
     "env_path": dict(xres=32, yres=16, integrator="path", xsamples=2, ysamples=2, jitter=True),
+    # DirectLighting "weighted" (WeightedSampleOneLight transport.cpp:71-122): the frame-long recurrence over every shading point in program order
+    "weighted_delta3_glass": dict(xres=40, yres=40, integrator="directlighting", integrator_params='"string strategy" ["weighted"]', xsamples=2, ysamples=1, jitter=True,
+                                  world_kwargs=dict(point_light=True, area_light=False, extra=SPOT + DISTANT, mirror_quad=True, glass_sphere_tris=blob)),
+    "weighted_qlights_point": dict(xres=32, yres=32, integrator="directlighting", integrator_params='"string strategy" ["weighted"]', xsamples=2, ysamples=2, jitter=True,
+                                   world_kwargs=dict(point_light=True, area_light=False, extra=QLIGHTS, mirror_quad=True)),
+    "weighted_mesh_emitters": dict(xres=40, yres=40, integrator="directlighting", integrator_params='"string strategy" ["weighted"]', xsamples=2, ysamples=1, jitter=True,
+                                   world_kwargs=dict(extra=MESH_EMITTER, glass_sphere_tris=blob)),
+    "weighted_one_light": dict(xres=32, yres=32, integrator="directlighting", integrator_params='"string strategy" ["weighted"]'),
+    "weighted_ld_six_lights_soup": dict(xres=32, yres=32, integrator="directlighting", integrator_params='"string strategy" ["weighted"]', maxdepth=3, sampler="lowdiscrepancy",
+                                        pixelsamples=4, soup_tris=800, soup_materials=True,
+                                        world_kwargs=dict(point_light=True, area_light=False, extra=SPOT + DISTANT + SPOT_XF + DISTANT_XF + POINT2)),
     "whitted_orennayar_triangle": dict(xres=32, yres=32, integrator="whitted", pixel_filter="triangle",
                                        world_kwargs=dict(point_light=True)),
 }

@@ -108,12 +108,14 @@ def test_f4_plugins_are_accepted(pkg):
 
 def test_reference_features_off_the_path_invalidate_the_frame(pkg):
     """Nothing is silently replaced by something else: the reference's default sampler
-    (bestcandidate, api.cpp:62-71) and the "weighted" light strategy (transport.cpp:71-122) are Errors that leave the frame
-    invalid, exactly like an unknown plugin."""
+    (bestcandidate, api.cpp:62-71) is an Error that leaves the frame invalid, exactly like an unknown plugin.  The "weighted" light
+    strategy (transport.cpp:71-122) parses since round 4: rt_render runs its recurrence on the device (tests/test_gpu_weighted.py)."""
     ps = pkg.ParsedScene(text=(BASE % ("", 'LightSource "point"\n' + TRI)).replace('Sampler "stratified"\n', ""))
     assert not ps.valid and ps.errors >= 1
     ps = pkg.ParsedScene(text=BASE % ('SurfaceIntegrator "directlighting" "string strategy" ["weighted"]', 'LightSource "point"\n' + TRI))
-    assert not ps.valid and ps.errors >= 1
+    assert ps.valid and ps.errors == 0 and ps.warnings == 0 and ps.render_view()["strategy"] == 2
+    ps = pkg.ParsedScene(text=BASE % ('SurfaceIntegrator "directlighting" "string strategy" ["wieghted"]', 'LightSource "point"\n' + TRI))
+    assert ps.valid and ps.warnings == 1 and ps.render_view()["strategy"] == 0          # unknown strategy: Warning, "all" (directlighting.cpp:203-206)
     ps = pkg.ParsedScene(text=BASE % ('SurfaceIntegrator "directlighting" "string strategy" ["one"]', 'LightSource "point"\n' + TRI))
     assert ps.valid and ps.errors == 0 and ps.warnings == 0
 
