@@ -156,7 +156,9 @@ enum { RT_INTEGRATOR_WHITTED = 0, RT_INTEGRATOR_DIRECT = 1, RT_INTEGRATOR_PATH =
 enum { RT_STRATEGY_ALL = 0, RT_STRATEGY_ONE = 1, RT_STRATEGY_WEIGHTED = 2 };
 /* RT_STRATEGY_WEIGHTED: WeightedSampleOneLight (transport.cpp:71-122), a recurrence over every shading point of the frame in program order.
  * rt_render accepts it on one shard (shard_count == 1) for scenes whose lights all draw the same number of random numbers per estimate
- * (any mix of point / spot / distant / single-triangle / quadric emitters, or only emitters of several triangles) and at most 2048 lights. */
+ * (any mix of point / spot / distant / single-triangle / quadric emitters, or only emitters of several triangles) and at most 2048 lights.
+ * Such a frame is five launches (RtRenderStats.weighted_ms); rt_render waits on the stream once in the middle of it, for the number of shading
+ * points that sizes the survey's tables (every other frame is asynchronous from the first launch on). */
 enum { RT_VOLUME_NONE = 0, RT_VOLUME_EMISSION = 1, RT_VOLUME_SINGLE = 2 };
 enum { RT_SAMPLER_STRATIFIED = 0, RT_SAMPLER_LOWDISCREPANCY = 1, RT_SAMPLER_RANDOM = 2 };
 

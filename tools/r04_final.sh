@@ -3,7 +3,7 @@
 export PBRT_HIP_TUNE=1
 ulimit -c 0
 cd $GRAFT_REPO_ROOT
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r04_final4; mkdir -p $OUT
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r04_final5; mkdir -p $OUT
 for wl in c3 p1000000 c4 c2 c5; do
   ROUND=r04 bash tools/profile.sh $wl --publish > $OUT/profile_$wl.log 2>&1
   tail -c 600 $OUT/profile_$wl.log
