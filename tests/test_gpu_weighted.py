@@ -4,7 +4,7 @@ The strategy is a recurrence over EVERY shading point of the frame in program or
 rest of the frame.  The five reference films tests/golden/weighted_*.npz (1, 2, 3, 4 and 6 lights; delta, quadric and two-triangle emitters; glass and
 mirror recursion; stratified and low-discrepancy samplers) are covered by test_gpu_parity.py::test_device_film_matches_reference_golden.  Here:
 larger seeded frames against the oracle (whose "weighted" is pinned by those five films, tests/test_oracle_golden.py), the timed kernels against
-their counting twins, the LDS-table path of the recurrence kernel (40 lights), a medium, the grid, the frames the device refuses."""
+their counting twins, both forms of the recurrence kernel (40 lights in lanes, 70 in LDS tables), a medium, the grid, the frames the device refuses."""
 import numpy as np
 import pytest
 from test_gpu_parity import need_gpu, check_film
@@ -34,6 +34,10 @@ CASES = {
                                    world_kwargs=dict(extra=EMITTER2)),
     "forty_points_ld": dict(xres=64, yres=64, sampler="lowdiscrepancy", pixelsamples=4, soup_tris=500, soup_materials=True,
                             world_kwargs=dict(area_light=False, extra=many_points(40))),
+    "seventy_points": dict(xres=48, yres=48, xsamples=2, ysamples=1, jitter=True, soup_tris=300, soup_materials=True,              # > 64 lights: the recurrence's LDS form
+                           world_kwargs=dict(area_light=False, extra=many_points(70, 11))),
+    "delta4_soup200k_256": dict(xres=256, yres=256, xsamples=2, ysamples=2, jitter=True, soup_tris=200000, soup_materials=True,      # 0.4 M shading points: many LDS chunks, every scan block
+                                world_kwargs=dict(point_light=True, area_light=False, extra=SPOT + DISTANT + many_points(1, 2))),
     "grid_four_lights": dict(xres=64, yres=64, xsamples=2, ysamples=1, accelerator="grid", soup_tris=2000,
                              world_kwargs=dict(point_light=True, area_light=False, extra=SPOT + DISTANT + many_points(1, 9), mirror_quad=True)),
     "medium_two_points": dict(xres=32, yres=32, xsamples=2, ysamples=1, jitter=True, volume_integrator='"single" "float stepsize" [80]',
