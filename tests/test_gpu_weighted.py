@@ -75,6 +75,23 @@ def test_weighted_frame_matches_the_oracle(pkg, scenes, oracle, case):
     ds.close()
 
 
+def test_weighted_against_the_live_reference_when_present(pkg, scenes):
+    """The compiled reference travels to the GPU box (oracle/_ref): one "weighted" frame that is in no fixture, rendered by both, live -- the device
+    against the reference itself, the oracle not in the loop.  Delta lights only: every estimate is bit-reproducible, so the recurrences cannot part."""
+    need_gpu(pkg)
+    import __graft_entry__ as g_entry
+    text = scenes.cornell_scene(xres=80, yres=64, xsamples=2, ysamples=2, jitter=True, soup_tris=6000, soup_materials=True, keyed=True, count=True, seed=23,
+                                integrator="directlighting", integrator_params=W, maxdepth=4,
+                                world_kwargs=dict(point_light=True, area_light=False, extra=SPOT + DISTANT + many_points(2, 31), mirror_quad=True))
+    try:
+        ref_rgb, ref_alpha, st = g_entry.load_ref_runner().run_reference(text, keyed=True)
+    except FileNotFoundError:
+        pytest.skip("oracle/_ref not on this box")
+    rgb, alpha, cnt, _ = pkg.render_text(text)
+    check_film("weighted:live", rgb, alpha, ref_rgb, ref_alpha, 1)
+    assert cnt["closest_rays"] == st["closest_rays"] and cnt["any_rays"] == st["any_rays"]
+
+
 def test_weighted_is_the_references_estimator_including_its_scale(pkg, scenes):
     """What the reference computes, not what one might expect of it: SampleStep1d's pdf (mc.cpp:51) is a DENSITY over [0, 1) -- a light is chosen with
     probability pdf / nLights -- and transport.cpp:118 divides the estimate by that density, so a converged "weighted" image is the direct lighting
