@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Build a variant of libpbrt_hip.so next to the product library for A/B measurements in ONE gpurun call.
 
-    python tools/build_variant.py NAME [-DKNOB=V ...] [--units rt_trace.hip,rt_mega_p.hip]
+    python tools/build_variant.py NAME [-DKNOB=V ...] [--mllvm OPT ...] [--units rt_trace.hip,rt_mega_p.hip]
 
 compiles the listed translation units (default: all) with the extra defines into pbrt-v1_amd/lib/obj_NAME/, takes the others
 from the product build (pbrt-v1_amd/lib/obj/), and links pbrt-v1_amd/lib/libpbrt_hip_NAME.so.  A process picks it with
@@ -17,6 +17,9 @@ def main():
     pkg = entry.load_package()
     name = sys.argv[1]
     defines = [a for a in sys.argv[2:] if a.startswith("-D")]
+    for i, a in enumerate(sys.argv):                              # --mllvm OPT: a code generation option for the device compiler (scheduling experiments)
+        if a == "--mllvm":
+            defines += ["-mllvm", sys.argv[i + 1]]
     units = list(pkg.HIP_UNITS)
     for i, a in enumerate(sys.argv):
         if a == "--units":
