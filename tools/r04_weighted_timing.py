@@ -10,6 +10,11 @@ SPOT = 'LightSource "spot" "point from" [278 540 100] "point to" [200 0 330] "co
 DISTANT = 'LightSource "distant" "point from" [0.3 1 -0.8] "point to" [0 0 0] "color L" [1.5 1.6 2.0]\n'
 POINT2 = 'LightSource "point" "point from" [100 300 100] "color I" [150000 250000 150000]\n'
 n_tris = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+n_more = int(sys.argv[2]) if len(sys.argv) > 2 else 0          # extra point lights (how the recurrence's cost per point grows with the number of lights)
+if n_more:
+    rng = np.random.default_rng(5)
+    POINT2 += "".join('LightSource "point" "point from" [%.1f %.1f %.1f] "color I" [%.0f %.0f %.0f]\n' % (*rng.uniform((40, 60, 40), (510, 520, 500)), *rng.uniform(20000, 160000, 3))
+                      for _ in range(n_more))
 for strat in ("one", "all", "weighted"):
     text = scenes.cornell_scene(xres=1024, yres=1024, xsamples=2, ysamples=2, jitter=True, keyed=True, integrator="directlighting",
                                 integrator_params='"string strategy" ["%s"]' % strat, soup_tris=n_tris, soup_materials=True,
