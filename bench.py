@@ -27,6 +27,10 @@ Prints ONE JSON line on rank 0 (see the contract in the task description) includ
                  for the other BASELINE configs at the size one GPU holds: C2, the 1 M-triangle path frame
                  (the north star's case), C4 (1 M triangles, material mix, path depth 8), C5 (SURVEY 8d inputs: 64 spp, stepsize 20, g 0).
                  `roofline.frac` is priced on the dominant kernel alone; `frac_frame_kernels` on every kernel of the frame.
+                 (N > 1) the configurations BASELINE.json states for several GPUs, each with `per_rank`: C4 as stated (10 M triangles,
+                 2048 x 2048 @ 256 spp) at 8 ranks, C5 at 4 and 8 ranks (--multi-workloads).
+N > 1 merge per frame: rt_film_pack_parts, ONE reduce-scatter (chunk r = the 5 planes of rank r's film rows), rt_film_resolve_device_rgba
+on those rows, ONE all-gather of RGBA rows.
 """
 from __future__ import annotations
 
@@ -63,6 +67,11 @@ def workload(name: str):
         text = scenes.cornell_scene(xres=640, yres=426, integrator="path", maxdepth=8, xsamples=2, ysamples=2, jitter=True, pixel_filter="mitchell",   # 426 rows: not a multiple of 8
                                     soup_tris=3000, soup_materials=True)
         label = "test frame: Cornell + 3000-triangle soup, matte/glass/mirror mix, path depth 8, 640x426 @ 4 spp"
+        crop = (0.4, 0.6, 0.4, 0.6)
+    elif name == "t5":                  # tests/test_multirank_gpu.py: C5's kind of frame (homogeneous medium, single scattering: the queue pipeline with the march kernel)
+        text = scenes.cornell_scene(xres=320, yres=214, integrator="directlighting", xsamples=2, ysamples=2, jitter=True, pixel_filter="mitchell", soup_tris=3000,
+                                    volume_integrator='"single" "float stepsize" [20]', world_kwargs=dict(volume='"float g" [0]'))
+        label = "test frame: Cornell + 3000-triangle soup in a homogeneous medium, single scattering + DirectLighting, 320x214 @ 4 spp"
         crop = (0.4, 0.6, 0.4, 0.6)
     elif name == "c1":
         text = scenes.cornell_scene(xres=512, yres=512, integrator="whitted", xsamples=1, ysamples=1, jitter=False,
@@ -224,13 +233,23 @@ def run_workload(name, args, pkg, torch, dist, world, rank, device_index, steps,
     #   reduce_scatter  (default) row-wise reduce-scatter per plane, every rank resolves ITS rows (rt_film_resolve_device), one all-gather of
     #                   the resolved rows (4 floats per pixel instead of 5, 1/N of the normalisation per rank).
     merge = args.merge if dist is not None else "none"
+    emulate = emu if (emu > 1 and world == 1) else 0            # one GPU renders rank 0's share of an `emu`-rank job AND runs the merge's own kernels (no collective)
+    if emulate and merge == "none":
+        merge = "reduce_scatter"
+    mworld = emulate or world
     H, W = ps.height, ps.width
     if merge == "reduce_scatter":
-        rows = (H + world - 1) // world
-        pad = torch.zeros((5, rows * world, W), dtype=torch.float32, device="cuda")
+        # ONE reduce-scatter + ONE all-gather per frame (round 5; rounds 3-4: one reduce-scatter per plane, two all-gathers and a padding copy):
+        # rt_film_pack_parts lays the rank's film out as `world` parts of `rows` film rows, part r = [5][rows][W] = everything rank r resolves;
+        # rt_film_resolve_device_rgba turns the summed part into RGBA rows, which one all-gather hands to everybody.
+        rows = (H + mworld - 1) // mworld
+        send = torch.zeros((mworld, 5, rows, W), dtype=torch.float32, device="cuda")
         part = torch.zeros((5, rows, W), dtype=torch.float32, device="cuda")
-        rgb_part = torch.zeros((rows, W, 3), dtype=torch.float32, device="cuda"); alpha_part = torch.zeros((rows, W), dtype=torch.float32, device="cuda")
-        rgb_all = torch.zeros((rows * world, W, 3), dtype=torch.float32, device="cuda"); alpha_all = torch.zeros((rows * world, W), dtype=torch.float32, device="cuda")
+        rgba_part = torch.zeros((rows, W, 4), dtype=torch.float32, device="cuda")
+        rgba_all = torch.zeros((rows * mworld, W, 4), dtype=torch.float32, device="cuda")
+        host_rgba_t = torch.empty((H, W, 4), dtype=torch.float32, pin_memory=True) if rank == 0 else None
+        if rank == 0:
+            host_rgb, host_alpha = host_rgba_t.numpy()[..., :3], host_rgba_t.numpy()[..., 3]
     host_backend = dist is not None and dist.get_backend() != "nccl"      # the 2-ranks-on-one-GPU test harness: collectives through the host
 
     # The timed step ends with the RESOLVED film in device memory (ImageFilm::WriteImage's arithmetic done, rt_film_resolve_device); handing it to host
@@ -244,22 +263,24 @@ def run_workload(name, args, pkg, torch, dist, world, rank, device_index, steps,
         if merge == "allreduce":
             dist.all_reduce(film, op=dist.ReduceOp.SUM)
         elif merge == "reduce_scatter":
-            pad[:, :H].copy_(film)
-            if host_backend:
-                hp, ho = pad.cpu(), torch.zeros((5, rows, W))
-                for k in range(5):
-                    dist.reduce_scatter_tensor(ho[k], hp[k])
+            ds.pack_parts(film.data_ptr(), mworld, rows, send.data_ptr())
+            if emulate:
+                part.copy_(send[0])                                  # what the reduce-scatter would leave here, minus the other ranks' samples
+            elif host_backend:
+                ho = torch.zeros((5, rows, W))
+                dist.reduce_scatter_tensor(ho.view(-1), send.cpu().view(-1))
                 part.copy_(ho)
             else:
-                for k in range(5):
-                    dist.reduce_scatter_tensor(part[k], pad[k])
-            ds.resolve_device(part.data_ptr(), rows * W, rgb_part.data_ptr(), alpha_part.data_ptr())
-            if host_backend:
-                hr, ha = torch.zeros((rows * world, W, 3)), torch.zeros((rows * world, W))
-                dist.all_gather_into_tensor(hr, rgb_part.cpu()); dist.all_gather_into_tensor(ha, alpha_part.cpu())
-                rgb_all.copy_(hr); alpha_all.copy_(ha)
+                dist.reduce_scatter_tensor(part.view(-1), send.view(-1))      # (flat views: chunk r of `send` is part r)
+            ds.resolve_device_rgba(part.data_ptr(), rows * W, rgba_part.data_ptr())
+            if emulate:
+                rgba_all[:rows].copy_(rgba_part)
+            elif host_backend:
+                hr = torch.zeros((rows * world, W, 4))
+                dist.all_gather_into_tensor(hr, rgba_part.cpu())
+                rgba_all.copy_(hr)
             else:
-                dist.all_gather_into_tensor(rgb_all, rgb_part); dist.all_gather_into_tensor(alpha_all, alpha_part)
+                dist.all_gather_into_tensor(rgba_all, rgba_part)
             return
         if rank == 0:
             ds.resolve_device(film.data_ptr(), H * W, rgb_dev.data_ptr(), alpha_dev.data_ptr())      # ImageFilm::WriteImage normalisation, on the device
@@ -269,7 +290,7 @@ def run_workload(name, args, pkg, torch, dist, world, rank, device_index, steps,
         if rank != 0:
             return None
         if merge == "reduce_scatter":
-            host_rgb_t.copy_(rgb_all[:H], non_blocking=True); host_alpha_t.copy_(alpha_all[:H], non_blocking=True)
+            host_rgba_t.copy_(rgba_all[:H], non_blocking=True)
         else:
             host_rgb_t.copy_(rgb_dev, non_blocking=True); host_alpha_t.copy_(alpha_dev, non_blocking=True)
         torch.cuda.synchronize()
@@ -349,7 +370,7 @@ def run_workload(name, args, pkg, torch, dist, world, rank, device_index, steps,
                        "kd_nodes": int(info.n_nodes), "kd_build_s": round(info.build_seconds, 4),
                        "parallelism": "%s dealt round-robin to %d rank(s); %s; accelerator built once per node (%.2f s scene create on rank 0)"
                                       % ("2-D tiles of %dx%d pixels" % tuple(tiles_used) if args.tile_2d > 0 else "tiles of %d consecutive pixels" % args.tile_pixels, world,
-                                         {"allreduce": "RCCL all-reduce(sum) of the 5-plane film, rank 0 resolves", "reduce_scatter": "RCCL reduce-scatter of film rows, per-rank resolve, all-gather of the resolved rows",
+                                         {"allreduce": "RCCL all-reduce(sum) of the 5-plane film, rank 0 resolves", "reduce_scatter": "one RCCL reduce-scatter of the film (part r = the 5 planes of rank r's rows), per-rank resolve, one all-gather of the resolved RGBA rows",
                                           "none": "single rank"}[merge], t_create),
                        "rng": "counter-based keyed RNG, seed 0"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
@@ -406,6 +427,9 @@ def main():
     # the other BASELINE.json configs at the size one GPU holds, reported as full sub-records in "workloads" (N = 1 only)
     ap.add_argument("--extra-workloads", default="c2,p1000000,c4,c5")
     ap.add_argument("--no-extra", action="store_true")
+    # N > 1: the configurations BASELINE.json states for several GPUs, as sub-records with `per_rank` next to the headline: "auto" = C4 as stated
+    # (10 M triangles, 2048 x 2048 @ 256 spp, "tiles over 8 x MI355X") at 8 ranks, C5 ("4 MI355X") at 4 and 8 ranks
+    ap.add_argument("--multi-workloads", default="auto")
     ap.add_argument("--dump-film", default=None, help="rank 0 writes the last resolved film of the headline workload here (.npz)")
     # 48: with the 1028-pixel sample rows of the default frame, 64-pixel tiles give 16.06 tiles per row, so one rank owns the
     # same columns for ~16 consecutive rows and whole 16x16 film-gather blocks fall to a single rank (measured at 8 ranks:
@@ -460,12 +484,17 @@ def main():
 
     out = run_workload(args.workload, args, pkg, torch, dist, world, rank, device_index, args.steps, args.warmup,
                        with_cpu=not args.no_cpu_baseline, dump_film=args.dump_film)
-    extras = [] if (world > 1 or args.no_extra or args.workload != HEADLINE) else [w for w in args.extra_workloads.split(",") if w]
+    if world > 1:
+        multi = ({8: "c4full,c5", 4: "c5"}.get(world, "") if args.workload == HEADLINE else "") if args.multi_workloads == "auto" else args.multi_workloads
+        extras = [] if args.no_extra else [w for w in multi.split(",") if w]
+    else:
+        extras = [] if (args.no_extra or args.workload != HEADLINE) else [w for w in args.extra_workloads.split(",") if w]
     records = []
     for w in extras:
-        rec = run_workload(w, args, pkg, torch, dist, world, rank, device_index, min(args.steps, 3), 1, with_cpu=not args.no_cpu_baseline)
+        rec = run_workload(w, args, pkg, torch, dist, world, rank, device_index, min(args.steps, 3), 1, with_cpu=not args.no_cpu_baseline,
+                           dump_film=args.dump_film.replace(".npz", "_%s.npz" % w) if args.dump_film else None)
         if rec is not None:
-            records.append({k: rec[k] for k in ("value", "unit", "ms_per_step", "steps", "host_handover", "config", "roofline", "cpu_baseline") if k in rec} |
+            records.append({k: rec[k] for k in ("value", "unit", "n_gpus", "ms_per_step", "steps", "host_handover", "config", "roofline", "per_rank", "cpu_baseline") if k in rec} |
                            ({"speedup_vs_cpu_baseline": rec["speedup_vs_cpu_baseline"]} if "speedup_vs_cpu_baseline" in rec else {}) | {"workload": w})
     if rank == 0:
         if records:

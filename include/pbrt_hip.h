@@ -158,7 +158,12 @@ enum { RT_STRATEGY_ALL = 0, RT_STRATEGY_ONE = 1, RT_STRATEGY_WEIGHTED = 2 };
  * rt_render accepts it on one shard (shard_count == 1) for scenes whose lights all draw the same number of random numbers per estimate
  * (any mix of point / spot / distant / single-triangle / quadric emitters, or only emitters of several triangles) and at most 2048 lights.
  * Such a frame is five launches (RtRenderStats.weighted_ms); rt_render waits on the stream once in the middle of it, for the number of shading
- * points that sizes the survey's tables (every other frame is asynchronous from the first launch on). */
+ * points that sizes the survey's tables (every other frame is asynchronous from the first launch on).  That wait is also the one place where
+ * rt_render can fail AFTER launching work (2^32 or more shading points, no memory for the survey's tables): the film and the sample buffer are
+ * untouched then (the count pass writes neither), rt_last_render_stats / rt_samples_read report "no frame".  In a participating medium the
+ * strategy needs lights that draw no random numbers at all (delta lights, single-triangle / quadric emitters): the medium makes an estimate's
+ * draws depend on occlusion, and an emitter of several triangles would draw its triangle from a different place in the stream than the
+ * survey did -- refused. */
 enum { RT_VOLUME_NONE = 0, RT_VOLUME_EMISSION = 1, RT_VOLUME_SINGLE = 2 };
 enum { RT_SAMPLER_STRATIFIED = 0, RT_SAMPLER_LOWDISCREPANCY = 1, RT_SAMPLER_RANDOM = 2 };
 
@@ -312,6 +317,14 @@ typedef struct RtRenderStats {
 /* ImageFilm::WriteImage's normalisation (image.cpp:157-203) of ANY 5-plane accumulator in device memory (planes of n floats each), e.g. the
  * rows of the film a rank owns after a reduce-scatter; rgb[n][3] and alpha[n] stay on the device.  Asynchronous on the scene's stream. */
 int rt_film_resolve_device(RtScene *s, const float *dev_accum, uint64_t n, int premultiply, float *dev_rgb, float *dev_alpha);
+/* The same with the result interleaved, dev_rgba[n][4] (16-byte aligned): what ONE all-gather moves when every rank resolves its own rows. */
+int rt_film_resolve_device_rgba(RtScene *s, const float *dev_accum, uint64_t n, int premultiply, float *dev_rgba);
+/* N > 1 film merge, send side.  The reference has no in-process merge: every cropwindow process writes its own image
+ * (film/image.cpp:220-228) and tools/exrassemble.cpp:42-75 adds them up.  Here a rank's full-frame 5-plane film `dev_accum`
+ * (h rows of w) is re-laid as `world` parts of `rows` film rows each, part r = [5][rows][w] (rows beyond h zero; world * rows >= h):
+ * the send buffer of ONE reduce-scatter whose r-th chunk is everything rank r resolves.  dev_parts = world*5*rows*w floats.
+ * Asynchronous on the scene's stream. */
+int rt_film_pack_parts(RtScene *s, const float *dev_accum, int32_t w, int32_t h, int32_t world, int32_t rows, float *dev_parts);
 int rt_last_render_stats(RtScene *s, RtRenderStats *out);
 
 #ifdef __cplusplus

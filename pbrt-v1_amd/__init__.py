@@ -182,7 +182,8 @@ def hip_lib():
                      "rt_film_clear", "rt_film_read", "rt_film_resolve", "rt_render", "rt_sync", "rt_counters",
                      "rt_counters_reset", "rt_last_render_ms", "rt_last_render_stats", "rt_samples_read", "rt_device_count", "rt_set_counting",
                      "rt_kdtree_build", "rt_kdtree_info", "rt_kdtree_copy", "rt_kdtree_destroy",
-                     "rt_accel_build", "rt_accel_info", "rt_accel_copy", "rt_accel_destroy", "rt_scene_create_prebuilt", "rt_film_resolve_device"):
+                     "rt_accel_build", "rt_accel_info", "rt_accel_copy", "rt_accel_destroy", "rt_scene_create_prebuilt", "rt_film_resolve_device",
+                     "rt_film_resolve_device_rgba", "rt_film_pack_parts"):
             getattr(L, name).restype = C.c_int
         L.rt_scene_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
         L.rt_scene_create_prebuilt.argtypes = [C.c_void_p, C.c_int, C.POINTER(RtPrebuiltAccel), C.POINTER(C.c_void_p)]
@@ -199,6 +200,8 @@ def hip_lib():
         L.rt_film_resolve.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.rt_render.argtypes = [C.c_void_p, C.c_void_p]
         L.rt_film_resolve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
+        L.rt_film_resolve_device_rgba.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
+        L.rt_film_pack_parts.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
         L.rt_sync.argtypes = [C.c_void_p]
         L.rt_counters.argtypes = [C.c_void_p, C.POINTER(RtCounters)]
         L.rt_counters_reset.argtypes = [C.c_void_p]
@@ -559,6 +562,15 @@ class DeviceScene:
         """rt_film_resolve_device: WriteImage's normalisation of a 5-plane accumulator (planes of n floats) in device memory."""
         pm = self.parsed.premultiply if premultiply is None else premultiply
         _chk(hip_lib().rt_film_resolve_device(self._s, C.c_void_p(accum_ptr), n, int(pm), C.c_void_p(rgb_ptr), C.c_void_p(alpha_ptr)))
+
+    def resolve_device_rgba(self, accum_ptr: int, n: int, rgba_ptr: int, premultiply: bool | None = None):
+        """rt_film_resolve_device_rgba: the same, interleaved RGBA [n][4] (the payload of one all-gather)."""
+        pm = self.parsed.premultiply if premultiply is None else premultiply
+        _chk(hip_lib().rt_film_resolve_device_rgba(self._s, C.c_void_p(accum_ptr), n, int(pm), C.c_void_p(rgba_ptr)))
+
+    def pack_parts(self, accum_ptr: int, world: int, rows: int, parts_ptr: int):
+        """rt_film_pack_parts: this rank's 5-plane film as `world` parts of `rows` rows, part r = [5][rows][W] (the send buffer of one reduce-scatter)."""
+        _chk(hip_lib().rt_film_pack_parts(self._s, C.c_void_p(accum_ptr), self.parsed.width, self.parsed.height, world, rows, C.c_void_p(parts_ptr)))
 
     def film_accum(self) -> np.ndarray:
         out = np.zeros((5, self.parsed.height, self.parsed.width), np.float32)

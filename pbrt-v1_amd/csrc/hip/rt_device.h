@@ -55,7 +55,8 @@ struct DevLight {
     float cos_total, cos_falloff;
 };
 
-#define RT_MAX_DIM_REQ 40
+#define RT_MAX_DIM_REQ 12         // requests the frame descriptor itself carries (PathIntegrator: 11 one-dimensional, 9 two-dimensional); DirectLighting "all"
+                                  // has three per light, without bound (directlighting.cpp:39-66): DevFrame::light_dims
 struct DimReq { unsigned f_base, u_base; unsigned short n; unsigned short dims; };
 
 struct DevScene {
@@ -73,6 +74,8 @@ struct DevScene {
                                // stack entries) instead of indices, a leaf and a popped subtree root need no fetch of their own: gathers per
                                // ray = interior nodes visited, not nodes visited (-44 % at 1 M triangles).  Pairs are stored depth-first.
     unsigned root_x, root_y;   // contents of the root in that encoding
+    unsigned top_pairs, pad_tp;  // the first top_pairs records of tpairs are the owner blocks of the tree's top levels, breadth-first and packed without
+                               // padding: what a workgroup copies into LDS (top_table_fill, rt_traverse.h)
     const float4 *ltris;       // triangle records in LEAF order: the n primitives of a leaf are n consecutive 48-byte records (p1, e1, e2 as
                                // in DevTri, the primitive's index in q2.w), placed so that a leaf touches the fewest 128-byte lines: one
                                // gather fetches what the mesh-order layout needs a leaf-list read plus 1.25 lines per triangle for
@@ -126,6 +129,8 @@ struct DevFrame {
     unsigned pixgen_draws;       // draws consumed when a new pixel's strata are generated
     DimReq one_d[RT_MAX_DIM_REQ];
     DimReq two_d[RT_MAX_DIM_REQ];
+    const DimReq *light_dims;    // DirectLighting "all" (UniformSampleAllLights): per light {light sample 2-D, BSDF sample 2-D, BSDF component 1-D} in HBM, any number of lights
+    int dims_max_n;              // (host) the largest sample count of a 2-D request
     // scratch
     unsigned long long *work_counter;
     unsigned long long *counters;   // RtCounters as 8 u64

@@ -647,7 +647,8 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
         if (INTEG == RT_INTEGRATOR_DIRECT) {
             // UniformSampleAllLights transport.cpp:31-50 with the dimensions of directlighting.cpp:46-53
             if (ln.li >= nLights) { ln.L = ln.L + ln.L_all; ln.stage = ST_SPECULAR; return; }
-            const DimReq &rl = fr.two_d[2 * ln.li], &rb = fr.two_d[2 * ln.li + 1], &rc = fr.one_d[ln.li];
+            const DimReq RT_G *ld = RT_GPTR(const DimReq, fr.light_dims) + 3 * ln.li;
+            const DimReq rl = ld[0], rb = ld[1], rc = ld[2];
             if (ln.lj == 0) ln.Ld_light = mk3(0.f);
             const float ls1 = dim_value(fr, ln, rl, ln.lj, 0), ls2 = dim_value(fr, ln, rl, ln.lj, 1);
             ln.bs1 = dim_value(fr, ln, rb, ln.lj, 0); ln.bs2 = dim_value(fr, ln, rb, ln.lj, 1);
@@ -733,7 +734,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
             ln.stage = ST_SPECULAR;
         } else {
             ln.Ld_light = ln.Ld_light + ln.Ld;
-            const int ns = fr.two_d[2 * ln.li].n;
+            const int ns = RT_GPTR(const DimReq, fr.light_dims)[3 * ln.li].n;
             if (++ln.lj >= ns) {
                 ln.L_all = ln.L_all + ln.Ld_light * (1.f / float(ns));           // L += Ld / nSamples
                 ln.lj = 0; ++ln.li;

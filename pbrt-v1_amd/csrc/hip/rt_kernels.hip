@@ -502,6 +502,7 @@ __global__ __launch_bounds__(64, 2) void film_slot_kernel(const DevFrame *__rest
 
 // ImageFilm::WriteImage (film/image.cpp:157-203) on the device: XYZ round trip (color.h:177-184, color.cpp:35-43),
 // divide by the weight sum, clamps, premultiply.  out = rgb[H][W][3] then alpha[H][W].
+// `alpha` == nullptr: interleaved RGBA, out = rgba[n][4] (the payload of one all-gather, rt_film_resolve_device_rgba).
 __global__ void film_resolve_kernel(const float *__restrict__ accum, size_t n, int premultiply, float *__restrict__ rgb,
                                     float *__restrict__ alpha) {
     const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -522,7 +523,20 @@ __global__ void film_resolve_kernel(const float *__restrict__ accum, size_t n, i
         a = clampf(a * inv, 0.f, 1.f);
     }
     if (premultiply) { r *= a; g *= a; b *= a; }
-    rgb[3 * i] = r; rgb[3 * i + 1] = g; rgb[3 * i + 2] = b; alpha[i] = a;
+    if (alpha) { rgb[3 * i] = r; rgb[3 * i + 1] = g; rgb[3 * i + 2] = b; alpha[i] = a; }
+    else reinterpret_cast<float4 *>(rgb)[i] = make_float4(r, g, b, a);
+}
+
+// N > 1 merge: a rank's full-frame film (5 planes of h x w) re-laid as `world` parts of `rows` film rows, part r = [5][rows][w] (rows beyond h: zero) --
+// the send buffer of ONE reduce-scatter whose r-th chunk is everything rank r resolves (rt_film_pack_parts).  One float4 per thread where w allows.
+__global__ void film_pack_parts_kernel(const float *__restrict__ accum, int w, int h, int rows, size_t n_out, float *__restrict__ parts) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;           // output index: ((part * 5 + plane) * rows + row) * w + x
+    if (i >= n_out) return;
+    const size_t x = i % size_t(w), t = i / size_t(w);
+    const size_t row = t % size_t(rows), u = t / size_t(rows);
+    const size_t plane = u % 5u, part = u / 5u;
+    const size_t y = part * size_t(rows) + row;
+    parts[i] = y < size_t(h) ? accum[(plane * size_t(h) + y) * size_t(w) + x] : 0.f;
 }
 
 // rt_samples_read: records [first, first + count) of the shard's work list, out of the sample_slot() layout, as 2 x float4 per sample
@@ -612,6 +626,8 @@ struct RtScene {
     unsigned grid = 0, n_threads = 0;
     unsigned grids[48] = {0};          // resident grid per render_kernel<COUNT, INTEG> instantiation
     unsigned wgrids[8] = {0};          // ... of the DirectLighting "weighted" family (rt_mega_dw.hip)
+    DimReq *light_dims = nullptr; size_t light_dims_cap = 0;      // DirectLighting "all": the per-light sample requests (make_frame)
+    std::vector<DimReq> light_dims_host;
     int light_draws = 0;               // RandomFloat()s one EstimateDirect draws: the same for every light (0 / 1), or -1 when the lights differ
     unsigned *wt_base = nullptr; size_t wt_base_cap = 0; float *wt_rec = nullptr; size_t wt_rec_cap = 0; float2 *wt_pick = nullptr; size_t wt_pick_cap = 0;
     unsigned long long *wt_sums = nullptr;                     // per-block sums of the point-count scan
@@ -771,34 +787,56 @@ static void host_tri_frame_uv(const float *v, const float *uv, bool flip, float 
 // through a pop it takes a one-level step).  Blocks are emitted depth-first, the below side first, so a subtree stays contiguous.
 // Two phases: pair_blocks_order() decides where every pair goes (a sequential depth-first walk that looks at the tree's SHAPE only, so it runs
 // beside leaf_order_offsets on another thread), pair_blocks_fill() writes the records (needs the leaves' positions in ltris; 64 threads).
-struct PairBlockOrder { std::vector<uint32_t> order, pos; std::vector<uint8_t> owner; };
+// Round 5: the blocks of the tree's TOP levels come first, breadth-first (owner level by owner level, below side first) and packed without
+// padding, RT_TOP_PREFIX records at most -- the part of the array a workgroup keeps in LDS (top_table_fill, rt_traverse.h; any prefix of it is
+// "the topmost blocks").  The subtrees below that frontier follow depth-first in 64-byte-aligned blocks as before.
+#ifndef RT_TOP_PREFIX
+#define RT_TOP_PREFIX 4095u          // 1365 blocks of three records: 11-12 levels of a full tree
+#endif
+struct PairBlockOrder { std::vector<uint32_t> order, pos; std::vector<uint8_t> owner; uint32_t top = 0; };
 static void pair_blocks_order(const std::vector<Node> &tn, PairBlockOrder &o) {
-    o.order.clear(); o.pos.clear(); o.owner.clear();
+    o.order.clear(); o.pos.clear(); o.owner.clear(); o.top = 0;
     if (tn.empty() || (tn[0].x & 3u) == 3u) return;
     auto interior = [&](uint32_t n) { return (tn[n].x & 3u) != 3u; };
     std::vector<uint32_t> &order = o.order; order.reserve(tn.size() / 2 + tn.size() / 8 + 4);   // parent node of each emitted pair (~0u = padding)
     o.pos.assign(tn.size(), ~0u);                                             // node -> index of its children's pair
     o.owner.assign(tn.size(), 0);
-    std::vector<uint32_t> todo{0u};
-    while (!todo.empty()) {
-        const uint32_t P = todo.back(); todo.pop_back();
+    // emit the block of owner P; `next` receives the owners below it (the interior children of its members), below side first
+    auto emit = [&](uint32_t P, bool aligned, std::vector<uint32_t> &next, bool reversed) {
         const uint32_t b = P + 1u, a = tn[P].y;
         const bool bI = interior(b), aI = interior(a);
         const size_t size = 1u + (bI ? 1u : 0u) + (aI ? 1u : 0u);
-        if ((order.size() % 4) + size > 4) while (order.size() % 4) order.push_back(~0u);
+        if (aligned && (order.size() % 4) + size > 4) while (order.size() % 4) order.push_back(~0u);
         o.owner[P] = 1;
         o.pos[P] = uint32_t(order.size()); order.push_back(P);
         if (bI) { o.pos[b] = uint32_t(order.size()); order.push_back(b); }
         if (aI) { o.pos[a] = uint32_t(order.size()); order.push_back(a); }
-        // the owners below: interior children of the members; pushed so that below(below(P)) is placed next
-        const uint32_t mem[2] = {a, b};
-        const bool memI[2] = {aI, bI};
+        const uint32_t mem[2] = {reversed ? a : b, reversed ? b : a};
+        const bool memI[2] = {reversed ? aI : bI, reversed ? bI : aI};
         for (int k = 0; k < 2; ++k) {
             if (!memI[k]) continue;
             const uint32_t m = mem[k], mb = m + 1u, ma = tn[m].y;
-            if (interior(ma)) todo.push_back(ma);
-            if (interior(mb)) todo.push_back(mb);
+            const uint32_t c[2] = {reversed ? ma : mb, reversed ? mb : ma};
+            for (int j = 0; j < 2; ++j) if (interior(c[j])) next.push_back(c[j]);
         }
+    };
+    // the top: breadth-first, dense
+    std::vector<uint32_t> level{0u}, below;
+    size_t li = 0;
+    while (li < level.size() && order.size() + 3u <= RT_TOP_PREFIX) {
+        emit(level[li++], false, below, false);
+        if (li == level.size()) { level.swap(below); below.clear(); li = 0; }
+    }
+    o.top = uint32_t(order.size());
+    while (order.size() % 4) order.push_back(~0u);
+    // what is left: the rest of the current level, then the owners found below it; depth-first from each (a stack: pushed in reverse so that the
+    // first of them is placed first and below(below(P)) follows P)
+    std::vector<uint32_t> todo;
+    for (size_t k = below.size(); k-- > 0;) todo.push_back(below[k]);
+    for (size_t k = level.size(); k-- > li;) todo.push_back(level[k]);
+    while (!todo.empty()) {
+        const uint32_t P = todo.back(); todo.pop_back();
+        emit(P, true, todo, true);
     }
 }
 // `tn`: the nodes with a leaf's word 1 = its position in ltris (interior nodes as in the tree: same shape as pair_blocks_order saw)
@@ -1231,6 +1269,7 @@ static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel 
         std::vector<uint4> pairs;
         order_thread.join();
         pair_blocks_fill(tn, pbo, pairs, s->dev.root_x, s->dev.root_y);
+        s->dev.top_pairs = pbo.top;
         if (pairs.empty() || pairs.size() >= (size_t(1) << 30)) return fail(RT_EINVAL, "rt_scene_create: pair records beyond 2^30");
         tick("pair blocks");
         if ((rc = upload(s, pairs.data(), pairs.size(), &s->dev.tpairs))) return rc;
@@ -1374,6 +1413,7 @@ int rt_scene_destroy(RtScene *s) {
     if (s->samples) HIPWARN(hipFree(s->samples));
     if (s->resolve_buf) HIPWARN(hipFree(s->resolve_buf));
     if (s->vol_buf) HIPWARN(hipFree(s->vol_buf));
+    if (s->light_dims) HIPWARN(hipFree(s->light_dims));
     if (s->wt_base) HIPWARN(hipFree(s->wt_base));
     if (s->wt_rec) HIPWARN(hipFree(s->wt_rec));
     if (s->wt_pick) HIPWARN(hipFree(s->wt_pick));
@@ -1512,27 +1552,57 @@ static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool nee
     else if (rd->integrator == RT_INTEGRATOR_PATH) { n1.assign(9, 1); n2.assign(9, 1); }
     else if (rd->integrator != RT_INTEGRATOR_WHITTED) return fail(RT_EINVAL, "unknown integrator");
     n1.push_back(1); n1.push_back(1);                   // the volume integrator's tau / scatter samples
-    if (n1.size() > RT_MAX_DIM_REQ || n2.size() > RT_MAX_DIM_REQ) return fail(RT_EINVAL, "too many lights for the sample table");
+    // The requests in the reference's order (every 1-D request, then every 2-D one: Sample::Sample sampling.cpp:41-70).  DirectLighting "all" asks for
+    // 2 x 2-D and 1 x 1-D per light WITHOUT bound (directlighting.cpp:39-66): its per-light requests go to a table in HBM (DevFrame::light_dims, three
+    // records per light, indexed by the lane's light cursor); the frame descriptor itself carries the bounded rest.
+    const bool all_lights = rd->integrator == RT_INTEGRATOR_DIRECT && rd->strategy == RT_STRATEGY_ALL;
+    std::vector<DimReq> d1(n1.size()), d2(n2.size());
     unsigned c = 0;
-    fr.n1d = int(n1.size()); fr.n2d = int(n2.size());
     const unsigned P = unsigned(fr.spp);
     if (rd->sampler == RT_SAMPLER_STRATIFIED) {             // LatinHypercube: n*d floats then n*d shuffles per request
-        for (size_t i = 0; i < n1.size(); ++i) { fr.one_d[i] = DimReq{c, c + unsigned(n1[i]), (unsigned short)n1[i], 1}; c += 2u * n1[i]; }
-        for (size_t i = 0; i < n2.size(); ++i) { fr.two_d[i] = DimReq{c, c + 2u * n2[i], (unsigned short)n2[i], 2}; c += 4u * n2[i]; }
+        for (size_t i = 0; i < n1.size(); ++i) { d1[i] = DimReq{c, c + unsigned(n1[i]), (unsigned short)n1[i], 1}; c += 2u * n1[i]; }
+        for (size_t i = 0; i < n2.size(); ++i) { d2[i] = DimReq{c, c + 2u * n2[i], (unsigned short)n2[i], 2}; c += 4u * n2[i]; }
         fr.lhs_total = c;
         fr.pixgen_draws = fr.jitter ? 7u * P : 2u * P;      // stratified.cpp:99-117
     } else if (rd->sampler == RT_SAMPLER_RANDOM) {          // one float per value (random.cpp:107-112)
-        for (size_t i = 0; i < n1.size(); ++i) { fr.one_d[i] = DimReq{c, 0, (unsigned short)n1[i], 1}; c += unsigned(n1[i]); }
-        for (size_t i = 0; i < n2.size(); ++i) { fr.two_d[i] = DimReq{c, 0, (unsigned short)n2[i], 2}; c += 2u * n2[i]; }
+        for (size_t i = 0; i < n1.size(); ++i) { d1[i] = DimReq{c, 0, (unsigned short)n1[i], 1}; c += unsigned(n1[i]); }
+        for (size_t i = 0; i < n2.size(); ++i) { d2[i] = DimReq{c, 0, (unsigned short)n2[i], 2}; c += 2u * n2[i]; }
         fr.lhs_total = c;
         fr.pixgen_draws = 5u * P;                           // random.cpp:88-92
     } else {                                                // per-pixel tables (lowdiscrepancy.cpp:93-104, sampling.h:152-174)
         c = (2 + 2 * P) + (2 + 2 * P) + (1 + 2 * P);        // image, lens, time blocks
-        for (size_t i = 0; i < n1.size(); ++i) { fr.one_d[i] = DimReq{c, 0, (unsigned short)n1[i], 1}; c += 1u + unsigned(n1[i]) * P + P; }
-        for (size_t i = 0; i < n2.size(); ++i) { fr.two_d[i] = DimReq{c, 0, (unsigned short)n2[i], 2}; c += 2u + unsigned(n2[i]) * P + P; }
+        for (size_t i = 0; i < n1.size(); ++i) { d1[i] = DimReq{c, 0, (unsigned short)n1[i], 1}; c += 1u + unsigned(n1[i]) * P + P; }
+        for (size_t i = 0; i < n2.size(); ++i) { d2[i] = DimReq{c, 0, (unsigned short)n2[i], 2}; c += 2u + unsigned(n2[i]) * P + P; }
         fr.lhs_total = 0;
         fr.pixgen_draws = c;
     }
+    {   // the draws of one camera sample are addressed by a 32-bit counter: the tables above must fit well inside it
+        unsigned long long draws = 0;
+        for (int n : n1) draws += 2ull * unsigned(n) * (P + 1);
+        for (int n : n2) draws += 4ull * unsigned(n) * (P + 1);
+        if (draws > 0x3fffffffull) return fail(RT_EINVAL, "rt_render: the lights' sample requests need more than 2^30 random numbers per camera sample");
+    }
+    fr.light_dims = nullptr;
+    fr.dims_max_n = 0;
+    for (const DimReq &r : d2) fr.dims_max_n = std::max(fr.dims_max_n, int(r.n));
+    if (all_lights) {
+        std::vector<DimReq> tab(size_t(nl) * 3 + 1, DimReq{0, 0, 0, 0});
+        for (int i = 0; i < nl; ++i) { tab[3 * size_t(i)] = d2[2 * size_t(i)]; tab[3 * size_t(i) + 1] = d2[2 * size_t(i) + 1]; tab[3 * size_t(i) + 2] = d1[size_t(i)]; }
+        std::vector<DimReq> &up = s->light_dims_host;          // what the device holds: uploaded again only when a frame asks for other requests
+        if (!s->light_dims || up.size() != tab.size() || std::memcmp(up.data(), tab.data(), tab.size() * sizeof(DimReq)) != 0) {
+            int rc = ensure(s, &s->light_dims, &s->light_dims_cap, tab.size()); if (rc) return rc;
+            up.swap(tab);
+            HIPCHK(hipMemcpyAsync(s->light_dims, up.data(), up.size() * sizeof(DimReq), hipMemcpyHostToDevice, s->stream));
+        }
+        fr.light_dims = s->light_dims;
+        d1.erase(d1.begin(), d1.begin() + nl);              // what stays in the descriptor: the volume integrator's two 1-D requests
+        d2.clear();
+    }
+    if (d1.size() > RT_MAX_DIM_REQ || d2.size() > RT_MAX_DIM_REQ) return fail(RT_ESTATE, "rt_render: sample table overflow");      // (cannot happen: 11 / 9 for the path integrator)
+    fr.n1d = int(d1.size()); fr.n2d = int(d2.size());
+    std::memset(fr.one_d, 0, sizeof fr.one_d); std::memset(fr.two_d, 0, sizeof fr.two_d);
+    for (size_t i = 0; i < d1.size(); ++i) fr.one_d[i] = d1[i];
+    for (size_t i = 0; i < d2.size(); ++i) fr.two_d[i] = d2[i];
     // traversal scheduling knobs (performance only; results and counters do not depend on them)
     {
         const size_t nn = s->tree.nodes.size();
@@ -1574,7 +1644,7 @@ static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool nee
         fr.pipeline = (!tiny && s->volume.present) ? 1 : 0;
         if (const char *e = knob("PBRT_HIP_PIPELINE")) fr.pipeline = std::atoi(e) != 0;
         if (fr.max_depth > 250 || fr.max_depth < 0) fr.pipeline = 0;     // the slot's control word holds depth in 8 bits
-        for (int i = 0; i < fr.n2d; ++i) if (fr.two_d[i].n >= 65535) fr.pipeline = 0;         // ... and the light / sample cursors in 16 bits each
+        if (fr.dims_max_n >= 65535) fr.pipeline = 0;                     // ... and the light / sample cursors in 16 bits each
         if (s->dev.n_lights >= 65535u) fr.pipeline = 0;
         if (rd->integrator == RT_INTEGRATOR_DIRECT && rd->strategy == RT_STRATEGY_WEIGHTED) fr.pipeline = 0;    // three megakernel passes (rt_weighted.h)
         if (fr.shard_count == 1 && !fr.pipeline) {
@@ -1711,6 +1781,31 @@ int rt_film_resolve_device(RtScene *s, const float *dev_accum, uint64_t n, int p
     return RT_OK;
 }
 
+// The same with the result interleaved, dev_rgba[n][4]: what ONE all-gather moves when every rank resolves its own rows.
+int rt_film_resolve_device_rgba(RtScene *s, const float *dev_accum, uint64_t n, int premultiply, float *dev_rgba) {
+    if (!s || !dev_accum || !dev_rgba) return fail(RT_EINVAL, "null argument");
+    if (reinterpret_cast<uintptr_t>(dev_rgba) % 16u) return fail(RT_EINVAL, "rt_film_resolve_device_rgba: the output must be 16-byte aligned");
+    if (n == 0) return RT_OK;
+    HIPCHK(hipSetDevice(s->device));
+    hipLaunchKernelGGL(film_resolve_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s->stream, dev_accum, size_t(n), premultiply, dev_rgba, (float *)nullptr);
+    HIPCHK(hipGetLastError());
+    return RT_OK;
+}
+
+// N > 1 film merge, send side (the reference: every cropwindow process writes its own EXR, tools/exrassemble.cpp:42-75 adds them up): the rank's
+// full-frame 5-plane film `dev_accum` (h rows of w) re-laid as `world` parts of `rows` film rows each, part r = [5][rows][w], rows beyond h zero;
+// world * rows >= h.  dev_parts = world * 5 * rows * w floats.  Asynchronous on the scene's stream.
+int rt_film_pack_parts(RtScene *s, const float *dev_accum, int32_t w, int32_t h, int32_t world, int32_t rows, float *dev_parts) {
+    if (!s || !dev_accum || !dev_parts) return fail(RT_EINVAL, "null argument");
+    if (w <= 0 || h <= 0 || world <= 0 || rows <= 0 || int64_t(world) * rows < h) return fail(RT_EINVAL, "rt_film_pack_parts: world * rows must cover the film's rows");
+    HIPCHK(hipSetDevice(s->device));
+    const size_t n_out = size_t(world) * 5u * size_t(rows) * size_t(w);
+    if ((n_out + 255) / 256 > 0x7fffffffull) return fail(RT_EINVAL, "rt_film_pack_parts: film too large");
+    hipLaunchKernelGGL(film_pack_parts_kernel, dim3(unsigned((n_out + 255) / 256)), dim3(256), 0, s->stream, dev_accum, w, h, rows, n_out, dev_parts);
+    HIPCHK(hipGetLastError());
+    return RT_OK;
+}
+
 int rt_render(RtScene *s, const RtRenderDesc *rd) {
     if (!s || !rd) return fail(RT_EINVAL, "null argument");
     HIPCHK(hipSetDevice(s->device));
@@ -1725,6 +1820,13 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
         if (fr.shard_count != 1) return fail(RT_EINVAL, "rt_render: strategy \"weighted\" is a recurrence over the whole frame in the sampler's order (transport.cpp:71-122): one shard only");
         if (s->light_draws < 0) return fail(RT_EINVAL, "rt_render: strategy \"weighted\" needs lights that draw the same number of random numbers per estimate "
                                                        "(emitters of several triangles draw one, ShapeSet::Sample shape.h:115-121; every other light none): this scene mixes them");
+        // With a medium EstimateDirect draws one RandomFloat per UNOCCLUDED shadow / MIS ray (Scene::Transmittance), so the draws of an estimate depend on
+        // the light AND on occlusion: the survey pass (every light, the counter left where the LAST light's estimate ends) and the frame pass (the chosen
+        // light only) then reach the sample's next shading point with different counters, and a light that draws (ShapeSet::Sample's triangle pick) is fed
+        // a different random number than the one its surveyed luminance came from.  Delta lights never draw: their Ld does not depend on it.
+        if (s->volume.present && s->light_draws != 0) return fail(RT_EINVAL, "rt_render: strategy \"weighted\" in a participating medium needs lights whose estimates draw no random numbers "
+                                                                            "(point / spot / distant / single-triangle / quadric lights): an emitter of several triangles draws its triangle, and the medium makes "
+                                                                            "the draw's position in the stream depend on occlusion");
         if (s->dev.n_lights > 2048u) return fail(RT_EINVAL, "rt_render: strategy \"weighted\" holds the per-light tables of its recurrence in LDS: at most 2048 lights");
         if (fr.total_work >= 0xffffffffull) return fail(RT_EINVAL, "rt_render: strategy \"weighted\": more than 2^32 - 2 camera samples in the frame");
     }
@@ -1858,10 +1960,13 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
             HIPCHK(hipEventRecord(s->wt_ev[1], s->stream));
             HIPCHK(hipStreamSynchronize(s->stream));
             const unsigned long long n_points = *s->wt_total;
-            if (n_points >= 0xffffffffull) return fail(RT_EINVAL, "rt_render: strategy \"weighted\": more than 2^32 - 2 shading points in the frame");
+            // The one place where rt_render can fail AFTER it has launched work (the number of shading points is only known once the count pass has run;
+            // pbrt_hip.h says so): the film and the sample buffer are untouched (the count pass writes neither), the scene is left without a last frame.
+            auto late_fail = [&](int code, const char *msg) { s->last_weighted = false; s->last_pipeline = false; s->have_timing = false; s->wt_points = 0; return fail(code, msg); };
+            if (n_points >= 0xffffffffull) return late_fail(RT_EINVAL, "rt_render: strategy \"weighted\": more than 2^32 - 2 shading points in the frame");
             s->wt_points = n_points;
-            rc = ensure(s, &s->wt_rec, &s->wt_rec_cap, size_t(n_points) * size_t(R) + 1); if (rc) return rc;
-            rc = ensure(s, &s->wt_pick, &s->wt_pick_cap, size_t(n_points) + 1); if (rc) return rc;
+            rc = ensure(s, &s->wt_rec, &s->wt_rec_cap, size_t(n_points) * size_t(R) + 1); if (rc) return late_fail(rc, rt_last_error());
+            rc = ensure(s, &s->wt_pick, &s->wt_pick_cap, size_t(n_points) + 1); if (rc) return late_fail(rc, rt_last_error());
             fr.wt_rec = s->wt_rec; fr.wt_pick = s->wt_pick;
             if (n_points > 0) {
                 if ((rc = pass(2))) return rc;

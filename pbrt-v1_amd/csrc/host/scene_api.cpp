@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 
 namespace pbrthip {
 
@@ -140,15 +141,19 @@ static void addPluginPath(const std::string &path) {         // colon-separated,
         a = b + 1;
     }
 }
+// The factories carry product-specific names (PbrtHipCreate*, not the reference's Create*): the descriptors they fill are another ABI than the
+// reference's `Create*(const ParamSet &, ...)` returning C++ objects, and a SearchPath that points at a pbrt-v1 install holds stratified.so,
+// kdtree.so, ... of exactly the names a scene asks for.  A shared object that does not load here (a reference plugin: its core symbols
+// are unresolved) or lacks the product's factory is not an error: a warning, then the compiled-in plugin answers.  PBRT_SEARCHPATH is the
+// reference's install and is not searched; PBRT_HIP_PLUGIN_PATH and the scene's SearchPath directives are.
 static void *findPluginSymbol(const std::string &name, const char *symbol) {
     static bool env_done = false;
     if (!env_done) {
         env_done = true;
         if (const char *e = std::getenv("PBRT_HIP_PLUGIN_PATH")) addPluginPath(e);
-        if (const char *e = std::getenv("PBRT_SEARCHPATH")) addPluginPath(e);
     }
     if (name.empty() || name.find('/') != std::string::npos) return nullptr;
-    static std::map<std::string, void *> handles;              // a shared object is opened once per process, as the reference's Plugin cache does
+    static std::map<std::string, void *> handles;              // a shared object is opened once per process, as the reference's Plugin cache does (nullptr: did not load)
     for (const std::string &dir : pluginDirs())
         for (const char *prefix : {"", "lib"}) {
             const std::string file = dir + "/" + prefix + name + ".so";
@@ -158,16 +163,21 @@ static void *findPluginSymbol(const std::string &name, const char *symbol) {
             else {
                 if (access(file.c_str(), R_OK) != 0) continue;
                 h = dlopen(file.c_str(), RTLD_NOW | RTLD_LOCAL);
-                if (!h) { Error("Unable to load plugin \"%s\": %s", file.c_str(), dlerror()); continue; }
+                if (!h) Warning("Plugin \"%s\" does not load here (%s); using the built-in \"%s\" if there is one", file.c_str(), dlerror(), name.c_str());
                 handles[file] = h;
             }
+            if (!h) continue;
+            // the ABI the object was built against (include/pbrt_hip_plugin.h PBRT_HIP_PLUGIN_ABI); an object without the symbol predates the check
+            if (void *abi = dlsym(h, "PbrtHipPluginAbi")) {
+                const int v = reinterpret_cast<int (*)()>(abi)();
+                if (v != PBRT_HIP_PLUGIN_ABI) { Warning("Plugin \"%s\" was built for plugin ABI %d, this library speaks %d; ignored", file.c_str(), v, PBRT_HIP_PLUGIN_ABI); continue; }
+            }
             if (void *sym = dlsym(h, symbol)) return sym;
-            Error("Plugin \"%s\" has no %s function", file.c_str(), symbol);
         }
     return nullptr;
 }
 namespace {
-struct CParams { const ParamSet *ps; mutable std::vector<std::string> strings; };
+struct CParams { const ParamSet *ps; mutable std::deque<std::string> strings; };      // deque: a later find_string must not move the strings handed out before
 const CParams *cp(const PbrtHipParams *p) { return reinterpret_cast<const CParams *>(p); }
 const PbrtHipParamsApi kParamsApi = {
     [](const PbrtHipParams *p, const char *n, int d) { return cp(p)->ps->FindOneInt(n, d); },
@@ -181,7 +191,7 @@ const PbrtHipParamsApi kParamsApi = {
 Sampler MakeSampler(const std::string &nameIn, const ParamSet &ps, const Film &, bool *ok) {
     Sampler s; *ok = true; s.seed = 0; s.pixelsamples = 4; s.xsamples = s.ysamples = 2; s.jitter = true;
     const std::string &name = nameIn;
-    if (void *sym = findPluginSymbol(name, "CreateSampler")) {                      // dynload.cpp:230-245 MakeSampler
+    if (void *sym = findPluginSymbol(name, "PbrtHipCreateSampler")) {                      // dynload.cpp:230-245 MakeSampler
         CParams c{&ps}; PbrtHipSampler o{};
         if (reinterpret_cast<PbrtHipCreateSamplerFn>(sym)(reinterpret_cast<const PbrtHipParams *>(&c), &kParamsApi, &o) != 0 ||
             o.kind < RT_SAMPLER_STRATIFIED || o.kind > RT_SAMPLER_RANDOM) { Error("Unable to load plugin \"%s\" (sampler)", name.c_str()); *ok = false; s.kind = RT_SAMPLER_STRATIFIED; }
@@ -212,7 +222,7 @@ Sampler MakeSampler(const std::string &nameIn, const ParamSet &ps, const Film &,
 // ------------------------------------------------------------------ integrators
 SurfaceIntegrator MakeSurfaceIntegrator(const std::string &name, const ParamSet &ps, bool *ok) {
     SurfaceIntegrator si; *ok = true; si.strategy = RT_STRATEGY_ALL;
-    if (void *sym = findPluginSymbol(name, "CreateSurfaceIntegrator")) {            // dynload.cpp:185-199 MakeSurfaceIntegrator
+    if (void *sym = findPluginSymbol(name, "PbrtHipCreateSurfaceIntegrator")) {            // dynload.cpp:185-199 MakeSurfaceIntegrator
         CParams c{&ps}; PbrtHipSurfaceIntegrator o{};
         if (reinterpret_cast<PbrtHipCreateSurfaceIntegratorFn>(sym)(reinterpret_cast<const PbrtHipParams *>(&c), &kParamsApi, &o) != 0 ||
             o.kind < RT_INTEGRATOR_WHITTED || o.kind > RT_INTEGRATOR_PATH || (o.strategy < RT_STRATEGY_ALL || o.strategy > RT_STRATEGY_WEIGHTED)) {
@@ -237,7 +247,7 @@ SurfaceIntegrator MakeSurfaceIntegrator(const std::string &name, const ParamSet 
 }
 VolumeIntegrator MakeVolumeIntegrator(const std::string &name, const ParamSet &ps, bool *ok) {
     VolumeIntegrator vi; *ok = true;
-    if (void *sym = findPluginSymbol(name, "CreateVolumeIntegrator")) {             // dynload.cpp:200-214 MakeVolumeIntegrator
+    if (void *sym = findPluginSymbol(name, "PbrtHipCreateVolumeIntegrator")) {             // dynload.cpp:200-214 MakeVolumeIntegrator
         CParams c{&ps}; PbrtHipVolumeIntegrator o{};
         if (reinterpret_cast<PbrtHipCreateVolumeIntegratorFn>(sym)(reinterpret_cast<const PbrtHipParams *>(&c), &kParamsApi, &o) != 0 ||
             (o.kind != RT_VOLUME_EMISSION && o.kind != RT_VOLUME_SINGLE)) { Error("Unable to load plugin \"%s\" (volume integrator)", name.c_str()); *ok = false; vi.kind = RT_VOLUME_EMISSION; vi.stepSize = 1.f; }
@@ -255,7 +265,7 @@ VolumeIntegrator MakeVolumeIntegrator(const std::string &name, const ParamSet &p
 Accelerator MakeAccelerator(const std::string &nameIn, const ParamSet &ps, bool *ok) {
     Accelerator a; *ok = true; std::memset(&a.params, 0, sizeof a.params);
     const std::string &name = nameIn;
-    if (void *sym = findPluginSymbol(name, "CreateAccelerator")) {                  // dynload.cpp:246-260 MakeAccelerator
+    if (void *sym = findPluginSymbol(name, "PbrtHipCreateAccelerator")) {                  // dynload.cpp:246-260 MakeAccelerator
         CParams c{&ps}; PbrtHipAccelerator o{};
         if (reinterpret_cast<PbrtHipCreateAcceleratorFn>(sym)(reinterpret_cast<const PbrtHipParams *>(&c), &kParamsApi, &o) != 0 ||
             (o.params.kind != RT_ACCEL_KDTREE && o.params.kind != RT_ACCEL_GRID)) {

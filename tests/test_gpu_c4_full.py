@@ -96,3 +96,34 @@ def test_c4_frame_properties_at_the_stated_film_size(pkg, soup10m):
     assert ca["closest_rays"] >= ca["camera_rays"] and ca["any_rays"] > 0.2 * ca["camera_rays"]
     for k in COUNTERS:
         assert ca[k] > 0, k
+
+
+def test_c4_sample_count_beyond_2_to_the_30_work_items_and_2_to_the_32_rays(pkg, scenes):
+    """C4's stated sample count -- 2048 x 2048 film, 256 samples per pixel: 2049 * 2049 * 256 = 1 074 790 656 camera samples, just over 2^30 work items, a
+    34 GB sample buffer, ~6 G rays (beyond 2^32) -- on the 1 M-triangle tree (VERDICT r04 weak #1a: the 10 M-triangle test above renders 4 of the 256
+    samples per pixel, so the 32-bit work index, the sample-slot arithmetic and the 64-bit ray counters were never exercised at this size).  Box filter,
+    unjittered strata: every camera sample lands in exactly one pixel, so the weight plane counts them.  Determinism (the timed kernel twice) and
+    timed kernel == counting twin, bit for bit."""
+    need_gpu(pkg)
+    text = scenes.cornell_scene(xres=2048, yres=2048, integrator="path", maxdepth=8, xsamples=16, ysamples=16, jitter=False, pixel_filter="box",
+                                soup_tris=1_000_000, soup_materials=True, keyed=True)
+    ps = pkg.ParsedScene(text=text)
+    del text
+    assert ps.valid and ps.errors == 0 and ps.n_camera_samples == 2049 * 2049 * 256 > (1 << 30)
+    ds = pkg.DeviceScene(ps)
+    ds.bind_film()
+    ds.set_counting(False); ds.render(); a = ds.film_accum(); st = ds.last_stats()
+    assert st["pipeline"] == 0
+    ds.clear_film(); ds.render(); a2 = ds.film_accum()
+    assert np.array_equal(a, a2), "two renders of the timed kernel differ"
+    del a2
+    assert np.all(a[4][1:-1, 1:-1] == 256.0), "a camera sample was dropped or rendered twice"
+    assert np.isfinite(a).all() and a[:3].min() >= 0 and np.all(a[3] <= a[4] * (1 + 1e-5))
+    # the last work items of the list (beyond index 2^30) are rendered like the first: the bottom rows of the film are lit like their neighbours above
+    assert a[:3, -8:, 8:-8].mean() > 0.25 * a[:3, -64:-8, 8:-8].mean()
+    ds.set_counting(True); ds.reset_counters(); ds.clear_film(); ds.render(); t = ds.film_accum(); c = ds.counters()
+    assert np.array_equal(a, t), "the timed kernel's film differs from its counting twin's"
+    assert c["camera_rays"] == 2049 * 2049 * 256 and c["bad_samples"] == 0
+    assert c["closest_rays"] + c["any_rays"] > (1 << 32) and c["closest_rays"] >= c["camera_rays"]
+    assert c["nodes_visited"] > 40 * c["camera_rays"]
+    ds.close()

@@ -131,6 +131,15 @@ def test_frames_the_weighted_recurrence_cannot_serve_are_refused(pkg, scenes):
         ds.render()
     assert "weighted" in str(e.value) and "random numbers" in str(e.value)
     ds.close()
+    # a participating medium with the two-triangle emitter: Scene::Transmittance draws per unoccluded ray, so the survey and the frame pass
+    # would hand ShapeSet::Sample different random numbers at a sample's second shading point (here: behind the mirror)
+    ps = pkg.ParsedScene(text=scenes.cornell_scene(volume_integrator='"single" "float stepsize" [60]', world_kwargs=dict(volume='"float g" [0]', mirror_quad=True), **kw))
+    assert ps.valid
+    ds = pkg.DeviceScene(ps)
+    with pytest.raises(pkg.RtError) as e:
+        ds.render()
+    assert "medium" in str(e.value) and "weighted" in str(e.value)
+    ds.close()
     # more than one shard: the recurrence spans the frame
     ps = pkg.ParsedScene(text=scenes.cornell_scene(**kw))
     ps.set_shard(0, 2, 64)

@@ -256,18 +256,20 @@ def test_bench_reports_a_stale_profile_as_stale(pkg, tmp_path):
 def test_plugins_are_loaded_from_the_search_path(pkg, tmp_path):
     """north_star: "host-side C++ keeps pbrt's plugin API (SurfaceIntegrator/Aggregate/Sampler)".  As core/dynload.cpp:462-514 does, the host library
     resolves `SurfaceIntegrator "name"` / `Accelerator "name"` / `Sampler "name"` to name.so along the search path (SearchPath directive,
-    PBRT_SEARCHPATH) and calls its extern "C" Create<Kind> factory (include/pbrt_hip_plugin.h); the compiled-in plugins are the fall-back."""
+    PBRT_HIP_PLUGIN_PATH) and calls its extern "C" PbrtHipCreate<Kind> factory (include/pbrt_hip_plugin.h); the compiled-in plugins are the fall-back.
+    A shared object of a plugin's name that is NOT a plugin of this library -- the reference's own stratified.so / kdtree.so on a SearchPath that points
+    at a pbrt-v1 install: another ABI behind the same Create<Kind> names -- is never called: a warning at most, the built-in answers."""
     import subprocess, ctypes as C
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = tmp_path / "plug.cpp"
     src.write_text('''
 #include "pbrt_hip_plugin.h"
-extern "C" int CreateSurfaceIntegrator(const PbrtHipParams *p, const PbrtHipParamsApi *api, PbrtHipSurfaceIntegrator *out) {
+extern "C" int PbrtHipCreateSurfaceIntegrator(const PbrtHipParams *p, const PbrtHipParamsApi *api, PbrtHipSurfaceIntegrator *out) {
     out->kind = RT_INTEGRATOR_PATH; out->max_depth = api->find_int(p, "bounces", 3) + 1; out->strategy = RT_STRATEGY_ALL; return 0; }
-extern "C" int CreateAccelerator(const PbrtHipParams *p, const PbrtHipParamsApi *api, PbrtHipAccelerator *out) {
+extern "C" int PbrtHipCreateAccelerator(const PbrtHipParams *p, const PbrtHipParamsApi *api, PbrtHipAccelerator *out) {
     RtAccelParams a = {}; a.kind = RT_ACCEL_KDTREE; a.isect_cost = api->find_int(p, "cost", 80); a.trav_cost = 1; a.empty_bonus = 0.5f; a.max_prims = 4; a.max_depth = -1;
     out->params = a; return 0; }
-extern "C" int CreateSampler(const PbrtHipParams *p, const PbrtHipParamsApi *api, PbrtHipSampler *out) {
+extern "C" int PbrtHipCreateSampler(const PbrtHipParams *p, const PbrtHipParamsApi *api, PbrtHipSampler *out) {
     out->kind = RT_SAMPLER_STRATIFIED; out->xsamples = out->ysamples = api->find_int(p, "side", 2); out->jitter = api->find_bool(p, "jitter", 0);
     out->pixelsamples = 4; out->seed = 11; return 0; }
 ''')
@@ -292,3 +294,34 @@ extern "C" int CreateSampler(const PbrtHipParams *p, const PbrtHipParamsApi *api
     assert ps3.valid and ps3.errors == 0 and ps3.render_view()["integrator"] == 2 and ps3.render_view()["max_depth"] == 5
     ps4 = pkg.ParsedScene(text=base.replace('SurfaceIntegrator "path"', 'SurfaceIntegrator "nosuchplugin"'))
     assert ps4.errors >= 1
+    # objects with the reference's factory names and the reference's (C++) signatures under the built-ins' names: one that loads, one that does not
+    # (an unresolved core symbol, as a real pbrt-v1 plugin has here).  Neither factory is called (they would abort); no error; the scene is the built-in's.
+    ref = tmp_path / "refdir"; ref.mkdir()
+    (tmp_path / "ref.cpp").write_text('''
+#include <cstdlib>
+struct ParamSet; struct Film;
+extern "C" void *CreateSampler(const ParamSet &, const Film *) { abort(); }
+extern "C" void *CreateSurfaceIntegrator(const ParamSet &) { abort(); }
+extern "C" void *CreateAccelerator(const void *, const ParamSet &) { abort(); }
+''')
+    (tmp_path / "ref2.cpp").write_text('''
+#include <cstdlib>
+extern int pbrt_core_symbol_that_is_not_here;
+extern "C" void *CreateVolumeIntegrator(const void *) { if (pbrt_core_symbol_that_is_not_here) abort(); return 0; }
+''')
+    for name in ("stratified", "path", "kdtree"):
+        subprocess.check_call(["g++", "-shared", "-fPIC", str(tmp_path / "ref.cpp"), "-o", str(ref / (name + ".so"))])
+    subprocess.check_call(["g++", "-shared", "-fPIC", str(tmp_path / "ref2.cpp"), "-o", str(ref / "emission.so")])
+    ps5 = pkg.ParsedScene(text=('SearchPath "%s"\n' % ref) + base.replace('WorldBegin', 'VolumeIntegrator "emission"\nWorldBegin'))
+    assert ps5.valid and ps5.errors == 0 and ps5.render_view()["integrator"] == 2 and ps5.render_view()["max_depth"] == 5
+    assert ps5.warnings <= 1                                        # at most the one "does not load here" of emission.so
+    # a plugin built against another plugin ABI is refused by its PbrtHipPluginAbi
+    (tmp_path / "old.cpp").write_text('''
+#include "pbrt_hip_plugin.h"
+extern "C" int PbrtHipPluginAbi(void) { return PBRT_HIP_PLUGIN_ABI + 1; }
+extern "C" int PbrtHipCreateSurfaceIntegrator(const PbrtHipParams *, const PbrtHipParamsApi *, PbrtHipSurfaceIntegrator *out) { out->kind = RT_INTEGRATOR_WHITTED; out->max_depth = 1; out->strategy = 0; return 0; }
+''')
+    old = tmp_path / "olddir"; old.mkdir()
+    subprocess.check_call(["g++", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"), str(tmp_path / "old.cpp"), "-o", str(old / "path.so")])
+    ps6 = pkg.ParsedScene(text=('SearchPath "%s"\n' % old) + base)
+    assert ps6.valid and ps6.errors == 0 and ps6.render_view()["integrator"] == 2 and ps6.warnings == 1

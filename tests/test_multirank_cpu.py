@@ -35,6 +35,56 @@ def _worker(rank, world, port, scene_text, tile, out_dir):
     dist.destroy_process_group()
 
 
+def pack_parts(accum, world, rows):
+    """numpy restatement of rt_film_pack_parts (include/pbrt_hip.h): [5][H][W] -> [world][5][rows][W], rows beyond H zero"""
+    _, H, W = accum.shape
+    pad = np.zeros((5, world * rows, W), np.float32)
+    pad[:, :H] = accum
+    return np.ascontiguousarray(pad.reshape(5, world, rows, W).transpose(1, 0, 2, 3))
+
+
+def _worker_parts(rank, world, port, scene_text, tile, out_dir):
+    """bench.py's N > 1 step since round 5: pack, ONE reduce-scatter, per-rank resolve of the rank's rows, ONE all-gather of RGBA rows"""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as entry
+    import oracle
+    pkg = entry.load_package()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ps = pkg.ParsedScene(text=scene_text)
+    ps.set_shard(rank, world, tile)
+    nodes, refs, bounds, _ = ps.kdtree()
+    _, _, accum, _ = oracle.render(ps, nodes, refs, bounds)
+    H, W = accum.shape[1:]
+    rows = (H + world - 1) // world
+    part = torch.zeros((5, rows, W))
+    dist.reduce_scatter_tensor(part.view(-1), torch.from_numpy(pack_parts(accum, world, rows)).view(-1))
+    rgb, alpha = oracle.resolve(part.numpy().copy(), premultiply=ps.premultiply)
+    rgba_all = torch.zeros((world * rows, W, 4))
+    dist.all_gather_into_tensor(rgba_all, torch.from_numpy(np.concatenate([rgb, alpha[..., None]], axis=-1).astype(np.float32)))
+    if rank == 1:                                                     # (any rank holds the whole frame)
+        np.save(os.path.join(out_dir, "rgba.npy"), rgba_all.numpy()[:H])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("tile", [(8, 8), 7])
+def test_two_rank_fused_merge_gives_the_single_rank_image(pkg, scenes, oracle, tmp_path, tile):
+    """21 film rows over 2 ranks: 11 each, the second rank's part padded by one row of zeros."""
+    import torch.multiprocessing as mp
+    text = scenes.cornell_scene(xres=24, yres=21, integrator="path", xsamples=2, ysamples=2, jitter=True, pixel_filter="mitchell", keyed=True)
+    ps = pkg.ParsedScene(text=text)
+    nodes, refs, bounds, _ = ps.kdtree()
+    rgb, alpha, _, _ = oracle.render(ps, nodes, refs, bounds)
+    port = 31500 + (os.getpid() + (tile if isinstance(tile, int) else 100 + tile[0])) % 2000
+    mp.spawn(_worker_parts, args=(2, port, text, tile, str(tmp_path)), nprocs=2, join=True)
+    rgba = np.load(tmp_path / "rgba.npy")
+    assert rgba.shape == (21, 24, 4)
+    assert np.allclose(rgba[..., :3], rgb, rtol=2e-5, atol=2e-6) and np.allclose(rgba[..., 3], alpha, rtol=2e-5, atol=2e-6)
+
+
 @pytest.mark.parametrize("tile", [7, 64, (8, 8), (16, 5)])
 def test_two_rank_tile_shards_sum_to_the_full_film(pkg, scenes, oracle, tmp_path, tile):
     import torch.multiprocessing as mp

@@ -111,24 +111,33 @@ def test_prebuilt_accelerator_gives_the_same_scene(pkg, scenes, tmp_path):
 
 
 def test_eight_ranks_on_one_gpu_rehearsal(pkg, tmp_path):
-    """The shape of the driver's 8-GPU run, rehearsed on the one GPU this box has: 8 ranks launched by torch.distributed.run
-    share GPU 0 over gloo; local rank 0 builds the accelerator and publishes it under /dev/shm, the other seven attach it
-    (rt_scene_create_prebuilt); 2-D tiles dealt round-robin; row-wise reduce-scatter with a film height that is NOT a multiple of the world
-    size (426 rows: 54 per rank, the last rank's padded), per-rank resolve, all-gather.  The frame is the single-rank frame, every camera
-    sample is rendered exactly once, and the tiles balance the ranks: max / mean of the per-rank ray counts <= 1.05."""
+    """The shape of the driver's 8-GPU run, rehearsed on the one GPU this box has: 8 ranks launched by
+    torch.distributed.run share GPU 0 over gloo; local rank 0 builds the accelerator and publishes it under /dev/shm, the other seven attach it
+    (rt_scene_create_prebuilt); 2-D tiles dealt round-robin; the merge is rt_film_pack_parts + ONE reduce-scatter (a film height that is NOT a
+    multiple of the world size: 426 rows, 54 per rank, the last rank's part padded) + per-rank RGBA resolve + ONE all-gather.  The run prints the
+    headline record AND, as at N > 1 in production (--multi-workloads), a C4-shaped (material mix, path depth 8) and a C5-shaped (medium, march
+    kernel) sub-record with per-rank figures.  Every frame is the single-rank frame, every camera sample is rendered exactly once, and the tiles
+    balance the ranks: max / mean of the per-rank ray counts <= 1.05."""
     if pkg.device_count() < 1:
         pytest.fail("no HIP device visible")
     env = dict(os.environ, PBRT_BENCH_BACKEND="gloo", PBRT_BENCH_SAME_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     one, eight = str(tmp_path / "one.npz"), str(tmp_path / "eight.npz")
-    base = ["--steps", "1", "--warmup", "0", "--workload", "t8", "--no-cpu-baseline", "--no-extra", "--tile-2d", "16", "--merge", "reduce_scatter"]
-    j1 = _bench(["--gpus", "1", "--dump-film", one] + base, env)
-    j8 = _bench(["--gpus", "8", "--dump-film", eight] + base, env, nproc=8, timeout=1500)
+    base = ["--steps", "1", "--warmup", "0", "--workload", "tsmall", "--multi-workloads", "t8,t5", "--no-cpu-baseline", "--tile-2d", "16", "--merge", "reduce_scatter"]
+    j8 = _bench(["--gpus", "8", "--dump-film", eight] + base, env, nproc=8, timeout=2400)
     assert j8["n_gpus"] == 8 and len(j8["per_rank"]) == 8
-    assert j8["config"]["camera_samples_per_frame"] == j1["config"]["camera_samples_per_frame"] == 644 * 430 * 4      # mitchell 2 x 2: the sample extent reaches 2 pixels beyond the film
-    assert abs(j8["config"]["rays_per_frame"] - j1["config"]["rays_per_frame"]) <= 2e-4 * j1["config"]["rays_per_frame"] + 8
-    rays = np.array([r["rays"] for r in j8["per_rank"]], np.float64)
-    assert rays.min() > 0 and rays.max() / rays.mean() <= 1.05, rays
-    a, b = np.load(one), np.load(eight)
-    assert a["rgb"].shape == (426, 640, 3)
-    assert np.allclose(a["rgb"], b["rgb"], rtol=2e-5, atol=2e-6) and np.allclose(a["alpha"], b["alpha"], rtol=2e-5, atol=2e-6)
+    assert [w["workload"] for w in j8["workloads"]] == ["t8", "t5"]
+    recs = {"tsmall": j8, "t8": j8["workloads"][0], "t5": j8["workloads"][1]}
+    for wl, rec in recs.items():
+        j1 = _bench(["--gpus", "1", "--dump-film", one, "--steps", "1", "--warmup", "0", "--workload", wl, "--no-cpu-baseline", "--no-extra", "--tile-2d", "16"], env)
+        assert rec["n_gpus"] == 8 and len(rec["per_rank"]) == 8, wl
+        assert rec["config"]["camera_samples_per_frame"] == j1["config"]["camera_samples_per_frame"], wl
+        if wl == "t8":
+            assert j1["config"]["camera_samples_per_frame"] == 644 * 430 * 4      # mitchell 2 x 2: the sample extent reaches 2 pixels beyond the film
+        assert abs(rec["config"]["rays_per_frame"] - j1["config"]["rays_per_frame"]) <= 2e-4 * j1["config"]["rays_per_frame"] + 8, wl
+        rays = np.array([r["rays"] for r in rec["per_rank"]], np.float64)
+        assert rays.min() > 0 and rays.max() / rays.mean() <= (1.05 if wl != "tsmall" else 1.25), (wl, rays)      # (tsmall: 160 x 120 pixels are 80 tiles for 8 ranks)
+        a, b = np.load(one), np.load(eight if wl == "tsmall" else eight.replace(".npz", "_%s.npz" % wl))
+        if wl == "t8":
+            assert a["rgb"].shape == (426, 640, 3)
+        assert np.allclose(a["rgb"], b["rgb"], rtol=2e-5, atol=2e-6) and np.allclose(a["alpha"], b["alpha"], rtol=2e-5, atol=2e-6), wl
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("pbrt_hip_accel_")]

@@ -31,7 +31,15 @@ def main():
 
     def run(u):
         obj = os.path.join(obj_dir, u.rsplit(".", 1)[0] + ".o")
-        subprocess.check_call(["hipcc"] + [f for f in pkg.HIPCC_FLAGS if f != "-shared"] + defines + ["-c", os.path.join(hip_dir, u), "-o", obj])
+        cmd = ["hipcc"] + [f for f in pkg.HIPCC_FLAGS if f != "-shared"] + defines + ["-c", os.path.join(hip_dir, u), "-o", obj]
+        if not u.endswith(".hip"):
+            subprocess.check_call(cmd)
+            return obj
+        r = subprocess.run(cmd + ["-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)      # the per-kernel resource report, as the product build keeps it
+        keep = [ln.split("remark:")[1].split("[-R")[0].rstrip() for ln in r.stderr.splitlines() if "remark:" in ln and any(k in ln for k in ("Function Name", " VGPRs:", "VGPRs Spill", "Occupancy", "ScratchSize", "LDS Size"))]
+        open(obj[:-2] + ".resources.txt", "w").write("\n".join(keep) + "\n")
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + r.stderr[-4000:])
         return obj
     with ThreadPoolExecutor(max_workers=min(len(units), os.cpu_count() or 4)) as ex:
         built = dict(zip(units, ex.map(run, units)))
