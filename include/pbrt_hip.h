@@ -91,7 +91,8 @@ typedef struct RtAccelParams {
     int32_t kind;
     int32_t isect_cost, trav_cost, max_prims, max_depth; /* kd defaults 80, 1, 1, -1 */
     float empty_bonus;                                    /* kd default 0.5           */
-    int32_t build_threads;                                /* 0 = auto                  */
+    int32_t build_threads;                                /* 0 = auto; -1 = the checking form of the kd build: one thread, every node
+                                                           * sorts its own edges as kdtree.cpp:246 does (same arrays, by test)  */
 } RtAccelParams;
 
 /* ---- quadrics: shapes/sphere.cpp:89-215, disk.cpp:51-130, cylinder.cpp:52-180, cone.cpp:41-186, paraboloid.cpp:44-190,

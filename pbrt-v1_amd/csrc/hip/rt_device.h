@@ -144,6 +144,9 @@ struct DevFrame {
     unsigned *wt_base;              // [total_work + 1]: pass 1 leaves a sample's shading-point count at [work]; scanned in place to the first ordinal
     float *wt_rec;                  // [point][1 + 2 * n_lights]: the light-number sample, then per light y(Ld) and y(n_lights * Ld)       (pass 2)
     float2 *wt_pick;                // [point]: the chosen light (int bits) and lightSampleWeight, 0 = the uniform start-up branch       (recurrence kernel)
+#ifdef RT_TAIL_PROBE
+    unsigned long long *probe;      // -DRT_TAIL_PROBE builds (tools/build_variant.py): per megakernel wave {start, work list found empty, end} in 10 ns ticks + samples taken
+#endif
 };
 
 // Explicit address spaces.  Pointers that live inside DevScene/DevFrame are loaded from memory, so the compiler cannot

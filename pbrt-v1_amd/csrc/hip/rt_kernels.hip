@@ -686,19 +686,10 @@ static void host_tri_frame(const float *v, bool flip, float nn[3], float sn[3]) 
 // consecutive 48-byte records; its run starts at a 128-byte boundary whenever starting where the previous leaf ended would make
 // it touch more 128-byte lines than necessary (measured: one L2 miss costs the same whether 8 or 128 bytes of the line are used,
 // ~56 G misses/s for the whole chip, and the 1 M-triangle frame makes 17 triangle tests per ray).
-// A vector whose resize() leaves the new elements uninitialised: the 12 GB of leaf-ordered records of a 10 M-triangle scene are first touched by
-// the threads that fill them, not zero-filled page by page by one thread beforehand.
-template <class T> struct NoInitAlloc : std::allocator<T> {
-    template <class U> struct rebind { using other = NoInitAlloc<U>; };
-    NoInitAlloc() = default;
-    template <class U> NoInitAlloc(const NoInitAlloc<U> &) {}
-    template <class U> void construct(U *) noexcept {}
-    template <class U, class... A> void construct(U *p, A &&...a) { ::new ((void *)p) U(std::forward<A>(a)...); }
-};
 typedef std::vector<float4, NoInitAlloc<float4>> LeafRecords;
 
 // pass 1 (sequential, arithmetic only): where every leaf's run starts; returns the array's size in float4 units
-static size_t leaf_order_offsets(const std::vector<Node> &nodes, std::vector<Node> &tnodes) {
+static size_t leaf_order_offsets(const NodeVec &nodes, NodeVec &tnodes) {
     tnodes = nodes;
     size_t off = 0;                                       // float4 units (16 B); a line is 8 units
     for (size_t i = 0; i < nodes.size(); ++i) {
@@ -715,7 +706,7 @@ static size_t leaf_order_offsets(const std::vector<Node> &nodes, std::vector<Nod
     return off ? off : 8;
 }
 // pass 2 on the host (the reference form of rt::derive_leaf_records_kernel below: PBRT_HIP_VERIFY_DERIVED compares the two byte for byte)
-static void leaf_order_fill_host(const std::vector<Node> &nodes, const std::vector<Node> &tnodes, const std::vector<uint32_t> &leaf_refs,
+static void leaf_order_fill_host(const NodeVec &nodes, const NodeVec &tnodes, const RefVec &leaf_refs,
                                  const std::vector<DevTri> &tris, LeafRecords &ltris, size_t units) {
     ltris.resize(units);
     std::memset((void *)ltris.data(), 0, units * sizeof(float4));
@@ -794,7 +785,7 @@ static void host_tri_frame_uv(const float *v, const float *uv, bool flip, float 
 #define RT_TOP_PREFIX 4095u          // 1365 blocks of three records: 11-12 levels of a full tree
 #endif
 struct PairBlockOrder { std::vector<uint32_t> order, pos; std::vector<uint8_t> owner; uint32_t top = 0; };
-static void pair_blocks_order(const std::vector<Node> &tn, PairBlockOrder &o) {
+static void pair_blocks_order(const NodeVec &tn, PairBlockOrder &o) {
     o.order.clear(); o.pos.clear(); o.owner.clear(); o.top = 0;
     if (tn.empty() || (tn[0].x & 3u) == 3u) return;
     auto interior = [&](uint32_t n) { return (tn[n].x & 3u) != 3u; };
@@ -840,7 +831,7 @@ static void pair_blocks_order(const std::vector<Node> &tn, PairBlockOrder &o) {
     }
 }
 // `tn`: the nodes with a leaf's word 1 = its position in ltris (interior nodes as in the tree: same shape as pair_blocks_order saw)
-static void pair_blocks_fill(const std::vector<Node> &tn, const PairBlockOrder &o, std::vector<uint4> &pairs, uint32_t &root_x, uint32_t &root_y) {
+static void pair_blocks_fill(const NodeVec &tn, const PairBlockOrder &o, std::vector<uint4> &pairs, uint32_t &root_x, uint32_t &root_y) {
     pairs.clear();
     if (tn.empty()) { root_x = 3u; root_y = 0u; pairs.push_back(make_uint4(3u, 0u, 3u, 0u)); return; }
     root_x = tn[0].x;
@@ -1221,7 +1212,7 @@ static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel 
     }
     tick("triangle / shading records");
     // nodes (+ one node of padding: the traversal may fetch node i+1 together with node i) and the leaf lists
-    auto upload_nodes = [&](const std::vector<Node> &v, const uint2 **dev) -> int {
+    auto upload_nodes = [&](const NodeVec &v, const uint2 **dev) -> int {
         void *p = nullptr;
         HIPCHK(hipMalloc(&p, (v.size() + 1) * sizeof(uint2)));
         s->allocs.push_back(p);
@@ -1237,7 +1228,7 @@ static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel 
     s->dev.nodes = nodes_dev;
     s->dev.tnodes = nodes_dev;
     if (s->accel_kind == RT_ACCEL_KDTREE) {
-        std::vector<Node> tn;
+        NodeVec tn;
         tick("node / leaf-list upload");
         PairBlockOrder pbo;
         std::thread order_thread([&] { pair_blocks_order(s->tree.nodes, pbo); });      // beside the offsets pass and the uploads below
@@ -1985,6 +1976,13 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
             HIPCHK(hipEventRecord(s->ev1, s->stream));
             s->last_pipeline = false; s->last_weighted = true;
         } else {
+#ifdef RT_TAIL_PROBE
+        static unsigned long long *probe = nullptr;
+        const size_t n_waves = size_t(s->grids[variant]) * (RT_BLOCK / 64);
+        if (!probe) HIPCHK(hipMalloc((void **)&probe, size_t(s->n_threads / 64 + 64) * 4 * sizeof(unsigned long long)));
+        HIPCHK(hipMemsetAsync(probe, 0, n_waves * 4 * sizeof(unsigned long long), s->stream));
+        fr.probe = probe;
+#endif
         HIPCHK(hipMemcpyAsync(s->dev_frame, &fr, sizeof(DevFrame), hipMemcpyHostToDevice, s->stream));
         HIPCHK(hipMemsetAsync(s->work_counter, 0, 64 * sizeof(unsigned long long), s->stream));
         HIPCHK(hipEventRecord(s->ev0, s->stream));
@@ -1992,6 +1990,30 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
                            (const DevScene *)s->dev_scene, (const DevFrame *)s->dev_frame);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(s->ev1, s->stream));
+#ifdef RT_TAIL_PROBE
+        {   // the launch's timeline: when the waves started, when each found the work list empty, when each ended (10 ns ticks of s_memrealtime)
+            std::vector<unsigned long long> h(n_waves * 4);
+            HIPCHK(hipStreamSynchronize(s->stream));
+            HIPCHK(hipMemcpy(h.data(), probe, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            unsigned long long t0 = ~0ull, t0max = 0, e0 = ~0ull, e1 = 0, x1 = 0, smin = ~0ull, smax = 0, stot = 0;
+            std::vector<double> ends, drain;
+            for (size_t w = 0; w < n_waves; ++w) {
+                const unsigned long long *r = &h[4 * w];
+                if (!r[2]) continue;
+                t0 = std::min(t0, r[0]); t0max = std::max(t0max, r[0]); x1 = std::max(x1, r[2]);
+                if (r[1]) { e0 = std::min(e0, r[1]); e1 = std::max(e1, r[1]); drain.push_back(double(r[2] - r[1]) * 1e-2); }
+                smin = std::min(smin, r[3]); smax = std::max(smax, r[3]); stot += r[3];
+                ends.push_back(double(r[2]));
+            }
+            std::sort(ends.begin(), ends.end()); std::sort(drain.begin(), drain.end());
+            auto q = [&](const std::vector<double> &v, double f) { return v.empty() ? 0.0 : v[size_t(f * (v.size() - 1))]; };
+            std::fprintf(stderr, "RT_TAIL_PROBE waves=%zu span=%.1f us | starts spread %.1f us | list first seen empty at %.1f us, last at %.1f us | wave ends (us after start): p1 %.1f p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f | "
+                                 "drain per wave (end - empty, us): p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f | samples per wave min %llu mean %.1f max %llu\n",
+                         ends.size(), double(x1 - t0) * 1e-2, double(t0max - t0) * 1e-2, double(e0 - t0) * 1e-2, double(e1 - t0) * 1e-2,
+                         (q(ends, .01) - double(t0)) * 1e-2, (q(ends, .1) - double(t0)) * 1e-2, (q(ends, .5) - double(t0)) * 1e-2, (q(ends, .9) - double(t0)) * 1e-2, (q(ends, .99) - double(t0)) * 1e-2, (q(ends, 1.) - double(t0)) * 1e-2,
+                         q(drain, .1), q(drain, .5), q(drain, .9), q(drain, .99), q(drain, 1.), smin, double(stot) / double(std::max<size_t>(ends.size(), 1)), smax);
+        }
+#endif
         s->last_pipeline = false; s->last_weighted = false;
         }
     }

@@ -82,6 +82,10 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
 #else
 #define RT_PF(x)
 #endif
+#ifdef RT_TAIL_PROBE
+    const unsigned long long tp_start = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tp_empty = 0, tp_taken = 0;
+#endif
     unsigned long long w_next = 0, w_end = 0;                              // this wave's chunk of the sample list (wave-uniform)
     const unsigned n_bands = fr.xcd_bands ? 8u : 1u, home = fr.xcd_bands ? (blockIdx.x & 7u) : 0u;
     unsigned band_shift = 0;                                               // bands this wave has seen the end of
@@ -118,6 +122,9 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
                     }
                 }
                 const bool none_left = band_shift >= n_bands;             // every band's counter has passed its end
+#ifdef RT_TAIL_PROBE
+                if (none_left && !tp_empty) tp_empty = __builtin_amdgcn_s_memrealtime();
+#endif
                 const unsigned long long rk = __popcll(want & ((1ull << lane) - 1ull));
                 const unsigned long long w_mine = rk < have ? w_next + rk : fresh + (rk - have);
                 const bool got = rk < have || w_mine < fresh_end;          // (a chunk clipped at its band's end serves fewer lanes: the others ask again)
@@ -128,6 +135,9 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
                 if (!ln.has_ray && ln.stage == ST_FETCH && !got) { if (none_left) ln.stage = ST_EXIT; }
                 else if (!ln.has_ray && ln.stage == ST_FETCH) {
                     const unsigned long long w = w_mine;
+#ifdef RT_TAIL_PROBE
+                    tp_taken += 1;
+#endif
                     {
                         unsigned long long pixel; int s;
                         bool ok;
@@ -177,6 +187,15 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
     }
 #endif
 
+#ifdef RT_TAIL_PROBE
+    {
+        for (int off = 32; off > 0; off >>= 1) tp_taken += __shfl_down(tp_taken, off);
+        if (lane == 0 && fr.probe) {
+            unsigned long long *o = fr.probe + size_t(gtid >> 6) * 4u;
+            o[0] = tp_start; o[1] = tp_empty; o[2] = __builtin_amdgcn_s_memrealtime(); o[3] = tp_taken;
+        }
+    }
+#endif
     if (COUNT && !(INTEG == RT_INTEG_DIRECT_WEIGHTED && fr.weighted_phase != 3)) {       // (a weighted frame's count and survey passes are not Scene::Render's rays)
         unsigned long long v[8] = {c_cam, c_closest, c_any, tc.nodes, tc.leaf_refs, tc.tris, c_bad, tc.spills};
 #pragma unroll

@@ -163,11 +163,13 @@ def test_parallel_kd_build_equals_serial_and_the_reference_at_60k(pkg, scenes):
         _fields_ = [("kind", C.c_int32), ("isect_cost", C.c_int32), ("trav_cost", C.c_int32), ("max_prims", C.c_int32), ("max_depth", C.c_int32),
                     ("empty_bonus", C.c_float), ("build_threads", C.c_int32)]
     out = {}
-    for threads in (1, 8):
+    for threads in (1, 8, 3, -1):                       # -1: the sorting form (every node sorts its own edges, kdtree.cpp:246) of the sort-once build
         p = P(0, 80, 1, 1, -1, 0.5, threads)
         out[threads] = pkg.build_kdtree(tv, C.addressof(p))
     (n1, r1, b1, i1), (n8, r8, b8, i8) = out[1], out[8]
-    assert np.array_equal(n1, n8) and np.array_equal(r1, r8) and np.array_equal(b1, b8) and i1.max_depth == i8.max_depth
+    for k in (8, 3, -1):
+        nk, rk, bk, ik = out[k]
+        assert np.array_equal(n1, nk) and np.array_equal(r1, rk) and np.array_equal(b1, bk) and i1.max_depth == ik.max_depth, k
     table = json.loads(str(np.load(os.path.join(ROOT, "tests", "golden", "chain", "kd_soup60k.npz"))["stats"]))
     leaf = (n8[:, 0] & 3) == 3
     for key, mine in (("Interior kd-tree nodes made", int((~leaf).sum())), ("Leaf kd-tree nodes made", int(leaf.sum()))):
@@ -177,6 +179,38 @@ def test_parallel_kd_build_equals_serial_and_the_reference_at_60k(pkg, scenes):
     ref_refs, ref_leaves = (stat_int(x)[0] for x in table["Avg. number of primitives in leaf nodes"].split(":"))
     assert abs(int(nprims.sum()) - ref_refs) <= 0.0006 * ref_refs + 50 and abs(int(leaf.sum()) - ref_leaves) <= 0.0006 * ref_leaves + 50
     assert int(nprims.max()) == int(table["Maximum number of primitives in leaf node"])
+
+
+def test_kd_build_tie_order_is_defined(pkg):
+    """Edges that compare equal under the reference's (t, START < END) keep whatever order its std::sort leaves them in; the order shows (it is the
+    order of a leaf's primitives).  kd_build.cpp defines it -- (t, START < END, primitive number) -- which is what lets it sort once at the root and
+    filter below.  Triangles on a lattice (nearly every bound ties with many others): the sort-once build, serial and with 2 / 5 / 8 threads, and the
+    form that sorts in every node give the same arrays; every primitive of the scene is referenced; leaves list their primitives in ascending order
+    of the split that separated them -- here simply: no leaf lists a primitive twice."""
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    n = 30000
+    centre = np.floor(rng.uniform(0, 556, (n, 1, 3)) / 16) * 16
+    tv = (centre + np.floor(rng.uniform(-8, 8, (n, 3, 3)) / 4) * 4).astype(np.float32).reshape(n, 9)
+    class P(C.Structure):
+        _fields_ = [("kind", C.c_int32), ("isect_cost", C.c_int32), ("trav_cost", C.c_int32), ("max_prims", C.c_int32), ("max_depth", C.c_int32),
+                    ("empty_bonus", C.c_float), ("build_threads", C.c_int32)]
+    ref = None
+    for threads in (-1, 1, 2, 5, 8):
+        p = P(0, 80, 1, 1, -1, 0.5, threads)
+        nodes, refs, bounds, info = pkg.build_kdtree(tv, C.addressof(p))
+        if ref is None:
+            ref = (nodes, refs, bounds, info.max_depth)
+        else:
+            assert np.array_equal(ref[0], nodes) and np.array_equal(ref[1], refs) and np.array_equal(ref[2], bounds) and ref[3] == info.max_depth, threads
+    nodes, refs = ref[0], ref[1]
+    leaf = (nodes[:, 0] & 3) == 3
+    np_leaf = nodes[leaf, 0] >> 2
+    single = nodes[leaf][np_leaf == 1][:, 1]
+    assert len(np.unique(np.concatenate([refs, single]))) == n
+    for x, y in nodes[leaf][np_leaf > 1][:2000]:
+        lst = refs[y:y + (x >> 2)]
+        assert len(np.unique(lst)) == len(lst)
 
 
 def test_kd_build_equals_the_reference_at_1m(pkg, scenes):
