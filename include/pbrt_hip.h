@@ -156,8 +156,9 @@ typedef struct RtSceneDesc {
 enum { RT_INTEGRATOR_WHITTED = 0, RT_INTEGRATOR_DIRECT = 1, RT_INTEGRATOR_PATH = 2 };
 enum { RT_STRATEGY_ALL = 0, RT_STRATEGY_ONE = 1, RT_STRATEGY_WEIGHTED = 2 };
 /* RT_STRATEGY_WEIGHTED: WeightedSampleOneLight (transport.cpp:71-122), a recurrence over every shading point of the frame in program order.
- * rt_render accepts it on one shard (shard_count == 1) for scenes whose lights all draw the same number of random numbers per estimate
- * (any mix of point / spot / distant / single-triangle / quadric emitters, or only emitters of several triangles) and at most 2048 lights.
+ * rt_render accepts it on one shard (shard_count == 1) with at most 2048 lights of any mix (round 5: emitters of several triangles, which draw one
+ * random number per estimate -- ShapeSet::Sample, shape.h:115-121 -- next to lights that draw none: the survey then keeps one estimate per possible
+ * position of that draw in the sample's stream).
  * Such a frame is five launches (RtRenderStats.weighted_ms); rt_render waits on the stream once in the middle of it, for the number of shading
  * points that sizes the survey's tables (every other frame is asynchronous from the first launch on).  That wait is also the one place where
  * rt_render can fail AFTER launching work (2^32 or more shading points, no memory for the survey's tables): the film and the sample buffer are

@@ -159,7 +159,9 @@ class Builder {
             split(root, L, depth, 0);
             return;
         }
-        std::vector<Task> tk; tasks = &tk; cutoff = std::max(2048, int(nTris / (8 * threads)));
+        int per_thread = 8;                                            // tasks per thread the cut aims at (subtree sizes vary a lot: more, smaller tasks balance the pool)
+        if (const char *e = std::getenv("PBRT_HIP_KD_TASKS_PER_THREAD")) per_thread = std::max(1, std::atoi(e));
+        std::vector<Task> tk; tasks = &tk; cutoff = std::max(2048, int(nTris / (size_t(per_thread) * threads)));
         fork_levels = 0; for (int t = 1; t < threads && fork_levels < 6; t <<= 1) ++fork_levels;
         par = threads;
         split(root, L, depth, 0);
@@ -173,11 +175,15 @@ class Builder {
         std::vector<size_t> order(tk.size());
         for (size_t i = 0; i < tk.size(); ++i) order[i] = i;
         std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return tk[x].prims.size() != tk[y].prims.size() ? tk[x].prims.size() > tk[y].prims.size() : x < y; });
+        std::vector<double> idle_at(size_t(threads), 0.0);
+        const auto pool_t0 = std::chrono::steady_clock::now();
+        std::atomic<int> worker_id(0);
         auto worker = [&]() {
+            const int me = worker_id.fetch_add(1);
             Builder sub(*this, nullptr);                           // one scratch stack per worker, reused by its tasks
             for (;;) {
                 const size_t k = next.fetch_add(1);
-                if (k >= tk.size()) return;
+                if (k >= tk.size()) { idle_at[size_t(me)] = std::chrono::duration<double>(std::chrono::steady_clock::now() - pool_t0).count(); return; }
                 Task &t = tk[order[k]];
                 sub.target = &t.sub;
                 sub.build_task(t);
@@ -187,7 +193,11 @@ class Builder {
         for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
         for (auto &th : pool) th.join();
         tick("task pool");
-        if (log) std::fprintf(stderr, "KDBUILD %zu tasks, cutoff %d, %d threads\n", tk.size(), cutoff, threads);
+        if (log) {
+            std::sort(idle_at.begin(), idle_at.end());
+            std::fprintf(stderr, "KDBUILD %zu tasks, cutoff %d, %d threads; workers ran out of tasks after %.3f (first) / %.3f (median) / %.3f s (last)\n", tk.size(), cutoff, threads,
+                         idle_at.front(), idle_at[idle_at.size() / 2], idle_at.back());
+        }
         stitch(tk, threads);
         tick("stitch");
     }

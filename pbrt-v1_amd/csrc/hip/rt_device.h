@@ -144,6 +144,13 @@ struct DevFrame {
     unsigned *wt_base;              // [total_work + 1]: pass 1 leaves a sample's shading-point count at [work]; scanned in place to the first ordinal
     float *wt_rec;                  // [point][1 + 2 * n_lights]: the light-number sample, then per light y(Ld) and y(n_lights * Ld)       (pass 2)
     float2 *wt_pick;                // [point]: the chosen light (int bits) and lightSampleWeight, 0 = the uniform start-up branch       (recurrence kernel)
+    // lights of MIXED RNG use (an emitter of several triangles draws its triangle, ShapeSet::Sample shape.h:115-121; every other light draws nothing): the RNG
+    // counter at a sample's j-th shading point depends on how many of the j points before it chose a drawing light (k = 0 .. j), so the survey keeps, for
+    // every drawing light, one estimate per k; a point's record is [u | per light: (y, y*n) once, or j + 1 times for a drawing light] and the records of
+    // sample `work` start at wt_recbase[work]
+    int wt_mixed;
+    unsigned wt_nd;                 // number of drawing lights
+    const unsigned *wt_recbase;     // [total_work + 1], float offsets into wt_rec
 #ifdef RT_TAIL_PROBE
     unsigned long long *probe;      // -DRT_TAIL_PROBE builds (tools/build_variant.py): per megakernel wave {start, work list found empty, end} in 10 ns ticks + samples taken
 #endif

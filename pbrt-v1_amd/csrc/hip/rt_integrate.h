@@ -420,6 +420,15 @@ RT_DEV void estimate_direct_bsdf(const DevScene &sc, Lane &ln) {
     }
 }
 
+// DirectLighting "weighted" (rt_weighted.h): does one EstimateDirect of this light draw a random number (ShapeSet::Sample's triangle pick, shape.h:115-121)?
+RT_DEV bool light_draws_rng(LightRef L) { return !light_is_delta(L) && L.quadric < 0 && L.n_tris > 1u; }
+// ... and where the survey's record of the lane's current shading point starts in DevFrame::wt_rec (floats)
+RT_DEV size_t weighted_record(const DevFrame &fr, const Lane &ln, int nLights) {
+    if (!fr.wt_mixed) return size_t(ln.ord) * size_t(1 + 2 * nLights);
+    const size_t j = ln.ord - RT_GPTR(const unsigned, fr.wt_base)[ln.work];
+    return size_t(RT_GPTR(const unsigned, fr.wt_recbase)[ln.work]) + j * size_t(1 + 2 * (nLights - int(fr.wt_nd))) + size_t(fr.wt_nd) * j * (j + 1);
+}
+
 // light-sampling half
 template <bool EXT, bool DEFER = false>
 RT_DEV void estimate_direct_begin(const DevScene &sc, Lane &ln, int light, float ls1, float ls2) {
@@ -603,7 +612,12 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
             if (nLights == 0) { ln.stage = ST_SPECULAR; return; }                                   // directlighting.cpp:106
             if (fr.weighted_phase == 1) { ++ln.ord; ln.stage = ST_SPECULAR; return; }             // count: the specular tree alone
             if (fr.weighted_phase == 3 && ln.li > 0) { ln.stage = ST_SPECULAR; return; }
-            if (fr.weighted_phase == 2) {
+            if (fr.weighted_phase == 2 && fr.wt_mixed) {
+                // lights of mixed RNG use: light li with the counter k = lj draws further (every k the frame pass can arrive with, DevFrame::wt_mixed)
+                if (ln.li == 0 && ln.lj == 0) { ln.ctr0 = ln.rng.ctr; ln.wt_w = __uint_as_float(1u); }      // wt_w: where the next estimate goes inside the point's record
+                if (ln.li >= nLights) { ++ln.ord; ln.rng.ctr = ln.ctr0; ln.lj = 0; ln.stage = ST_SPECULAR; return; }   // the counter stands at k = 0: nothing but the chosen lights' draws moves it
+                ln.rng.ctr = ln.ctr0 + uint32_t(ln.lj);
+            } else if (fr.weighted_phase == 2) {
                 if (ln.li == 0) ln.ctr0 = ln.rng.ctr;
                 if (ln.li >= nLights) { ++ln.ord; ln.stage = ST_SPECULAR; return; }                // (the counter stands where one estimate leaves it)
                 ln.rng.ctr = ln.ctr0;
@@ -612,7 +626,7 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
             ln.bs1 = dim_value(fr, ln, fr.two_d[1], 0, 0); ln.bs2 = dim_value(fr, ln, fr.two_d[1], 0, 1);
             ln.bcs = dim_value(fr, ln, fr.one_d[1], 0, 0);
             if (fr.weighted_phase == 2) {
-                if (ln.li == 0) RT_GPTR(float, fr.wt_rec)[size_t(ln.ord) * size_t(1 + 2 * nLights)] = dim_value(fr, ln, fr.one_d[0], 0, 0);
+                if (ln.li == 0 && ln.lj == 0) RT_GPTR(float, fr.wt_rec)[weighted_record(fr, ln, nLights)] = dim_value(fr, ln, fr.one_d[0], 0, 0);
                 estimate_direct_begin<EXT, DEFER>(sc, ln, ln.li, ls1, ls2);
             } else {
                 const float2 pick = RT_GPTR(const float2, fr.wt_pick)[ln.ord++];
@@ -715,10 +729,16 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
         const int nLights = int(sc.n_lights);
         if constexpr (WEIGHTED) {
             if (fr.weighted_phase == 2) {                                       // survey: what L.y() would be had this light been the chosen one
-                float RT_G *rec = RT_GPTR(float, fr.wt_rec) + size_t(ln.ord) * size_t(1 + 2 * nLights) + 1 + 2 * ln.li;
+                const unsigned at = fr.wt_mixed ? __float_as_uint(ln.wt_w) : 1u + 2u * unsigned(ln.li);
+                float RT_G *rec = RT_GPTR(float, fr.wt_rec) + weighted_record(fr, ln, nLights) + at;
                 rec[0] = lum_y(ln.Ld);                                          // transport.cpp:113 (weighted branch)
                 rec[1] = lum_y(ln.Ld * float(nLights));                         // transport.cpp:95  (start-up branch: L = nLights * EstimateDirect)
-                ++ln.li; ln.stage = ST_DIRECT_NEXT;
+                if (fr.wt_mixed) {
+                    ln.wt_w = __uint_as_float(at + 2u);
+                    const unsigned j = ln.ord - RT_GPTR(const unsigned, fr.wt_base)[ln.work];      // this is the sample's j-th shading point: k = 0 .. j
+                    if (light_draws_rng(RT_LIGHT(sc, ln.li)) && unsigned(ln.lj) < j) ++ln.lj; else { ln.lj = 0; ++ln.li; }
+                } else ++ln.li;
+                ln.stage = ST_DIRECT_NEXT;
             } else {
                 if (ln.wt_w == 0.f) ln.L = ln.L + ln.Ld * float(nLights);       // UniformSampleOneLight transport.cpp:66-69
                 else ln.L = ln.L + div_s(ln.Ld, ln.wt_w);                       // L /= lightSampleWeight transport.cpp:118

@@ -628,6 +628,8 @@ struct RtScene {
     unsigned wgrids[8] = {0};          // ... of the DirectLighting "weighted" family (rt_mega_dw.hip)
     DimReq *light_dims = nullptr; size_t light_dims_cap = 0;      // DirectLighting "all": the per-light sample requests (make_frame)
     std::vector<DimReq> light_dims_host;
+    const unsigned *light_draw_flags = nullptr; unsigned n_drawing_lights = 0;
+    unsigned *wt_recbase = nullptr; size_t wt_recbase_cap = 0;
     int light_draws = 0;               // RandomFloat()s one EstimateDirect draws: the same for every light (0 / 1), or -1 when the lights differ
     unsigned *wt_base = nullptr; size_t wt_base_cap = 0; float *wt_rec = nullptr; size_t wt_rec_cap = 0; float2 *wt_pick = nullptr; size_t wt_pick_cap = 0;
     unsigned long long *wt_sums = nullptr;                     // per-block sums of the point-count scan
@@ -1328,9 +1330,15 @@ static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel 
     }
     if ((rc = upload(s, lights.data(), lights.size(), &s->dev.lights))) return rc;
     if ((rc = upload(s, ltris.data(), ltris.size(), &s->dev.light_tris))) return rc;
-    for (uint32_t i = 0; i < d->n_lights; ++i) {           // ShapeSet::Sample (shape.h:115-121) draws one RandomFloat() when the emitter has several triangles
-        const int draws = (d->lights[i].type == RT_LIGHT_AREA && d->lights[i].quadric_plus1 == 0 && d->lights[i].n_tris > 1) ? 1 : 0;
-        if (i == 0) s->light_draws = draws; else if (draws != s->light_draws) s->light_draws = -1;
+    {
+        std::vector<unsigned> flags(d->n_lights ? d->n_lights : 1, 0u);
+        s->n_drawing_lights = 0;
+        for (uint32_t i = 0; i < d->n_lights; ++i) {       // ShapeSet::Sample (shape.h:115-121) draws one RandomFloat() when the emitter has several triangles
+            const int draws = (d->lights[i].type == RT_LIGHT_AREA && d->lights[i].quadric_plus1 == 0 && d->lights[i].n_tris > 1) ? 1 : 0;
+            if (i == 0) s->light_draws = draws; else if (draws != s->light_draws) s->light_draws = -1;
+            flags[i] = unsigned(draws); s->n_drawing_lights += unsigned(draws);
+        }
+        if ((rc = upload(s, flags.data(), flags.size(), &s->light_draw_flags))) return rc;      // (read by the recurrence of a "weighted" frame with lights of mixed RNG use)
     }
 
     s->dev.n_tris = d->n_tris; s->dev.n_lights = d->n_lights;
@@ -1406,6 +1414,7 @@ int rt_scene_destroy(RtScene *s) {
     if (s->vol_buf) HIPWARN(hipFree(s->vol_buf));
     if (s->light_dims) HIPWARN(hipFree(s->light_dims));
     if (s->wt_base) HIPWARN(hipFree(s->wt_base));
+    if (s->wt_recbase) HIPWARN(hipFree(s->wt_recbase));
     if (s->wt_rec) HIPWARN(hipFree(s->wt_rec));
     if (s->wt_pick) HIPWARN(hipFree(s->wt_pick));
     if (s->wt_total) HIPWARN(hipHostFree(s->wt_total));
@@ -1809,8 +1818,8 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
     if (rd->integrator == RT_INTEGRATOR_DIRECT && (rd->strategy < RT_STRATEGY_ALL || rd->strategy > RT_STRATEGY_WEIGHTED)) return fail(RT_EINVAL, "rt_render: unknown direct lighting strategy");
     if (weighted) {                                           // WeightedSampleOneLight: rt_weighted.h
         if (fr.shard_count != 1) return fail(RT_EINVAL, "rt_render: strategy \"weighted\" is a recurrence over the whole frame in the sampler's order (transport.cpp:71-122): one shard only");
-        if (s->light_draws < 0) return fail(RT_EINVAL, "rt_render: strategy \"weighted\" needs lights that draw the same number of random numbers per estimate "
-                                                       "(emitters of several triangles draw one, ShapeSet::Sample shape.h:115-121; every other light none): this scene mixes them");
+        // (lights of mixed RNG use -- an emitter of several triangles draws its triangle, every other light draws nothing -- run the general form of the
+        // survey and the recurrence: DevFrame::wt_mixed)
         // With a medium EstimateDirect draws one RandomFloat per UNOCCLUDED shadow / MIS ray (Scene::Transmittance), so the draws of an estimate depend on
         // the light AND on occlusion: the survey pass (every light, the counter left where the LAST light's estimate ends) and the frame pass (the chosen
         // light only) then reach the sample's next shading point with different counters, and a light that draws (ShapeSet::Sample's triangle pick) is fed
@@ -1925,7 +1934,7 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
         if (fr.high_occupancy && !s->counting) variant = 24 + ((s->volume.present ? 1 : 0) * 2 + (s->accel_kind == RT_ACCEL_GRID ? 1 : 0)) * 3 + rd->integrator;
         if (s->has_ext && !s->counting) variant = 36 + ((s->volume.present ? 1 : 0) * 2 + (s->accel_kind == RT_ACCEL_GRID ? 1 : 0)) * 3 + rd->integrator;
         if (s->grids[variant] == 0) return fail(RT_ESTATE, "render kernel variant has no resident grid");
-        fr.weighted_phase = 0; fr.wt_base = nullptr; fr.wt_rec = nullptr; fr.wt_pick = nullptr;
+        fr.weighted_phase = 0; fr.wt_base = nullptr; fr.wt_rec = nullptr; fr.wt_pick = nullptr; fr.wt_mixed = 0; fr.wt_nd = 0; fr.wt_recbase = nullptr;
         if (weighted) {
             // rt_weighted.h: count -> scan -> survey -> recurrence -> the frame.  ev0 .. ev1 bracket all of it (kernel_ms of a weighted frame is the five together)
             const int wk = ((s->volume.present ? 1 : 0) * 2 + (s->accel_kind == RT_ACCEL_GRID ? 1 : 0)) * 2 + (s->counting ? 1 : 0);
@@ -1956,7 +1965,25 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
             auto late_fail = [&](int code, const char *msg) { s->last_weighted = false; s->last_pipeline = false; s->have_timing = false; s->wt_points = 0; return fail(code, msg); };
             if (n_points >= 0xffffffffull) return late_fail(RT_EINVAL, "rt_render: strategy \"weighted\": more than 2^32 - 2 shading points in the frame");
             s->wt_points = n_points;
-            rc = ensure(s, &s->wt_rec, &s->wt_rec_cap, size_t(n_points) * size_t(R) + 1); if (rc) return late_fail(rc, rt_last_error());
+            const bool mixed = s->light_draws < 0;
+            const int nD = int(s->n_drawing_lights);
+            size_t rec_floats = size_t(n_points) * size_t(R);
+            fr.wt_mixed = mixed ? 1 : 0; fr.wt_nd = unsigned(nD); fr.wt_recbase = nullptr;
+            if (mixed) {
+                // where every sample's records start: per-sample sizes from the point counts (P * A + nD * P * (P + 1)), scanned like the counts were
+                rc = ensure(s, &s->wt_recbase, &s->wt_recbase_cap, size_t(fr.total_work) + 1); if (rc) return late_fail(rc, rt_last_error());
+                const unsigned long long nw = fr.total_work;
+                if (nw) hipLaunchKernelGGL(weighted_sizes_kernel, dim3(unsigned((nw + 255) / 256)), dim3(256), 0, s->stream, (const unsigned *)s->wt_base, nw, unsigned(1 + 2 * (nL - nD)), unsigned(nD), s->wt_recbase);
+                hipLaunchKernelGGL(weighted_scan_sums_kernel, dim3(RT_WSCAN_BLOCKS), dim3(RT_WSCAN_THREADS), 0, s->stream, (const unsigned *)s->wt_recbase, nw, s->wt_sums);
+                hipLaunchKernelGGL(weighted_scan_top_kernel, dim3(1), dim3(RT_WSCAN_THREADS), 0, s->stream, s->wt_recbase, nw, s->wt_sums, s->wt_total);
+                hipLaunchKernelGGL(weighted_scan_apply_kernel, dim3(RT_WSCAN_BLOCKS), dim3(RT_WSCAN_THREADS), 0, s->stream, s->wt_recbase, nw, (const unsigned long long *)s->wt_sums);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipStreamSynchronize(s->stream));
+                if (*s->wt_total >= 0xffffffffull) return late_fail(RT_EINVAL, "rt_render: strategy \"weighted\" with lights of mixed RNG use: the survey's records exceed 2^32 floats");
+                rec_floats = size_t(*s->wt_total);
+                fr.wt_recbase = s->wt_recbase;
+            }
+            rc = ensure(s, &s->wt_rec, &s->wt_rec_cap, rec_floats + 1); if (rc) return late_fail(rc, rt_last_error());
             rc = ensure(s, &s->wt_pick, &s->wt_pick_cap, size_t(n_points) + 1); if (rc) return late_fail(rc, rt_last_error());
             fr.wt_rec = s->wt_rec; fr.wt_pick = s->wt_pick;
             if (n_points > 0) {
@@ -1967,8 +1994,19 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
                 int chunk = int((size_t(64) * 1024 / 4 - state_f - 2) / size_t(R + 2));
                 chunk = chunk > 1024 ? 1024 : chunk < 1 ? 1 : chunk;
                 const size_t lds = (state_f + size_t((chunk * R + 1) & ~1) + size_t(chunk) * 2) * sizeof(float);
+                if (mixed) {
+                    // LDS of the general form: [5 nL + 1 state | 2 x (group + 1) sample offsets | staged records | staged picks] within 64 KB
+                    const int group = 256;
+                    const size_t fixed = size_t(5 * nL + 2) + 2 * size_t(group + 1);
+                    const size_t room = size_t(64) * 1024 / 4 - fixed - 4;
+                    const int cap_points = int(room / 4 / 2), cap_floats = int(room - size_t(cap_points) * 2) & ~1;     // a quarter of the room for the picks (2 floats each)
+                    const size_t mlds = (fixed + size_t(cap_floats) + 2 + size_t(cap_points) * 2) * sizeof(float);
+                    hipLaunchKernelGGL(weighted_recurrence_mixed_kernel, dim3(1), dim3(64), mlds, s->stream, (const float *)s->wt_rec, s->wt_pick, (const unsigned *)s->wt_base,
+                                       (const unsigned *)s->wt_recbase, (unsigned long long)fr.total_work, nL, nD, s->light_draw_flags, group, cap_floats, cap_points);
+                } else {
                 auto rk = nL <= 64 ? weighted_recurrence_lanes_kernel : weighted_recurrence_lds_kernel;      // light i in lane i | tables in LDS, one lane
                 hipLaunchKernelGGL(rk, dim3(1), dim3(64), lds, s->stream, (const float *)s->wt_rec, s->wt_pick, n_points, nL, chunk);
+                }
                 HIPCHK(hipGetLastError());
                 HIPCHK(hipEventRecord(s->wt_ev[3], s->stream));
             } else { HIPCHK(hipEventRecord(s->wt_ev[2], s->stream)); HIPCHK(hipEventRecord(s->wt_ev[3], s->stream)); }

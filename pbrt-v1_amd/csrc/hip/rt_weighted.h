@@ -183,4 +183,89 @@ __global__ __launch_bounds__(64) void weighted_recurrence_lds_kernel(const float
     }
 }
 
+
+// ---- lights of mixed RNG use (DevFrame::wt_mixed) ------------------------------------------------------------------------------------------
+// A sample with P shading points holds P * A + nD * P * (P + 1) record floats (A = 1 + 2 * (nL - nD); point j: A + 2 * nD * (j + 1)).
+__global__ void weighted_sizes_kernel(const unsigned *__restrict__ base, unsigned long long n, unsigned A, unsigned nD, unsigned *__restrict__ recbase) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long P = base[i + 1] - base[i];
+    const unsigned long long sz = P * A + (unsigned long long)nD * P * (P + 1);
+    recbase[i] = sz > 0xffffffffull ? 0xffffffffu : unsigned(sz);        // (the scan's 64-bit total then passes 2^32 and the host refuses the frame)
+}
+// The recurrence for such a frame: as weighted_recurrence_lds_kernel (one lane walks, the integrator's arrays in LDS), sample by sample, with k = the
+// drawing lights chosen so far in the sample: a drawing light's estimate is read from the k-th of its j + 1 survey entries.  Groups of consecutive
+// samples are staged through LDS by all lanes; a sample whose records do not fit is read from HBM directly.
+// LDS floats: avgY[nL] f[nL] cdf[nL + 1] ya[nL] yb[nL] | sb[group + 1] rb[group + 1] | buf[cap_floats] | out float2[cap_points]
+__global__ __launch_bounds__(64) void weighted_recurrence_mixed_kernel(const float *__restrict__ rec, float2 *__restrict__ pick, const unsigned *__restrict__ base,
+                                                                        const unsigned *__restrict__ recbase, unsigned long long n_samples, int nL, int nD,
+                                                                        const unsigned *__restrict__ draws, int group, int cap_floats, int cap_points) {
+    extern __shared__ float wt_lds[];
+    float *avgY = wt_lds, *f = avgY + nL, *cdf = f + nL, *ya = cdf + nL + 1, *yb = ya + nL;
+    unsigned *sb = (unsigned *)(yb + nL), *rb = sb + group + 1;
+    float *buf = (float *)(rb + group + 1);
+    float2 *out = (float2 *)(buf + ((cap_floats + 1) & ~1));
+    const int lane = threadIdx.x;
+    const unsigned A = 1u + 2u * unsigned(nL - nD);
+    float overall = 0.f;
+    if (lane == 0) for (int i = 0; i < nL; ++i) avgY[i] = 0.f;
+    for (unsigned long long s0 = 0; s0 < n_samples;) {
+        const int g = int(n_samples - s0 < (unsigned long long)group ? n_samples - s0 : (unsigned long long)group);
+        for (int i = lane; i <= g; i += 64) { sb[i] = base[s0 + i]; rb[i] = recbase[s0 + i]; }
+        __syncthreads();
+        int take = 0;                                                          // samples of this round (wave-uniform: every lane reads the same LDS words)
+        while (take < g && rb[take + 1] - rb[0] <= unsigned(cap_floats) && sb[take + 1] - sb[0] <= unsigned(cap_points)) ++take;
+        const bool direct = take == 0;                                        // one sample larger than the staging buffers: straight from HBM
+        if (direct) take = 1;
+        if (!direct) for (unsigned i = lane; i < rb[take] - rb[0]; i += 64) buf[i] = rec[size_t(rb[0]) + i];
+        __syncthreads();
+        if (lane == 0) {
+            for (int i = 0; i < take; ++i) {
+                const unsigned P = sb[i + 1] - sb[i];
+                const float *sr = direct ? rec + rb[i] : buf + (rb[i] - rb[0]);
+                unsigned k = 0;
+                for (unsigned j = 0; j < P; ++j) {
+                    const float *r = sr + size_t(j) * A + size_t(nD) * j * (j + 1);
+                    const float u = r[0];
+                    unsigned off = 1;
+                    for (int l = 0; l < nL; ++l) {
+                        if (draws[l]) { ya[l] = r[off + 2 * k]; yb[l] = r[off + 2 * k + 1]; off += 2 * (j + 1); }
+                        else { ya[l] = r[off]; yb[l] = r[off + 1]; off += 2; }
+                    }
+                    int light; float w, lum;
+                    if (overall == 0.f) {                                      // transport.cpp:87-98
+                        light = min(int(floorf(u * float(nL))), nL - 1);
+                        lum = yb[light];
+                        overall = lum;
+                        for (int q = 0; q < nL; ++q) avgY[q] = lum;
+                        w = 0.f;
+                    } else {                                                   // transport.cpp:99-119, mc.cpp:31-53
+                        for (int q = 0; q < nL; ++q) f[q] = fmaxf(avgY[q], .1f * overall);
+                        cdf[0] = 0.f;
+                        for (int q = 1; q < nL + 1; ++q) cdf[q] = cdf[q - 1] + f[q - 1] / float(nL);
+                        const float c = cdf[nL];
+                        for (int q = 1; q < nL + 1; ++q) cdf[q] /= c;
+                        int idx = 0;
+                        while (idx < nL + 1 && !(u < cdf[idx])) ++idx;
+                        idx = min(max(0, idx - 1), nL - 1);
+                        const float uu = (u - cdf[idx]) / (cdf[idx + 1] - cdf[idx]);
+                        w = f[idx] / c;
+                        const float t = (float(idx) + uu) / float(nL);
+                        light = min(int(float(nL) * t), nL - 1);
+                        lum = ya[light]; avgY[light] = (1.f - .99f) * lum + .99f * avgY[light];
+                        overall = (1.f - .999f) * lum + .999f * overall;
+                    }
+                    if (draws[light]) ++k;                                      // the frame pass's counter moves on by this light's draw
+                    const float2 pk = make_float2(__int_as_float(light), w);
+                    if (direct) pick[size_t(sb[i]) + j] = pk; else out[sb[i] - sb[0] + j] = pk;
+                }
+            }
+        }
+        __syncthreads();
+        if (!direct) for (unsigned i = lane; i < sb[take] - sb[0]; i += 64) pick[size_t(sb[0]) + i] = out[i];
+        __syncthreads();
+        s0 += unsigned(take);
+    }
+}
+
 }  // namespace rt

@@ -40,6 +40,12 @@ CASES = {
                                 world_kwargs=dict(point_light=True, area_light=False, extra=SPOT + DISTANT + many_points(1, 2))),
     "grid_four_lights": dict(xres=64, yres=64, xsamples=2, ysamples=1, accelerator="grid", soup_tris=2000,
                              world_kwargs=dict(point_light=True, area_light=False, extra=SPOT + DISTANT + many_points(1, 9), mirror_quad=True)),
+    # lights of mixed RNG use (round 5): the two-triangle ceiling emitter draws its triangle, the point / spot / distant lights draw nothing; mirror and
+    # soup glass give samples of several shading points, so the emitter's draw sits at k = 0 .. j draws further depending on the lights chosen before
+    "mixed_emitter_and_deltas": dict(xres=72, yres=72, xsamples=2, ysamples=2, jitter=True, soup_tris=2500, soup_materials=True, maxdepth=4,
+                                     world_kwargs=dict(point_light=True, extra=SPOT + DISTANT, mirror_quad=True)),
+    "mixed_two_emitters_ld": dict(xres=64, yres=48, sampler="lowdiscrepancy", pixelsamples=4, soup_tris=1500, soup_materials=True, maxdepth=5,
+                                  world_kwargs=dict(point_light=True, extra=EMITTER2 + many_points(2, 17), mirror_quad=True)),
     "medium_two_points": dict(xres=32, yres=32, xsamples=2, ysamples=1, jitter=True, volume_integrator='"single" "float stepsize" [80]',
                               world_kwargs=dict(volume='"float g" [.3]', point_light=True, area_light=False, extra=many_points(1, 3), mirror_quad=True)),
 }
@@ -123,14 +129,8 @@ def test_weighted_without_lights_and_with_one(pkg, scenes):
 def test_frames_the_weighted_recurrence_cannot_serve_are_refused(pkg, scenes):
     need_gpu(pkg)
     kw = dict(xres=16, yres=16, keyed=True, integrator="directlighting", integrator_params=W)
-    # a point light (no random number per estimate) next to the two-triangle ceiling emitter (one, ShapeSet::Sample shape.h:115-121)
-    ps = pkg.ParsedScene(text=scenes.cornell_scene(world_kwargs=dict(point_light=True), **kw))
-    assert ps.valid
-    ds = pkg.DeviceScene(ps)
-    with pytest.raises(pkg.RtError) as e:
-        ds.render()
-    assert "weighted" in str(e.value) and "random numbers" in str(e.value)
-    ds.close()
+    # (a point light next to the two-triangle ceiling emitter -- lights of mixed RNG use -- was refused until round 5: now CASES["mixed_*"] and the
+    # reference film weighted_cornell_plus_point)
     # a participating medium with the two-triangle emitter: Scene::Transmittance draws per unoccluded ray, so the survey and the frame pass
     # would hand ShapeSet::Sample different random numbers at a sample's second shading point (here: behind the mirror)
     ps = pkg.ParsedScene(text=scenes.cornell_scene(volume_integrator='"single" "float stepsize" [60]', world_kwargs=dict(volume='"float g" [0]', mirror_quad=True), **kw))
