@@ -24,6 +24,7 @@
 #include <vector>
 #include <cmath>
 #include <chrono>
+#include <atomic>
 #include <thread>
 
 namespace rt {
@@ -690,22 +691,47 @@ static void host_tri_frame(const float *v, bool flip, float nn[3], float sn[3]) 
 // ~56 G misses/s for the whole chip, and the 1 M-triangle frame makes 17 triangle tests per ray).
 typedef std::vector<float4, NoInitAlloc<float4>> LeafRecords;
 
-// pass 1 (sequential, arithmetic only): where every leaf's run starts; returns the array's size in float4 units
+// pass 1 (arithmetic only): where every leaf's run starts; returns the array's size in float4 units.  Round 5: the node array is cut into blocks of
+// 2^20 nodes whose runs start on a line boundary, so a block's offsets do not depend on what precedes it: the blocks are laid out by all threads and
+// shifted by a prefix sum over their sizes (the layout depends on the block size, never on the thread count; 245.7 M nodes: 1.24 -> ~0.1 s).
 static size_t leaf_order_offsets(const NodeVec &nodes, NodeVec &tnodes) {
-    tnodes = nodes;
-    size_t off = 0;                                       // float4 units (16 B); a line is 8 units
-    for (size_t i = 0; i < nodes.size(); ++i) {
-        const Node &n = nodes[i];
-        if ((n.x & 3u) != 3u) continue;
-        const uint32_t np = n.x >> 2;
-        if (np == 0) { tnodes[i].y = 0u; continue; }
-        const size_t units = size_t(np) * 3;
-        const size_t lines_here = (off % 8 + units + 7) / 8, lines_min = (units + 7) / 8;
-        if (lines_here > lines_min) off = (off + 7) / 8 * 8;
-        tnodes[i].y = uint32_t(off);                     // (a run beyond 2^32 units is refused by the caller)
-        off += units;
-    }
-    return off ? off : 8;
+    tnodes.resize(nodes.size());
+    const size_t B = size_t(1) << 20, nb = (nodes.size() + B - 1) / B;
+    std::vector<size_t> size(nb + 1, 0);
+    auto block = [&](size_t b) {
+        size_t off = 0;                                   // float4 units (16 B) from the block's start; a line is 8 units
+        const size_t hi = std::min(nodes.size(), (b + 1) * B);
+        for (size_t i = b * B; i < hi; ++i) {
+            const Node n = nodes[i];
+            tnodes[i] = n;
+            if ((n.x & 3u) != 3u) continue;
+            const uint32_t np = n.x >> 2;
+            if (np == 0) { tnodes[i].y = 0u; continue; }
+            const size_t units = size_t(np) * 3;
+            const size_t lines_here = (off % 8 + units + 7) / 8, lines_min = (units + 7) / 8;
+            if (lines_here > lines_min) off = (off + 7) / 8 * 8;
+            tnodes[i].y = uint32_t(off);                 // block-local for now
+            off += units;
+        }
+        size[b + 1] = (off + 7) / 8 * 8;
+    };
+    const size_t nthreads = nb < 4 ? 1 : std::min<size_t>(nb, std::max(1u, std::min(64u, std::thread::hardware_concurrency())));
+    auto run = [&](auto fn) {
+        if (nthreads == 1) { for (size_t b = 0; b < nb; ++b) fn(b); return; }
+        std::atomic<size_t> next(0);
+        std::vector<std::thread> pool;
+        for (size_t t = 0; t < nthreads; ++t) pool.emplace_back([&] { for (;;) { const size_t b = next.fetch_add(1); if (b >= nb) return; fn(b); } });
+        for (auto &th : pool) th.join();
+    };
+    run(block);
+    for (size_t b = 0; b < nb; ++b) size[b + 1] += size[b];
+    if (size[nb] >= (size_t(1) << 32)) return size[nb];   // (refused by the caller; the 32-bit offsets below would wrap)
+    run([&](size_t b) {
+        const size_t base = size[b], hi = std::min(nodes.size(), (b + 1) * B);
+        if (!base) return;
+        for (size_t i = b * B; i < hi; ++i) if ((tnodes[i].x & 3u) == 3u && (tnodes[i].x >> 2)) tnodes[i].y += uint32_t(base);
+    });
+    return size[nb] ? size[nb] : 8;
 }
 // pass 2 on the host (the reference form of rt::derive_leaf_records_kernel below: PBRT_HIP_VERIFY_DERIVED compares the two byte for byte)
 static void leaf_order_fill_host(const NodeVec &nodes, const NodeVec &tnodes, const RefVec &leaf_refs,

@@ -1,10 +1,10 @@
 #!/bin/bash
-# GPU box: rocprofv3 evidence for one bench.py workload.  usage: [ROUND=r04] [PROF_TAG=_x] tools/profile.sh <workload> [--publish]
+# GPU box: rocprofv3 evidence for one bench.py workload.  usage: [ROUND=r05] [PROF_TAG=_x] tools/profile.sh <workload> [--publish]
 # Pass 1: --kernel-trace --stats.  Passes 2..: PMC counters, each group in its own run (no tracing domains next to --pmc).
 export PBRT_HIP_TUNE=1   # the library reads its PBRT_HIP_* knobs only then
 set -u
 WL=$1; shift
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r05}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_${ROUND}_$WL${PROF_TAG:-}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
