@@ -57,6 +57,10 @@ struct Lane {
     uint32_t ord;           // ordinal of the sample's next shading point in the frame's program order (DevFrame.wt_base[work] + points so far)
     uint32_t ctr0;          // survey pass: the RNG counter at the shading point, every light's estimate starts from it
     float wt_w;             // frame pass: lightSampleWeight of the light in flight (0: uniform start-up branch)
+    // --- by-vertex form of the path integrator in the megakernel (advance_pass_byv; dead in every other instantiation)
+    unsigned vf;            // BV_* flags of the vertex whose rays are being traced
+    V3 dM, dB;              // directions of its BSDF-sampled MIS ray and of its continuation ray (the shadow ray starts at once; all three leave v.p with mint = RAY_EPSILON)
+    V3 pendS, pendM, thr_old;   // the two contributions EstimateDirect adds if its rays confirm them, and the throughput they are weighted with
     // --- control
     int stage;
     bool has_ray;
@@ -862,6 +866,96 @@ RT_DEV void stage_body(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigne
         return;
     }
     (void)gtid; (void)c_closest; (void)c_any; (void)c_bad;
+}
+
+// ---- the path integrator BY VERTEX in the megakernel (round 5) -----------------------------------------------------------------------------
+// Nothing PathIntegrator::Li does at a vertex depends on what the vertex's rays return (without a medium): the sample values and every RandomFloat() are
+// consumed in an order no ray result changes, the continuation direction is sampled from the BSDF alone, and the two halves of EstimateDirect only
+// decide whether two already computed contributions count (rt_pipe_vertex.h runs the queue pipeline on that).  Per ray, a lane needs a shading pass
+// after EVERY ray -- VERTEX + DIRECT_NEXT, ED_BSDF, ED_DONE + BOUNCE -- and each pass finds a third of the finished lanes in each of those stages: the
+// stage bodies run at a third of the occupancy they could have.  Here one pass does the whole vertex (the reference's operations in the reference's
+// order: stage_body, DEFER form), the shadow ray starts at once, the MIS ray and the continuation ray wait in registers and are started INSIDE the
+// traversal loop when the lane's previous ray ends (byv_ray_advance: ~50 instructions, no shading pass), and the two EstimateDirect terms are added
+//     Ld = 0; if (unoccluded) Ld += pendS; if (the MIS ray hit the sampled emitter's front) Ld += pendM; L += thr_old * (Ld * nLights)
+// -- the reference's sums in the reference's order (transport.cpp:127,155,190; path.cpp:99-110) -- when the lane comes back for its next vertex.
+// Same rays, same arithmetic: films bit-identical to the per-ray form (the counting twins keep it; tests compare).
+enum { BV_S = 1u, BV_M = 2u, BV_B = 4u, BV_ED = 8u,            // the vertex has a shadow / MIS / continuation ray; EstimateDirect's sum is pending
+       BV_QM = 16u, BV_QB = 32u,                                // MIS / continuation ray not started yet
+       BV_CUR_S = 64u, BV_CUR_M = 128u, BV_CUR_B = 256u,        // the ray in flight
+       BV_S_CLEAR = 512u, BV_M_LIT = 1024u };                   // results: the shadow ray was unoccluded; the MIS ray hit the sampled emitter from its front
+// what the ray that has just ended says (transport.cpp:152-156, :180-190)
+template <bool COUNT, bool EXT>
+RT_DEV void byv_ray_result(const DevScene &sc, Lane &ln, unsigned *c_closest, unsigned *c_any) {
+    if (ln.vf & BV_CUR_S) {
+        if (COUNT) ++*c_any;
+        if (ln.tv.hit_prim < 0) ln.vf |= BV_S_CLEAR;
+    } else if (ln.vf & BV_CUR_M) {
+        if (COUNT) ++*c_closest;
+        if (ln.tv.hit_prim >= 0) {
+            V3 nh; int light;
+            prim_normal_light<EXT>(sc, ln.tv, nh, light);
+            if (light == ln.cur_light && dot3(nh, -ln.tv.d) > 0) ln.vf |= BV_M_LIT;
+        }
+    }
+    ln.vf &= ~(BV_CUR_S | BV_CUR_M | BV_CUR_B);
+}
+// inside the traversal loop: the lane's ray has ended and its vertex has another one waiting
+template <bool COUNT, int ACCEL, bool EXT>
+RT_DEV void byv_ray_advance(const DevScene &sc, Lane &ln, unsigned *c_closest, unsigned *c_any) {
+    byv_ray_result<COUNT, EXT>(sc, ln, c_closest, c_any);
+    Ray r; r.o = ln.tv.o; r.mint = RT_RAY_EPSILON; r.maxt = RT_INF;
+    if (ln.vf & BV_QM) { r.d = ln.dM; ln.vf = (ln.vf & ~BV_QM) | BV_CUR_M; }
+    else { r.d = ln.dB; ln.vf = (ln.vf & ~BV_QB) | BV_CUR_B; }
+    if (ACCEL == RT_ACCEL_GRID) grid_begin(ln.tv, sc, r, false); else trav_begin(ln.tv, sc, r, false);
+}
+// one pass: every lane without a ray finishes its previous vertex and runs its next one up to its rays (or ends the path: ST_FETCH)
+template <bool COUNT, int ACCEL, bool EXT>
+RT_DEV void advance_pass_byv(const DevScene &sc, const DevFrame &fr, Lane &ln, unsigned gtid, unsigned *c_closest, unsigned *c_any, unsigned *c_bad) {
+    constexpr int INTEG = RT_INTEGRATOR_PATH;
+#define RT_BV_BODY(S) stage_body<COUNT, INTEG, false, EXT, S, true>(sc, fr, ln, gtid, c_closest, c_any, c_bad)
+    const int nLights = int(sc.n_lights);
+    if (!ln.has_ray && (ln.stage == ST_VERTEX || ln.stage == ST_ED_DONE)) {
+        byv_ray_result<COUNT, EXT>(sc, ln, c_closest, c_any);          // the vertex's last ray (the earlier ones were read when the next ray started)
+        if (ln.vf & BV_ED) {                                            // the two halves of EstimateDirect, then path.cpp:99-110
+            V3 Ld = mk3(0.f);                                           // transport.cpp:127
+            if (ln.vf & BV_S_CLEAR) Ld = Ld + ln.pendS * mk3(1.f);      // Transmittance = 1 (no medium)
+            if (ln.vf & BV_M_LIT) Ld = Ld + ln.pendM * mk3(1.f);
+            ln.L = ln.L + ln.thr_old * (Ld * float(nLights));
+        }
+        ln.vf = 0u;
+        if (ln.stage == ST_ED_DONE) ln.stage = ST_RETURN;               // the path ended at that vertex
+    }
+    unsigned flags = 0;
+    V3 o = mk3(0.f), dS = mk3(0.f); float maxtS = 0.f;
+    if (!ln.has_ray && ln.stage == ST_VERTEX) RT_BV_BODY(ST_VERTEX);    // -> ST_DIRECT_NEXT, or ST_RETURN (the ray left the scene)
+    if (!ln.has_ray && ln.stage == ST_DIRECT_NEXT) {                    // UniformSampleOneLight -> EstimateDirect (transport.cpp:51-70, 123-194)
+        RT_BV_BODY(ST_DIRECT_NEXT);                                     // light-sampling half: shadow ray recorded in ln.tv, or ST_ED_BSDF, or (no lights) ST_BOUNCE
+        if (ln.has_ray) { ln.has_ray = false; ln.stage = ST_ED_BSDF; flags |= BV_S; ln.pendS = ln.pend; o = ln.tv.o; dS = ln.tv.d; maxtS = ln.tv.maxt; }
+        if (ln.stage == ST_ED_BSDF) {
+            RT_BV_BODY(ST_ED_BSDF);                                     // BSDF-sampling half: MIS ray recorded, or ST_ED_DONE
+            if (ln.has_ray) { ln.has_ray = false; flags |= BV_M | BV_QM; ln.pendM = ln.pend; o = ln.tv.o; ln.dM = ln.tv.d; }
+            if (flags & (BV_S | BV_M)) { flags |= BV_ED; ln.thr_old = ln.thr; }     // L += thr * (Ld * nLights) waits for the rays
+            else { ln.stage = ST_ED_DONE; RT_BV_BODY(ST_ED_DONE); }                  // Ld = 0: nothing to wait for
+            ln.stage = ST_BOUNCE;
+        }
+    }
+    if (!ln.has_ray && ln.stage == ST_BOUNCE) {                         // path.cpp:111-143
+        RT_BV_BODY(ST_BOUNCE);
+        if (ln.has_ray) { ln.has_ray = false; flags |= BV_B | BV_QB; o = ln.tv.o; ln.dB = ln.tv.d; }
+    }
+    if (!ln.has_ray && ln.stage == ST_RETURN && !(flags & BV_ED)) { RT_BV_BODY(ST_RETURN); RT_BV_BODY(ST_POP); RT_BV_BODY(ST_FINISH); }      // -> ST_FETCH
+    if (flags & (BV_S | BV_M | BV_B)) {                                 // start the vertex's first ray
+        Ray r; r.o = o; r.mint = RT_RAY_EPSILON;
+        bool any = false;
+        if (flags & BV_S) { r.d = dS; r.maxt = maxtS; any = true; flags |= BV_CUR_S; }
+        else if (flags & BV_M) { r.d = ln.dM; r.maxt = RT_INF; flags = (flags & ~BV_QM) | BV_CUR_M; }
+        else { r.d = ln.dB; r.maxt = RT_INF; flags = (flags & ~BV_QB) | BV_CUR_B; }
+        if (ACCEL == RT_ACCEL_GRID) grid_begin(ln.tv, sc, r, any); else trav_begin(ln.tv, sc, r, any);
+        ln.vf = flags;
+        ln.has_ray = true;
+        ln.stage = (flags & BV_B) ? ST_VERTEX : ST_ED_DONE;            // where the lane resumes when the last of these rays is back
+    }
+#undef RT_BV_BODY
 }
 
 // One shading pass.  The stages are visited in pipeline order, so a lane flows through as many of them as it can

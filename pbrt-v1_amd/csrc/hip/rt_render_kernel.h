@@ -33,6 +33,10 @@ RT_DEV unsigned long long band_lo(unsigned long long total, unsigned r, unsigned
 #ifndef RT_MEGA_TOP
 #define RT_MEGA_TOP 0
 #endif
+// the path integrator by vertex (rt_integrate.h advance_pass_byv) in the register-capped flavour of the kd-tree / grid kernels without a medium
+#ifndef RT_MEGA_BYV
+#define RT_MEGA_BYV 1
+#endif
 // waves per SIMD of the high-occupancy flavour: 4 = 128 VGPRs.  5 (96 VGPRs) was marginally faster at one point but its
 // spill placement swings with every code change (measured 108 -> 153 ms on the 1 M-triangle path frame for the same
 // algorithm); 4 is stable: 101 ms there, 138 ms on the 100 k soup.
@@ -69,7 +73,9 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
     const unsigned gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const unsigned top_lim = top_table_fill<TOP>(sc, (uint4 RT_L *)lds_top);
+    constexpr bool BYV = RT_MEGA_BYV != 0 && !POOL && INTEG == RT_INTEGRATOR_PATH && !VOL && !EXT && !COUNT;
     Lane ln;
+    ln.vf = 0u;
     ln.stage = ST_FETCH; ln.has_ray = false; ln.fsp = 0; ln.tv.active = false; ln.tv.hit_prim = -1;
     ln.L = mk3(0.f); ln.thr = mk3(1.f); ln.alpha = 0.f; ln.depth = 0; ln.specular = false;
     TravCounters tc; tc.nodes = tc.leaf_refs = tc.tris = tc.spills = 0;
@@ -91,13 +97,14 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
     unsigned band_shift = 0;                                               // bands this wave has seen the end of
     // phase gating (rt_integrate.h, stage_in_phase): sweeps alternate between the two halves of the path state machine;
     // the first sweep is of the second kind (it contains the work fetch)
-    int phase = (INTEG == RT_INTEGRATOR_PATH && fr.phase_sync) ? 1 : -1;
+    int phase = (INTEG == RT_INTEGRATOR_PATH && fr.phase_sync && !BYV) ? 1 : -1;
     for (;;) {
         RT_PF(pf_t0 = __builtin_readcyclecounter(); ++pf_outer;)
         // ---- shade / regenerate: run every lane that is not waiting on a ray until it is (or is out of work)
         do {
             RT_PF(++pf_inner;)
-            advance_pass<COUNT, INTEG, VOL, EXT>(sc, fr, ln, gtid, &c_closest, &c_any, &c_bad, phase);
+            if constexpr (BYV) advance_pass_byv<COUNT, ACCEL, EXT>(sc, fr, ln, gtid, &c_closest, &c_any, &c_bad);
+            else advance_pass<COUNT, INTEG, VOL, EXT>(sc, fr, ln, gtid, &c_closest, &c_any, &c_bad, phase);
             const unsigned long long want = phase == 0 ? 0ull : __ballot(!ln.has_ray && ln.stage == ST_FETCH);
             if (want) {                                                   // work fetch from the wave's private chunk of the sample list
                 // One device-scope counter serves ~6-8 ns per atomic whoever asks (measured through the trace kernel's refill rate,
@@ -154,6 +161,7 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
                             accel_begin<ACCEL>(ln.tv, sc, ray, false);
                             if (VOL) vol_store_ray(fr, 0, gtid, ray);
                             ln.has_ray = true; ln.stage = ST_VERTEX;
+                            if (BYV) ln.vf = BV_B | BV_CUR_B;                 // the camera ray is the "continuation" that leads to the first vertex
                         }
                     }
                 }
@@ -168,6 +176,10 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
         // ---- extend: one shared traversal loop.  Leave it early when only a few lanes are still traversing AND some
         // lane could meanwhile shade / fetch (its traversal state stays in registers + LDS and resumes next round).
         for (;;) {
+            if constexpr (BYV) {                                          // a lane whose ray has ended starts its vertex's next ray here, without a shading pass
+                const bool next = ln.has_ray && !ln.tv.active && (ln.vf & (BV_QM | BV_QB)) != 0u;
+                if (__any(next)) { if (next) byv_ray_advance<COUNT, ACCEL, EXT>(sc, ln, &c_closest, &c_any); }
+            }
             const bool act = ln.has_ray && ln.tv.active;
             const unsigned long long am = __ballot(act);
             if (!am) break;
@@ -177,7 +189,7 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
             else trace_round<COUNT, ACCEL, EXT, RT_STACK_LDS, !POOL, RT_TRACE_DSTEPS, TOP>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, lds_tm, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc, fr.leaf_min,
                                                                                             (const uint4 RT_L *)lds_top, top_lim);
         }
-        if (ln.has_ray && !ln.tv.active) ln.has_ray = false;
+        if (ln.has_ray && !ln.tv.active && !(BYV && (ln.vf & (BV_QM | BV_QB)) != 0u)) ln.has_ray = false;
         RT_PF(pf_trav += __builtin_readcyclecounter() - pf_t0;)
     }
 #ifdef RT_PROFILE

@@ -133,6 +133,6 @@ def test_c4_sample_count_beyond_2_to_the_30_work_items_and_2_to_the_32_rays(pkg,
                                                     soup_tris=1_000_000, soup_materials=True, keyed=True))
     d4 = pkg.DeviceScene(ps4); d4.bind_film(); d4.render(); b = d4.film_accum(); d4.close()
     L4 = (b[:3] / np.maximum(b[4], 1e-20)).reshape(3, 32, 64, 32, 64).mean((0, 2, 4))
-    lit = L4 > 0.02 * L4.max()
-    assert lit.sum() >= 100 and np.all(np.abs(L256 - L4)[lit] < 0.2 * L4[lit] + 0.01 * L4.max()), float(np.abs(L256 - L4)[lit].max())
-    assert np.all((L256 == 0) == (L4 == 0)) or np.abs(L256 - L4)[~lit].max() < 0.03 * L4.max()
+    nz = L4 > 0
+    med = float(np.median(L4[nz]))
+    assert nz.sum() >= 300 and np.all(np.abs(L256 - L4) < 0.25 * L4 + 0.05 * med), (int(nz.sum()), med, float(np.abs(L256 - L4).max()))
