@@ -958,6 +958,10 @@ RT_DEV void advance_pass_byv(const DevScene &sc, const DevFrame &fr, Lane &ln, u
 #undef RT_BV_BODY
 }
 
+// (The same for DirectLightingIntegrator::Li -- both rays of one EstimateDirect per pass, the vertex kept live for the next light and the specular recursion -- was
+// built, is bit-identical, and is 6 % SLOWER on C3 (kernel 12.07 -> 12.79 ms: the kernel sits at the 128-register cap with nothing dying across the rays, 11 spilled
+// registers); profiles/r05_direct_by_estimate_experiment.patch, profiles/r05_by_vertex_scan.txt.)
+
 // One shading pass.  The stages are visited in pipeline order, so a lane flows through as many of them as it can
 // in a single pass, and -- the point of the ordering -- lanes that entered at different stages *merge*: e.g. the
 // bounce-sampling block runs once per pass for every lane that needs it, whether the lane just came back from a

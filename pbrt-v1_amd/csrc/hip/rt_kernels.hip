@@ -1646,6 +1646,9 @@ static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool nee
         // long divergent rays: let finished lanes refill early.  Tiny scenes: only with phase gating (path integrator), where 8
         // measured +1.5 % (16: -13 %); Whitted / DirectLighting on Cornell lose 10 % with any early exit
         fr.exit_thresh = tiny ? (rd->integrator == RT_INTEGRATOR_PATH ? 8 : 0) : 32;
+        // round 5, the path integrator by vertex (a lane comes back for shading once per vertex, not once per ray): 16 on tiny trees (C2's kernel 49.8 -> 48.5 ms;
+        // 24: 48.7, 32: 50.1), 32-40 alike on the 1 M-triangle frames (profiles/r05_by_vertex_scan.txt)
+        if (RT_MEGA_BYV && tiny && rd->integrator == RT_INTEGRATOR_PATH && !s->volume.present && !s->has_ext) fr.exit_thresh = 16;
         fr.high_occupancy = (tiny && !tiny_path) ? 0 : 1;      // C2 (round 3): 4-wave flavour + batched rounds + exit threshold 8 = 54.0 ms, natural allocation + pooled lock-step 56.5
         if (const char *e = knob("PBRT_HIP_HIGH_OCC")) fr.high_occupancy = std::atoi(e);
         fr.leaf_min = tiny ? 8 : RT_TRACE_LEAF_MIN;          // C2: 50.8 ms at 8, 54.0 at 24 (few fat leaves: waiting for a fuller batch only idles lanes)
