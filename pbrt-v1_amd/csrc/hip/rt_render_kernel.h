@@ -37,9 +37,7 @@ RT_DEV unsigned long long band_lo(unsigned long long total, unsigned r, unsigned
 #ifndef RT_MEGA_BYV
 #define RT_MEGA_BYV 1
 #endif
-#ifndef RT_BYV_ADV_MIN
-#define RT_BYV_ADV_MIN 1          // lanes whose next ray waits before the wave spends the ~50 instructions of byv_ray_advance on them
-#endif
+
 // waves per SIMD of the high-occupancy flavour: 4 = 128 VGPRs.  5 (96 VGPRs) was marginally faster at one point but its
 // spill placement swings with every code change (measured 108 -> 153 ms on the 1 M-triangle path frame for the same
 // algorithm); 4 is stable: 101 ms there, 138 ms on the 100 k soup.
@@ -181,8 +179,7 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
         for (;;) {
             if constexpr (BYV) {                                          // a lane whose ray has ended starts its vertex's next ray here, without a shading pass
                 const bool next = ln.has_ray && !ln.tv.active && (ln.vf & (BV_QM | BV_QB)) != 0u;
-                const int n_next = __popcll(__ballot(next));
-                if (n_next >= RT_BYV_ADV_MIN || (n_next > 0 && !__any(ln.has_ray && ln.tv.active))) { if (next) byv_ray_advance<COUNT, ACCEL, EXT>(sc, ln, &c_closest, &c_any); }
+                if (__any(next)) { if (next) byv_ray_advance<COUNT, ACCEL, EXT>(sc, ln, &c_closest, &c_any); }       // (always at once: a lane left waiting here counts as "idle" for the exit test below)
             }
             const bool act = ln.has_ray && ln.tv.active;
             const unsigned long long am = __ballot(act);
