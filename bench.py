@@ -354,6 +354,9 @@ def run_workload(name, args, pkg, torch, dist, world, rank, device_index, steps,
             "metric": "Mrays/s (primary+secondary: every Scene::Intersect + Scene::IntersectP)",
             "value": round(rays_total * steps / elapsed / 1e6, 3),
             "unit": "Mrays/s",
+            # 2 (since round 4): the timed step ends with the RESOLVED film in device memory; 1 (rounds 1-3): it ended with the film in page-locked host memory --
+            # that figure is still printed, as host_handover.value, for like-for-like comparisons across the change
+            "metric_version": 2,
             "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(ms_per_step, 3),
             "s_per_frame": round(ms_per_step / 1e3, 5),

@@ -1160,6 +1160,11 @@ static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel 
     } else build_kdtree(d->tri_verts, d->n_tris, d->accel, s->tree);
 
     tick("accelerator");
+    // the order of the pair blocks: a sequential walk over the tree's shape (1.8 s at 10 M triangles) on its own thread, beside everything up to the pair fill
+    PairBlockOrder pbo;
+    std::thread order_thread;
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{order_thread};
+    if (s->accel_kind == RT_ACCEL_KDTREE) order_thread = std::thread([&] { pair_blocks_order(s->tree.nodes, pbo); });
     // triangles -> 48-byte records
     std::vector<DevTri> tris(d->n_tris);
     uint32_t n_quadric_slots = 0;
@@ -1258,9 +1263,6 @@ static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel 
     if (s->accel_kind == RT_ACCEL_KDTREE) {
         NodeVec tn;
         tick("node / leaf-list upload");
-        PairBlockOrder pbo;
-        std::thread order_thread([&] { pair_blocks_order(s->tree.nodes, pbo); });      // beside the offsets pass and the uploads below
-        struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{order_thread};
         const size_t units = leaf_order_offsets(s->tree.nodes, tn);
         tick("leaf-order offsets");
         if (units >= (size_t(1) << 32)) return fail(RT_EINVAL, "rt_scene_create: leaf-ordered triangle array beyond 2^32 float4 units");
