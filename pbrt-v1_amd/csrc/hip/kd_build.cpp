@@ -331,11 +331,11 @@ class Builder {
         if (fork) { fsub.reset(new KdTree); fTasks.reset(new std::vector<Task>); fb.reset(new Builder(*this, fsub.get())); }
         const Stack::Mark m1 = stack.mark();
         Stack &s1 = fork ? fb->stack : stack;                              // the above child's lists live where the above child is built
-        Lists c1; c1.n = n1; c1.prims = s1.get<int>(size_t(std::max(n1, 1)));
-        for (int a = 0; a < 3; ++a) c1.e[a] = s1.get<Edge>(size_t(2) * std::max(n1, 1));
+        Lists c1; c1.n = n1; c1.prims = s1.get<int>(size_t(n1) + 1);
+        for (int a = 0; a < 3; ++a) c1.e[a] = s1.get<Edge>(size_t(2) * n1 + 1);
         const Stack::Mark m0 = stack.mark();
-        Lists c0; c0.n = n0; c0.prims = stack.get<int>(size_t(std::max(n0, 1)));
-        for (int a = 0; a < 3; ++a) c0.e[a] = stack.get<Edge>(size_t(2) * std::max(n0, 1));
+        Lists c0; c0.n = n0; c0.prims = stack.get<int>(size_t(n0) + 1);
+        for (int a = 0; a < 3; ++a) c0.e[a] = stack.get<Edge>(size_t(2) * n0 + 1);
         if (sorting_form) {
             int k0 = 0, k1 = 0;
             for (int i = 0; i < bestEdge; ++i) if (edge_kind(e[i]) == 0) c0.prims[k0++] = int(edge_prim(e[i]));
@@ -347,10 +347,18 @@ class Builder {
             To *to = stack.get<To>(size_t(n));
             const int P = (tasks && par > 1 && n >= (1 << 16)) ? std::min(par, 64) : 1;      // the top of the tree: this node's passes cut into chunks, one thread each
             if (P == 1) {
+                // (branch-free: whether an edge is a START / goes to a child is a coin toss to the branch predictor; every store below is unconditional, into the
+                // real slot or a dummy one, and the cursors advance by 0 or 1.  The children's arrays have one spare element for the last store.)
                 std::memset(to, 0xff, size_t(n) * sizeof(To));
-                int k0 = 0, k1 = 0;
-                for (int i = 0; i < bestEdge; ++i) if (edge_kind(e[i]) == 0) { const uint32_t p = edge_prim(e[i]); to[p].q0 = k0; c0.prims[k0++] = prims[p]; }
-                for (int i = bestEdge + 1; i < 2 * n; ++i) if (edge_kind(e[i]) == 1) { const uint32_t p = edge_prim(e[i]); to[p].q1 = k1; c1.prims[k1++] = prims[p]; }
+                int k0 = 0, k1 = 0, dummy = 0;
+                for (int i = 0; i < bestEdge; ++i) {
+                    const uint32_t p = edge_prim(e[i]); const bool st = edge_kind(e[i]) == 0;
+                    (st ? to[p].q0 : dummy) = k0; c0.prims[k0] = prims[p]; k0 += st;
+                }
+                for (int i = bestEdge + 1; i < 2 * n; ++i) {
+                    const uint32_t p = edge_prim(e[i]); const bool en = edge_kind(e[i]) == 1;
+                    (en ? to[p].q1 : dummy) = k1; c1.prims[k1] = prims[p]; k1 += en;
+                }
                 for (int a = 0; a < 3; ++a) {                              // the children's lists: this node's, filtered
                     const Edge *src = L.e[a];
                     Edge *d0 = c0.e[a], *d1 = c1.e[a];
@@ -358,8 +366,8 @@ class Builder {
                         const Edge x = src[i];
                         const uint32_t kb = x.pk & 0x80000000u;
                         const To q = to[x.pk & 0x7fffffffu];
-                        if (q.q0 >= 0) *d0++ = Edge{x.t, kb | uint32_t(q.q0)};
-                        if (q.q1 >= 0) *d1++ = Edge{x.t, kb | uint32_t(q.q1)};
+                        *d0 = Edge{x.t, kb | uint32_t(q.q0)}; d0 += q.q0 >= 0;
+                        *d1 = Edge{x.t, kb | uint32_t(q.q1)}; d1 += q.q1 >= 0;
                     }
                 }
             } else {
