@@ -494,8 +494,24 @@ def main():
         extras = [] if (args.no_extra or args.workload != HEADLINE) else [w for w in args.extra_workloads.split(",") if w]
     records = []
     for w in extras:
-        rec = run_workload(w, args, pkg, torch, dist, world, rank, device_index, min(args.steps, 3), 1, with_cpu=not args.no_cpu_baseline,
-                           dump_film=args.dump_film.replace(".npz", "_%s.npz" % w) if args.dump_film else None)
+        # a sub-record must never cost the headline: whatever goes wrong in an extra workload (memory, a collective timing out) is recorded in its place
+        rec, err = None, None
+        try:
+            rec = run_workload(w, args, pkg, torch, dist, world, rank, device_index, min(args.steps, 3), 1, with_cpu=not args.no_cpu_baseline,
+                               dump_film=args.dump_film.replace(".npz", "_%s.npz" % w) if args.dump_film else None)
+        except BaseException as e:                                       # incl. SystemExit raised by run_workload
+            err = "%s: %s" % (type(e).__name__, e)
+        if dist is not None:                                             # all ranks agree on whether to go on
+            try:
+                flag = torch.tensor([0.0 if err is None else 1.0], device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                if flag.item() > 0 and err is None:
+                    err = "another rank failed in this workload"
+            except BaseException as e:
+                err = (err or "") + " | agreement all-reduce failed: %s" % e
+        if err is not None:
+            records.append({"workload": w, "error": err[:500]})
+            break
         if rec is not None:
             records.append({k: rec[k] for k in ("value", "unit", "n_gpus", "ms_per_step", "steps", "host_handover", "config", "roofline", "per_rank", "cpu_baseline") if k in rec} |
                            ({"speedup_vs_cpu_baseline": rec["speedup_vs_cpu_baseline"]} if "speedup_vs_cpu_baseline" in rec else {}) | {"workload": w})
@@ -504,7 +520,10 @@ def main():
             out["workloads"] = records
         print(json.dumps(out), flush=True)
     if dist is not None:
-        dist.destroy_process_group()
+        try:
+            dist.destroy_process_group()
+        except BaseException:
+            pass
 
 
 if __name__ == "__main__":

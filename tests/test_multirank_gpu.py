@@ -52,6 +52,18 @@ def test_two_ranks_on_one_gpu_through_bench(pkg, tmp_path, mode):
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("pbrt_hip_accel_")]            # the published tree is removed again
 
 
+def test_a_failing_sub_workload_does_not_cost_the_headline(pkg):
+    """bench.py at N > 1 runs the multi-GPU configurations after the headline and prints ONE line at the end: whatever goes wrong in a sub-workload (here: a
+    name that does not exist; on a node: memory, a collective timing out) is recorded in its place, all ranks agree to stop, the headline line is printed."""
+    if pkg.device_count() < 1:
+        pytest.fail("no HIP device visible")
+    env = dict(os.environ, PBRT_BENCH_BACKEND="gloo", PBRT_BENCH_SAME_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    j = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "tsmall", "--multi-workloads", "t5,nosuchworkload,t8", "--no-cpu-baseline", "--tile-2d", "16"], env, nproc=2)
+    assert j["n_gpus"] == 2 and j["value"] > 0
+    w = j["workloads"]
+    assert [x["workload"] for x in w] == ["t5", "nosuchworkload"] and w[0]["value"] > 0 and len(w[0]["per_rank"]) == 2 and "unknown workload" in w[1]["error"]
+
+
 def test_single_rank_rccl_process_group(pkg, tmp_path):
     """bench.py --force-dist: world size 1 over the nccl (= RCCL) backend on the one GPU this box has -- process-group set-up with
     device_id, the probe all-reduce, the shared-accelerator hand-shake, reduce-scatter / all-gather of device tensors through RCCL and
