@@ -75,7 +75,7 @@ struct DevScene {
                                // ray = interior nodes visited, not nodes visited (-44 % at 1 M triangles).  Pairs are stored depth-first.
     unsigned root_x, root_y;   // contents of the root in that encoding
     unsigned top_pairs, pad_tp;  // the first top_pairs records of tpairs are the owner blocks of the tree's top levels, breadth-first and packed without
-                               // padding: what a workgroup copies into LDS (top_table_fill, rt_traverse.h)
+                               // padding (pair_blocks_order; an LDS copy of them was measured and not kept: profiles/r05_lds_top_experiment.patch)
     const float4 *ltris;       // triangle records in LEAF order: the n primitives of a leaf are n consecutive 48-byte records (p1, e1, e2 as
                                // in DevTri, the primitive's index in q2.w), placed so that a leaf touches the fewest 128-byte lines: one
                                // gather fetches what the mesh-order layout needs a leaf-list read plus 1.25 lines per triangle for

@@ -807,8 +807,8 @@ static void host_tri_frame_uv(const float *v, const float *uv, bool flip, float 
 // Two phases: pair_blocks_order() decides where every pair goes (a sequential depth-first walk that looks at the tree's SHAPE only, so it runs
 // beside leaf_order_offsets on another thread), pair_blocks_fill() writes the records (needs the leaves' positions in ltris; 64 threads).
 // Round 5: the blocks of the tree's TOP levels come first, breadth-first (owner level by owner level, below side first) and packed without
-// padding, RT_TOP_PREFIX records at most -- the part of the array a workgroup keeps in LDS (top_table_fill, rt_traverse.h; any prefix of it is
-// "the topmost blocks").  The subtrees below that frontier follow depth-first in 64-byte-aligned blocks as before.
+// padding, RT_TOP_PREFIX records at most (any prefix of the array is "the topmost blocks": what an LDS copy would want -- measured, not kept,
+// profiles/r05_lds_top_scan.txt -- and what every ray walks sits in 64 KB).  The subtrees below that frontier follow depth-first in 64-byte-aligned blocks as before.
 #ifndef RT_TOP_PREFIX
 #define RT_TOP_PREFIX 4095u          // 1365 blocks of three records: 11-12 levels of a full tree
 #endif

@@ -22,9 +22,6 @@
 #ifndef RT_MARCH_STACK
 #define RT_MARCH_STACK 8          // LDS ring entries per lane (pair form: 12 B each): 24 KB per workgroup
 #endif
-#ifndef RT_MARCH_TOP
-#define RT_MARCH_TOP 0            // records of the tree's top levels in LDS (4 workgroups per CU: 24 KB of stack planes leave 16 KB each)
-#endif
 #ifndef RT_MARCH_REFILL
 #define RT_MARCH_REFILL 16        // leave the traversal loop when this many more lanes hold a finished shadow ray (they take their next step): 8 and 32 measured slower
 #endif
@@ -48,10 +45,7 @@ __global__ __launch_bounds__(RT_BLOCK, COUNT ? 1 : RT_MARCH_WAVES) void pipe_mar
                                                                              const PipePool *__restrict__ plp, MarchJob job) {
     __shared__ uint2 lds_stack[RT_MARCH_STACK * RT_BLOCK];
     __shared__ float lds_tm[(ACCEL != RT_ACCEL_GRID && !EXT) ? RT_MARCH_STACK * RT_BLOCK : 1];
-    constexpr int TOP = (ACCEL != RT_ACCEL_GRID && !EXT) ? RT_MARCH_TOP : 0;                            // the tree's top levels (rt_traverse.h top_table_fill)
-    __shared__ uint4 lds_top[TOP > 0 ? TOP : 1];
     const DevScene &sc = *scp;
-    const unsigned top_lim = top_table_fill<TOP>(sc, (uint4 RT_L *)lds_top);
     const DevFrame &fr = *frp;
     const PipePool &pl = *plp;
     const unsigned gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
@@ -135,8 +129,7 @@ __global__ __launch_bounds__(RT_BLOCK, COUNT ? 1 : RT_MARCH_WAVES) void pipe_mar
         const int leave_at = live0 > RT_MARCH_REFILL ? live0 - RT_MARCH_REFILL : 0;
 #pragma unroll 1
         do {
-            trace_round<COUNT, ACCEL, EXT, RT_MARCH_STACK, true, RT_PIPE_TRACE_DSTEPS, TOP>(ln.tv, busy && ln.has_ray, sc, (uint2 RT_L *)lds_stack, (float RT_L *)lds_tm, RT_GPTR(uint2, job.spill), job.n_threads, gtid, tc,
-                                                                                            RT_TRACE_LEAF_MIN, (const uint4 RT_L *)lds_top, top_lim);
+            trace_round<COUNT, ACCEL, EXT, RT_MARCH_STACK, true, RT_PIPE_TRACE_DSTEPS>(ln.tv, busy && ln.has_ray, sc, (uint2 RT_L *)lds_stack, (float RT_L *)lds_tm, RT_GPTR(uint2, job.spill), job.n_threads, gtid, tc);
         } while (__popcll(__ballot(busy && ln.has_ray && ln.tv.active)) > leave_at);
     }
     if (COUNT) {

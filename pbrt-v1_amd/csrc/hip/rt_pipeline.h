@@ -24,9 +24,6 @@
 #ifndef RT_TRACE_WAVES
 #define RT_TRACE_WAVES 6          // waves per SIMD the trace kernel is built for: its 24 KB of LDS stack planes allow 6 workgroups per CU (80 VGPRs)
 #endif
-#ifndef RT_TRACE_TOP
-#define RT_TRACE_TOP 0            // records of the tree's top levels in LDS (6 workgroups per CU: 24 KB of stack planes leave 2.6 KB each)
-#endif
 #ifndef RT_TRACE_STACK
 #define RT_TRACE_STACK 8          // LDS ring entries per lane in the trace kernel: 8 x 8 B x 256 = 16 KB per workgroup, 8 workgroups per CU
 #endif
@@ -266,10 +263,7 @@ template <bool COUNT, int ACCEL, bool EXT>
 __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) void pipe_trace_kernel(const DevScene *__restrict__ scp, TraceJob job) {
     __shared__ uint2 lds_stack[RT_TRACE_STACK * RT_BLOCK];
     __shared__ float lds_tm[(ACCEL != RT_ACCEL_GRID && !EXT) ? RT_TRACE_STACK * RT_BLOCK : 1];       // second plane of the pair-form stack
-    constexpr int TOP = (ACCEL != RT_ACCEL_GRID && !EXT) ? RT_TRACE_TOP : 0;                          // the tree's top levels (rt_traverse.h top_table_fill)
-    __shared__ uint4 lds_top[TOP > 0 ? TOP : 1];
     const DevScene &sc = *scp;
-    const unsigned top_lim = top_table_fill<TOP>(sc, (uint4 RT_L *)lds_top);
     const unsigned gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const unsigned n_closest = job.q_count[0], total = n_closest + job.q_count[RT_QC_ANY];
@@ -340,8 +334,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) void pipe_trace_kernel(co
         const int leave_at = exhausted ? 0 : (live0 > RT_TRACE_REFILL ? live0 - RT_TRACE_REFILL : 0);
 #pragma unroll 1
         do {
-            trace_round<COUNT, ACCEL, EXT, RT_TRACE_STACK, true, RT_PIPE_TRACE_DSTEPS, TOP>(tv, busy, sc, (uint2 RT_L *)lds_stack, (float RT_L *)lds_tm, RT_GPTR(uint2, job.spill), job.n_threads, gtid, tc,
-                                                                                            RT_TRACE_LEAF_MIN, (const uint4 RT_L *)lds_top, top_lim);
+            trace_round<COUNT, ACCEL, EXT, RT_TRACE_STACK, true, RT_PIPE_TRACE_DSTEPS>(tv, busy, sc, (uint2 RT_L *)lds_stack, (float RT_L *)lds_tm, RT_GPTR(uint2, job.spill), job.n_threads, gtid, tc);
         } while (__popcll(__ballot(busy && tv.active)) > leave_at);
     }
     if (COUNT) {

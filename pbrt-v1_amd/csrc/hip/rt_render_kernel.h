@@ -28,11 +28,6 @@ RT_DEV unsigned long long band_lo(unsigned long long total, unsigned r, unsigned
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 1
 #endif
-// records of the tree's top levels a workgroup of the register-capped flavour keeps in LDS (16 B each; 0: none).  4 workgroups per CU share 160 KB:
-// 36 KB of stack planes at 12 ring entries leave 4 KB each
-#ifndef RT_MEGA_TOP
-#define RT_MEGA_TOP 0
-#endif
 // the path integrator by vertex (rt_integrate.h advance_pass_byv) in the register-capped flavour of the kd-tree / grid kernels without a medium
 #ifndef RT_MEGA_BYV
 #define RT_MEGA_BYV 1
@@ -63,9 +58,6 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
     // use) runs the pair form; the natural-allocation kernels keep the index form (C2's kernel sits 2 VGPRs below the 3-wave step)
     __shared__ float lds_tm_own[POOL ? 1 : RT_STACK_LDS * RT_BLOCK];
     float RT_L *lds_tm = (float RT_L *)lds_tm_own;
-    // the tree's top levels (rt_traverse.h top_table_fill): pair-form kernels on the kd-tree only
-    constexpr int TOP = (!POOL && ACCEL != RT_ACCEL_GRID && !EXT) ? RT_MEGA_TOP : 0;
-    __shared__ uint4 lds_top[TOP > 0 ? TOP : 1];
     const DevScene &sc = *scp;
     const DevFrame &fr = *frp;
     const unsigned wave0 = POOL ? (threadIdx.x & ~63u) : 0u;
@@ -73,7 +65,6 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
                           (float4 RT_L *)pool_ray + 3 * wave0};
     const unsigned gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const unsigned top_lim = top_table_fill<TOP>(sc, (uint4 RT_L *)lds_top);
     constexpr bool BYV = RT_MEGA_BYV != 0 && !POOL && INTEG == RT_INTEGRATOR_PATH && !VOL && !EXT && !COUNT;
     Lane ln;
     ln.vf = 0u;
@@ -187,8 +178,7 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
             RT_PF(++pf_rounds; pf_act += __popcll(am);)
             if (fr.exit_thresh > 0 && __popcll(am) <= fr.exit_thresh && __any(!act && ln.stage != ST_EXIT)) break;
             if (POOL && fr.trav_mode == 3) accel_round_pooled<COUNT, ACCEL, EXT>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc, pool);
-            else trace_round<COUNT, ACCEL, EXT, RT_STACK_LDS, !POOL, RT_TRACE_DSTEPS, TOP>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, lds_tm, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc, fr.leaf_min,
-                                                                                            (const uint4 RT_L *)lds_top, top_lim);
+            else trace_round<COUNT, ACCEL, EXT, RT_STACK_LDS, !POOL>(ln.tv, ln.has_ray, sc, (uint2 RT_L *)lds_stack, lds_tm, RT_GPTR(uint2, fr.spill), fr.n_threads, gtid, tc, fr.leaf_min);
         }
         if (ln.has_ray && !ln.tv.active && !(BYV && (ln.vf & (BV_QM | BV_QB)) != 0u)) ln.has_ray = false;
         RT_PF(pf_trav += __builtin_readcyclecounter() - pf_t0;)

@@ -16,7 +16,6 @@
 //   * no mailboxing: re-testing a triangle returns the same t (ties accepted, B6).
 #pragma once
 #include "rt_device.h"
-#include "rt_top_fetch.h"
 
 // LDS stack entries per lane: 12 x 8 B x 256 lanes = 24 KB per workgroup, so LDS never limits residency below 6 workgroups
 // per CU; when the ring is full the oldest entry spills to HBM (counted) -- see stack_push / stack_pop.
@@ -552,20 +551,7 @@ RT_DEV void kd_pop_flat(Trav &tv, bool done, const uint2 RT_L *lds_stack, const 
 // ---- sibling-pair form of the node step and the pop (DevScene::tpairs) -----------------------------------------------------
 // Stack entry = {far child's node words, tmax}: 8 + 4 bytes in two LDS planes [NS][RT_BLOCK]; the oldest entries spill to HBM as
 // uint4.  Visit order, tie rules and counters are those of kd_step_flat (kdtree.cpp:313-488); what changes is what is fetched.
-struct PairStack { uint2 RT_L *xy; float RT_L *tm; uint4 RT_G *spill; const uint4 RT_L *top; unsigned top_lim; };
-// The top of the tree in LDS (round 5).  The first DevScene::top_pairs records of `tpairs` are the owner blocks of the tree's top levels in
-// breadth-first order, packed without padding (pair_blocks_order, rt_kernels.hip); a workgroup copies the first TOP of them into LDS once
-// (persistent kernels: amortised to nothing) and kdp_step reads a record whose index lies below the copy's end with ds_read_b128 instead of
-// global_load_dwordx4: the ~10 levels every ray walks leave the vector-memory path (the CU's L1 is stalled on its request queue 58-65 % of
-// the cycles).  Same records, same decisions: hits, films and counters cannot change.
-template <int TOP>
-RT_DEV unsigned top_table_fill(const DevScene &sc, uint4 RT_L *lds_top) {
-    if (TOP <= 0) return 0u;
-    const unsigned n = sc.top_pairs < unsigned(TOP) ? sc.top_pairs : unsigned(TOP);
-    for (unsigned i = threadIdx.x; i < n; i += RT_BLOCK) lds_top[i] = RT_GPTR(const uint4, sc.tpairs)[i];
-    __syncthreads();
-    return n > 2u ? n - 2u : 0u;             // a step reads records idx and idx + 1 or idx + 2
-}
+struct PairStack { uint2 RT_L *xy; float RT_L *tm; uint4 RT_G *spill; };
 // push {far child's words, tmax}; when the ring is full its oldest entry moves to HBM
 template <bool COUNT, int NS>
 RT_DEV void kdp_push(Trav &tv, PairStack st, unsigned sx, unsigned sy, float tmax, unsigned n_threads, unsigned gtid, TravCounters &cnt) {
@@ -588,7 +574,7 @@ RT_DEV void kdp_push(Trav &tv, PairStack st, unsigned sx, unsigned sy, float tma
 // exist).  So the step asks for pair(P) and pair(chosen child) together, and when they arrive takes the reference's decisions for P
 // and for that child back to back (kdtree.cpp:340-365, same comparisons, same push order).  A node that is not an owner (flags 0: a
 // member of its parent's block, reached through a pop) takes the one-level form of the same code.
-template <bool COUNT, int NS, int TOP = 0>
+template <bool COUNT, int NS>
 RT_DEV void kdp_step(Trav &tv, bool desc, const DevScene &sc, PairStack st, unsigned n_threads, unsigned gtid, TravCounters &cnt) {
     const bool dead = desc && !tv.any && tv.maxt < tv.tmin;                    // kdtree.cpp:330
     const bool go = desc && !dead;
@@ -609,18 +595,10 @@ RT_DEV void kdp_step(Trav &tv, bool desc, const DevScene &sc, PairStack st, unsi
     const unsigned idx = tv.cy & 0x3fffffffu, fb = (tv.cy >> 30) & 1u, fa = tv.cy >> 31;
     const bool two = interior && (c_above ? fa : fb) != 0u;                    // that child's pair sits in this node's block
     uint4 A, B; undef_u4(A); undef_u4(B);
-    const unsigned second = 1u + (c_above ? fb : 0u);
-    if (TOP > 0) {
-        // lanes whose node lies in the workgroup's LDS copy of the top levels read it there, the others from HBM: one instruction group, one wait
-        // (rt_top_fetch.h says why this is not left to the compiler)
-        const unsigned long long m_i = __ballot(interior), m_t = __ballot(idx < st.top_lim), m_2 = __ballot(two);
-        const unsigned la = unsigned(size_t(st.top)) + idx * 16u;
-        const uint4 RT_G *ga = RT_GPTR(const uint4, sc.tpairs) + idx;
-        pair_fetch_mixed(A, B, m_i & m_t, m_2 & m_t, m_i & ~m_t, m_2 & ~m_t, la, la + second * 16u, ga, ga + second);
-    } else if (interior) {
+    if (interior) {
         const uint4 RT_G *p = RT_GPTR(const uint4, sc.tpairs) + idx;
         A = p[0];
-        if (two) B = p[second];
+        if (two) B = p[1u + (c_above ? fb : 0u)];
     }
     const unsigned c_x = c_above ? A.z : A.x, c_y = c_above ? A.w : A.y;
     const unsigned f_x = c_above ? A.x : A.z, f_y = c_above ? A.y : A.w;
@@ -679,11 +657,11 @@ RT_DEV void kdp_pop(Trav &tv, bool done, PairStack st, unsigned n_threads, unsig
     tv.active = (done && (!pop || dead)) ? false : tv.active;
 }
 
-template <bool COUNT, int ACCEL, bool EXT, int NS, bool PAIRS_OK = true, int DSTEPS = RT_TRACE_DSTEPS, int TOP = 0>
+template <bool COUNT, int ACCEL, bool EXT, int NS, bool PAIRS_OK = true, int DSTEPS = RT_TRACE_DSTEPS>
 RT_DEV void trace_round(Trav &tv, bool busy, const DevScene &sc, uint2 RT_L *lds_stack, float RT_L *lds_tm, uint2 RT_G *spill, unsigned n_threads, unsigned gtid, TravCounters &cnt,
-                        int leaf_min = RT_TRACE_LEAF_MIN, const uint4 RT_L *lds_top = nullptr, unsigned top_lim = 0u) {
+                        int leaf_min = RT_TRACE_LEAF_MIN) {
     constexpr bool PAIRS = PAIRS_OK && ACCEL != RT_ACCEL_GRID && !EXT;
-    const PairStack pst = {lds_stack, lds_tm, (uint4 RT_G *)spill, lds_top, top_lim};
+    const PairStack pst = {lds_stack, lds_tm, (uint4 RT_G *)spill};
     if (ACCEL == RT_ACCEL_GRID) {
         if (busy && tv.active && !tv.at_leaf) grid_enter_voxel<COUNT>(tv, sc, cnt);
     } else if (PAIRS) {
@@ -691,7 +669,7 @@ RT_DEV void trace_round(Trav &tv, bool busy, const DevScene &sc, uint2 RT_L *lds
         for (int k = 0; k < DSTEPS; ++k) {
             const bool desc = busy && tv.active && !tv.at_leaf;
             if (!__any(desc)) break;
-            kdp_step<COUNT, NS, TOP>(tv, desc, sc, pst, n_threads, gtid, cnt);
+            kdp_step<COUNT, NS>(tv, desc, sc, pst, n_threads, gtid, cnt);
         }
     } else {
 #pragma unroll 1
