@@ -196,7 +196,7 @@ __global__ void weighted_sizes_kernel(const unsigned *__restrict__ base, unsigne
 // The recurrence for such a frame: as weighted_recurrence_lds_kernel (one lane walks, the integrator's arrays in LDS), sample by sample, with k = the
 // drawing lights chosen so far in the sample: a drawing light's estimate is read from the k-th of its j + 1 survey entries.  Groups of consecutive
 // samples are staged through LDS by all lanes; a sample whose records do not fit is read from HBM directly.
-// LDS floats: avgY[nL] f[nL] cdf[nL + 1] ya[nL] yb[nL] | sb[group + 1] rb[group + 1] | buf[cap_floats] | out float2[cap_points]
+// LDS floats: avgY[nL] f[nL] cdf[nL + 1] ya[nL] yb[nL] | sb[group + 1] rb[group + 1] | (pad to even) buf[cap_floats] | out float2[cap_points]
 __global__ __launch_bounds__(64) void weighted_recurrence_mixed_kernel(const float *__restrict__ rec, float2 *__restrict__ pick, const unsigned *__restrict__ base,
                                                                         const unsigned *__restrict__ recbase, unsigned long long n_samples, int nL, int nD,
                                                                         const unsigned *__restrict__ draws, int group, int cap_floats, int cap_points) {
@@ -204,6 +204,7 @@ __global__ __launch_bounds__(64) void weighted_recurrence_mixed_kernel(const flo
     float *avgY = wt_lds, *f = avgY + nL, *cdf = f + nL, *ya = cdf + nL + 1, *yb = ya + nL;
     unsigned *sb = (unsigned *)(yb + nL), *rb = sb + group + 1;
     float *buf = (float *)(rb + group + 1);
+    buf += (buf - wt_lds) & 1;                                                 // an even float offset, so that the picks behind the records are 8-byte aligned
     float2 *out = (float2 *)(buf + ((cap_floats + 1) & ~1));
     const int lane = threadIdx.x;
     const unsigned A = 1u + 2u * unsigned(nL - nD);
