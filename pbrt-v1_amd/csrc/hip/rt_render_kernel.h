@@ -32,9 +32,7 @@ RT_DEV unsigned long long band_lo(unsigned long long total, unsigned r, unsigned
 #ifndef RT_MEGA_BYV
 #define RT_MEGA_BYV 1
 #endif
-#ifndef RT_MEGA_GUIDED
-#define RT_MEGA_GUIDED 0          // > 0: guided chunk sizes near the end of a band, this many samples at least (under measurement)
-#endif
+
 
 // waves per SIMD of the high-occupancy flavour: 4 = 128 VGPRs.  5 (96 VGPRs) was marginally faster at one point but its
 // spill placement swings with every code change (measured 108 -> 153 ms on the 1 M-triangle path frame for the same
@@ -90,9 +88,7 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
     unsigned long long w_next = 0, w_end = 0;                              // this wave's chunk of the sample list (wave-uniform)
     const unsigned n_bands = fr.xcd_bands ? 8u : 1u, home = fr.xcd_bands ? (blockIdx.x & 7u) : 0u;
     unsigned band_shift = 0;                                               // bands this wave has seen the end of
-#if RT_MEGA_GUIDED
-    unsigned long long w_seen = 0; unsigned band_seen = ~0u;               // the head of that band's counter as this wave last saw it
-#endif
+
     // phase gating (rt_integrate.h, stage_in_phase): sweeps alternate between the two halves of the path state machine;
     // the first sweep is of the second kind (it contains the work fetch)
     int phase = (INTEG == RT_INTEGRATOR_PATH && fr.phase_sync && !BYV) ? 1 : -1;
@@ -119,24 +115,10 @@ __global__ __launch_bounds__(RT_BLOCK, MINW) void render_kernel(const DevScene *
                     while (band_shift < n_bands) {
                         const unsigned r = (home + band_shift) % n_bands;
                         const unsigned long long lo = band_lo(fr.total_work, r, n_bands), hi = band_lo(fr.total_work, r + 1u, n_bands);
-                        unsigned long long base = 0, csize = RT_MEGA_CHUNK;
-#if RT_MEGA_GUIDED
-                        // guided chunks: as a band runs dry a wave takes only what its idle lanes need now (at least RT_MEGA_GUIDED), so that the band's last samples are
-                        // spread over the lanes of ALL waves instead of waiting in the private remainders of a few
-                        {
-                            const unsigned long long head = lo + w_seen < hi && band_seen == r ? lo + w_seen : (band_seen == r ? hi : lo);
-                            const unsigned long long share = (hi - head) / (2ull * (gridDim.x * (RT_BLOCK / 64u) / n_bands) + 1ull);
-                            const unsigned long long need = n_want - have;
-                            csize = share < need ? need : share;
-                            csize = csize < RT_MEGA_GUIDED ? RT_MEGA_GUIDED : (csize > RT_MEGA_CHUNK ? RT_MEGA_CHUNK : csize);
-                        }
-#endif
-                        if (lane == leader) base = atomicAdd(fr.work_counter + 8u * r, csize);
+                        unsigned long long base = 0;
+                        if (lane == leader) base = atomicAdd(fr.work_counter + 8u * r, (unsigned long long)RT_MEGA_CHUNK);
                         base = uniform64(__shfl(base, leader));
-#if RT_MEGA_GUIDED
-                        band_seen = r; w_seen = base + csize;
-#endif
-                        if (lo + base < hi) { fresh = lo + base; fresh_end = fresh + csize < hi ? fresh + csize : hi; break; }
+                        if (lo + base < hi) { fresh = lo + base; fresh_end = fresh + RT_MEGA_CHUNK < hi ? fresh + RT_MEGA_CHUNK : hi; break; }
                         ++band_shift;
                     }
                 }
