@@ -515,15 +515,21 @@ def main():
         if rec is not None:
             records.append({k: rec[k] for k in ("value", "unit", "n_gpus", "ms_per_step", "steps", "host_handover", "config", "roofline", "per_rank", "cpu_baseline") if k in rec} |
                            ({"speedup_vs_cpu_baseline": rec["speedup_vs_cpu_baseline"]} if "speedup_vs_cpu_baseline" in rec else {}) | {"workload": w})
+    if dist is not None:                                                 # before the line is printed: RCCL writes its version banner to stdout when the group goes down
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except BaseException:
+            pass
+    try:                                                                 # RCCL's banner sits in the C library's stdout buffer until exit: out with it, so that the JSON line is the LAST line
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except BaseException:
+        pass
     if rank == 0:
         if records:
             out["workloads"] = records
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        try:
-            dist.destroy_process_group()
-        except BaseException:
-            pass
 
 
 if __name__ == "__main__":
