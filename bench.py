@@ -198,23 +198,29 @@ def run_workload(name, args, pkg, torch, dist, world, rank, device_index, steps,
     tiles_used = ps.set_shard(rank, emu if (emu > 1 and world == 1) else world, tiles, fit=True)   # 2-D tiles sized to pad the sample extent least
     # One accelerator build per node, not per rank: local rank 0 builds (all host cores: 10 M triangles take 15 s) and publishes the
     # flattened tree under /dev/shm; the other ranks map it (rt_scene_create_prebuilt).  Reference: every cropwindow process builds its own.
-    shared = None
-    if dist is not None and not os.environ.get("PBRT_BENCH_NO_SHARED_ACCEL"):
-        shm = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
-        shared = os.path.join(shm, "pbrt_hip_accel_%s_%s.bin" % (os.environ.get("MASTER_PORT", "0"), name))
+    share = dist is not None and not os.environ.get("PBRT_BENCH_NO_SHARED_ACCEL")
     t_create = time.perf_counter()
-    if shared is None:
+    if not share:
         ds = pkg.DeviceScene(ps, device=device_index)
     else:
         local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+        where = [None]
         if local_rank == 0:
             ds = pkg.DeviceScene(ps, device=device_index)
-            pkg.publish_accel(ds, shared)
-        dist.barrier()
+            for d in ("/dev/shm", "/tmp"):                                # the first place with room for it (10 M triangles: 6 GB); none: every rank builds its own
+                path = os.path.join(d, "pbrt_hip_accel_%s_%s.bin" % (os.environ.get("MASTER_PORT", "0"), name))
+                try:
+                    pkg.publish_accel(ds, path)
+                    where[0] = path
+                    break
+                except OSError as e:
+                    print("bench.py: cannot publish the accelerator under %s (%s)" % (d, e), file=sys.stderr, flush=True)
+        dist.broadcast_object_list(where, src=0)                          # (one node: rank 0 is local rank 0)
+        shared = where[0]
         if local_rank != 0:
-            ds = pkg.DeviceScene(ps, device=device_index, prebuilt=pkg.attach_accel(shared))
+            ds = pkg.DeviceScene(ps, device=device_index, prebuilt=pkg.attach_accel(shared)) if shared else pkg.DeviceScene(ps, device=device_index)
         dist.barrier()
-        if local_rank == 0:
+        if local_rank == 0 and shared:
             os.remove(shared)
     t_create = time.perf_counter() - t_create
     info = ds.accel_info()

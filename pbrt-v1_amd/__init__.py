@@ -337,12 +337,21 @@ def publish_accel(ds: "DeviceScene", path: str) -> None:
     """Rank 0 of a node: write the accelerator of `ds` where the other ranks can map it (e.g. under /dev/shm): one file, header
     (RtAccelInfo bytes) + nodes + leaf refs, renamed into place when complete."""
     info = ds.accel_info()
+    need = 256 + 8 * int(info.n_nodes) + 4 * int(info.n_leaf_refs)
+    st = os.statvfs(os.path.dirname(path) or ".")
+    if st.f_bavail * st.f_frsize < need + (64 << 20):
+        raise OSError("publish_accel: %s has %d MB free, the accelerator needs %d MB" % (os.path.dirname(path), st.f_bavail * st.f_frsize >> 20, need >> 20))
     nodes, refs = ds.accel_arrays()
     tmp = path + ".tmp%d" % os.getpid()
-    with open(tmp, "wb") as f:
-        f.write(bytes(info).ljust(256, b"\0"))
-        f.write(nodes.tobytes()); f.write(np.ascontiguousarray(refs, np.uint32).tobytes())
-    os.replace(tmp, path)
+    try:
+        with open(tmp, "wb") as f:
+            f.write(bytes(info).ljust(256, b"\0"))
+            np.ascontiguousarray(nodes, np.uint32).tofile(f); np.ascontiguousarray(refs, np.uint32).tofile(f)     # (no second copy in memory: 6 GB at 10 M triangles)
+        os.replace(tmp, path)
+    except BaseException:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+        raise
 
 
 def attach_accel(path: str):
