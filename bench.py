@@ -452,6 +452,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even for one rank: exercises the N > 1 code path on a single GPU")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")             # dmabuf IPC only on these hosts: without it RCCL's buffer exchange fails with hipIpcGetMemHandle errors
     import torch
     import __graft_entry__ as entry
     pkg = entry.load_package()
