@@ -3,15 +3,6 @@
 #include "rt_math.h"
 #include "../../../include/pbrt_hip.h"
 
-// Leaf-ordered triangle records (DevScene::ltris): RT_LEAF_REC_DWORDS = 12: 48-byte records {p1, e1, e2, bits, light, primitive} at 16-byte units (rounds 2-4);
-// 10: 40-byte records {p1, e1, e2, primitive} on a 40-byte grid (round 5: three single-primitive leaves per 128-byte line instead of two).  A leaf's word 1
-// counts RT_LEAF_UNIT_BYTES units; a record takes RT_LEAF_REC_UNITS of them.
-#ifndef RT_LEAF_REC_DWORDS
-#define RT_LEAF_REC_DWORDS 12
-#endif
-#define RT_LEAF_UNIT_BYTES (RT_LEAF_REC_DWORDS == 12 ? 16 : 40)
-#define RT_LEAF_REC_UNITS (RT_LEAF_REC_DWORDS == 12 ? 3 : 1)
-
 namespace rt {
 
 // One triangle = three 16-byte vectors (48 B, one 128-B line holds 2.67 of them):

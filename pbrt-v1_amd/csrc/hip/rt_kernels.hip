@@ -698,10 +698,8 @@ static size_t leaf_order_offsets(const NodeVec &nodes, NodeVec &tnodes) {
     tnodes.resize(nodes.size());
     const size_t B = size_t(1) << 20, nb = (nodes.size() + B - 1) / B;
     std::vector<size_t> size(nb + 1, 0);
-    constexpr size_t U = RT_LEAF_UNIT_BYTES, RB = size_t(RT_LEAF_REC_DWORDS) * 4;      // unit and record size in bytes; a line is 128 bytes
-    auto lines = [](size_t off, size_t bytes) { return (off * U + bytes - 1) / 128 - (off * U) / 128 + 1; };
     auto block = [&](size_t b) {
-        size_t off = 0;                                   // units from the block's start (the block starts on a line boundary)
+        size_t off = 0;                                   // float4 units (16 B) from the block's start; a line is 8 units
         const size_t hi = std::min(nodes.size(), (b + 1) * B);
         for (size_t i = b * B; i < hi; ++i) {
             const Node n = nodes[i];
@@ -709,16 +707,13 @@ static size_t leaf_order_offsets(const NodeVec &nodes, NodeVec &tnodes) {
             if ((n.x & 3u) != 3u) continue;
             const uint32_t np = n.x >> 2;
             if (np == 0) { tnodes[i].y = 0u; continue; }
-            const size_t bytes = size_t(np) * RB, lines_min = (bytes + 127) / 128;
-            if (lines(off, bytes) > lines_min) {
-                if (U == 16) off = (off + 7) / 8 * 8;     // to the next line
-                else for (int k = 0; k < 3 && lines(off, bytes) > lines_min; ++k) ++off;      // 40-byte grid: skip up to three record slots
-            }
+            const size_t units = size_t(np) * 3;
+            const size_t lines_here = (off % 8 + units + 7) / 8, lines_min = (units + 7) / 8;
+            if (lines_here > lines_min) off = (off + 7) / 8 * 8;
             tnodes[i].y = uint32_t(off);                 // block-local for now
-            off += size_t(np) * RT_LEAF_REC_UNITS;
+            off += units;
         }
-        const size_t q = U == 16 ? 8 : 16;                // units per whole number of lines (128 / 16; 640 / 40)
-        size[b + 1] = (off + q - 1) / q * q;
+        size[b + 1] = (off + 7) / 8 * 8;
     };
     const size_t nthreads = nb < 4 ? 1 : std::min<size_t>(nb, std::max(1u, std::min(64u, std::thread::hardware_concurrency())));
     auto run = [&](auto fn) {
@@ -741,20 +736,17 @@ static size_t leaf_order_offsets(const NodeVec &nodes, NodeVec &tnodes) {
 // pass 2 on the host (the reference form of rt::derive_leaf_records_kernel below: PBRT_HIP_VERIFY_DERIVED compares the two byte for byte)
 static void leaf_order_fill_host(const NodeVec &nodes, const NodeVec &tnodes, const RefVec &leaf_refs,
                                  const std::vector<DevTri> &tris, LeafRecords &ltris, size_t units) {
-    const size_t n4 = (units * RT_LEAF_UNIT_BYTES + 15) / 16;
-    ltris.resize(n4);
-    std::memset((void *)ltris.data(), 0, n4 * sizeof(float4));
+    ltris.resize(units);
+    std::memset((void *)ltris.data(), 0, units * sizeof(float4));
     for (size_t i = 0; i < nodes.size(); ++i) {
         const Node &n = nodes[i];
         if ((n.x & 3u) != 3u) continue;
         const uint32_t np = n.x >> 2;
-        float *dst = reinterpret_cast<float *>(ltris.data()) + size_t(tnodes[i].y) * (RT_LEAF_UNIT_BYTES / 4);
+        float4 *dst = ltris.data() + tnodes[i].y;
         for (uint32_t k = 0; k < np; ++k) {
             const uint32_t prim = np == 1 ? n.y : leaf_refs[n.y + k];
             float4 q2 = tris[prim].q2; std::memcpy(&q2.w, &prim, 4);
-            float *r = dst + size_t(k) * RT_LEAF_REC_DWORDS;
-            std::memcpy(r, &tris[prim].q0, 16); std::memcpy(r + 4, &tris[prim].q1, 16);
-            if (RT_LEAF_REC_DWORDS == 12) std::memcpy(r + 8, &q2, 16); else { r[8] = q2.x; r[9] = q2.w; }
+            dst[3 * k] = tris[prim].q0; dst[3 * k + 1] = tris[prim].q1; dst[3 * k + 2] = q2;
         }
     }
 }
@@ -769,17 +761,12 @@ __global__ void derive_leaf_records_kernel(const uint2 *__restrict__ nodes, cons
     const uint2 n = nodes[i];
     if ((n.x & 3u) != 3u) return;
     const unsigned np = n.x >> 2;
-    float *dst = reinterpret_cast<float *>(ltris) + size_t(tnodes[i].y) * (RT_LEAF_UNIT_BYTES / 4);
+    float4 *dst = ltris + tnodes[i].y;
     for (unsigned k = 0; k < np; ++k) {
         const unsigned prim = np == 1u ? n.y : leaf_refs[n.y + k];
         const DevTri t = tris[prim];
-        float *r = dst + size_t(k) * RT_LEAF_REC_DWORDS;
-#if RT_LEAF_REC_DWORDS == 12
         float4 q2 = t.q2; q2.w = __uint_as_float(prim);
-        reinterpret_cast<float4 *>(r)[0] = t.q0; reinterpret_cast<float4 *>(r)[1] = t.q1; reinterpret_cast<float4 *>(r)[2] = q2;
-#else
-        r[0] = t.q0.x; r[1] = t.q0.y; r[2] = t.q0.z; r[3] = t.q0.w; r[4] = t.q1.x; r[5] = t.q1.y; r[6] = t.q1.z; r[7] = t.q1.w; r[8] = t.q2.x; r[9] = __uint_as_float(prim);
-#endif
+        dst[3 * k] = t.q0; dst[3 * k + 1] = t.q1; dst[3 * k + 2] = q2;
     }
 }
 }  // namespace rt
@@ -1299,25 +1286,24 @@ static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel 
         tick("node / leaf-list upload");
         const size_t units = leaf_order_offsets(s->tree.nodes, tn);
         tick("leaf-order offsets");
-        if (units >= (size_t(1) << 32)) return fail(RT_EINVAL, "rt_scene_create: leaf-ordered triangle array beyond 2^32 units");
+        if (units >= (size_t(1) << 32)) return fail(RT_EINVAL, "rt_scene_create: leaf-ordered triangle array beyond 2^32 float4 units");
         if ((rc = upload_nodes(tn, &s->dev.tnodes))) return rc;
         {
             void *p = nullptr;
-            const size_t lbytes = (units * RT_LEAF_UNIT_BYTES + 15) / 16 * 16;
-            HIPCHK(hipMalloc(&p, lbytes + 16));
+            HIPCHK(hipMalloc(&p, units * sizeof(float4)));
             s->allocs.push_back(p);
             s->dev.ltris = (const float4 *)p;
-            HIPCHK(hipMemsetAsync(p, 0, lbytes + 16, s->stream));
+            HIPCHK(hipMemsetAsync(p, 0, units * sizeof(float4), s->stream));
             const size_t nn = s->tree.nodes.size();
             if (nn) hipLaunchKernelGGL(derive_leaf_records_kernel, dim3(unsigned((nn + 255) / 256)), dim3(256), 0, s->stream, s->dev.nodes, s->dev.tnodes,
                                        s->dev.leaf_refs, (const DevTri *)s->dev.tris, (float4 *)p, nn);
             HIPCHK(hipGetLastError());
             if (knob("PBRT_HIP_VERIFY_DERIVED")) {             // tests: the device fill against the host fill, byte for byte
                 LeafRecords lt; leaf_order_fill_host(s->tree.nodes, tn, s->tree.leaf_refs, tris, lt, units);
-                std::vector<float4> back(lbytes / 16);
+                std::vector<float4> back(units);
                 HIPCHK(hipStreamSynchronize(s->stream));
-                HIPCHK(hipMemcpy(back.data(), p, lbytes, hipMemcpyDeviceToHost));
-                if (std::memcmp(back.data(), lt.data(), lbytes) != 0) return fail(RT_ESTATE, "rt_scene_create: the device-built leaf-ordered records differ from the host fill");
+                HIPCHK(hipMemcpy(back.data(), p, units * sizeof(float4), hipMemcpyDeviceToHost));
+                if (std::memcmp(back.data(), lt.data(), units * sizeof(float4)) != 0) return fail(RT_ESTATE, "rt_scene_create: the device-built leaf-ordered records differ from the host fill");
             }
         }
         s->n_leaf_tri_units = units;

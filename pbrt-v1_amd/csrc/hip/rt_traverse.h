@@ -511,18 +511,8 @@ RT_DEV void leaf_test_flat(Trav &tv, bool leafw, const DevScene &sc, TravCounter
     const bool single = tv.ln_ == 1u;
     float4 q0, q1, q2; undef_f4(q0); undef_f4(q1); undef_f4(q2);
     if (leafw) {
-#if RT_LEAF_REC_DWORDS == 12
         const float4 RT_G *gt = RT_GPTR(const float4, sc.ltris) + (size_t(tv.ly) + 3u * tv.li);
         q0 = gt[0]; q1 = gt[1]; q2 = gt[2];
-#else
-        // 40-byte records on a 40-byte grid: two 16-byte loads at 8-byte alignment and one of 8 bytes {e2.z, primitive}
-        typedef float rt_f4a8 __attribute__((ext_vector_type(4), aligned(8)));
-        typedef float rt_f2a8 __attribute__((ext_vector_type(2), aligned(8)));
-        const float RT_G *g = RT_GPTR(const float, sc.ltris) + (size_t(tv.ly) + tv.li) * 10u;
-        const rt_f4a8 a = *(const rt_f4a8 RT_G *)g, b = *(const rt_f4a8 RT_G *)(g + 4);
-        const rt_f2a8 c = *(const rt_f2a8 RT_G *)(g + 8);
-        q0 = make_float4(a.x, a.y, a.z, a.w); q1 = make_float4(b.x, b.y, b.z, b.w); q2 = make_float4(c.x, 0.f, 0.f, c.y);
-#endif
     }
     const unsigned prim = __float_as_uint(q2.w);
     if (COUNT) { cnt.tris += leafw ? 1u : 0u; cnt.leaf_refs += (leafw && !single) ? 1u : 0u; }
