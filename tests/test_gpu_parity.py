@@ -377,6 +377,45 @@ def test_full_size_properties(pkg, scenes):
     assert np.allclose(b[:3], 2 * a[:3], rtol=1e-4, atol=1e-4) and np.array_equal(b[4], a[4])
 
 
+@pytest.mark.parametrize("k", range(10))
+def test_by_vertex_path_kernels_equal_the_per_ray_twins_on_random_scenes(pkg, scenes, k, monkeypatch):
+    """Round 5: the timed path kernels run a vertex at a time (rt_integrate.h advance_pass_byv: the MIS and continuation rays are started inside the traversal loop, the two
+    EstimateDirect terms are added a vertex later); the counting twins still run ray by ray.  Seeded random scenes -- soup size, material mix, path depth 1 .. 10, the three
+    samplers, kd-tree and grid, a lens, several lights incl. none and delta only, the register-capped flavour forced on tiny trees -- must give bit-identical films, and the
+    timed kernel the same film twice."""
+    need_gpu(pkg)
+    rng = np.random.default_rng(500 + k)
+    kw = dict(xres=int(rng.integers(24, 72)), yres=int(rng.integers(24, 72)), integrator="path", maxdepth=int(rng.integers(1, 11)), keyed=True,
+              soup_tris=int(rng.choice([0, 300, 3000, 30000])), soup_materials=bool(rng.integers(0, 2)), accelerator=str(rng.choice(["kdtree", "kdtree", "grid"])),
+              pixel_filter=str(rng.choice(["box", "mitchell", "gaussian"])), seed=int(rng.integers(0, 1000)))
+    sampler = str(rng.choice(["stratified", "lowdiscrepancy", "random"]))
+    if sampler == "lowdiscrepancy":
+        kw.update(sampler=sampler, pixelsamples=int(rng.choice([1, 4, 8])))
+    else:
+        kw.update(sampler=sampler, xsamples=int(rng.integers(1, 4)), ysamples=int(rng.integers(1, 3)))
+        if sampler == "stratified":
+            kw["jitter"] = bool(rng.integers(0, 2))
+    if rng.integers(0, 3) == 0:
+        kw.update(lensradius=float(rng.uniform(1, 8)), focaldistance=float(rng.uniform(500, 1100)))
+    lights = int(rng.integers(0, 4))                                   # 0: the ceiling emitter only, 1: + a point light, 2: a point light only, 3: no light at all
+    wk = dict(mirror_quad=bool(rng.integers(0, 2)))
+    if lights == 1: wk.update(point_light=True)
+    if lights == 2: wk.update(point_light=True, area_light=False)
+    if lights == 3: wk.update(area_light=False)
+    ps = pkg.ParsedScene(text=scenes.cornell_scene(world_kwargs=wk, **kw))
+    assert ps.valid and ps.errors == 0, kw
+    monkeypatch.setenv("PBRT_HIP_HIGH_OCC", "1")                       # the flavour the by-vertex form lives in, also on tiny trees
+    ds = pkg.DeviceScene(ps)
+    ds.set_counting(True); ds.render(); twin = ds.film_accum(); cnt = ds.counters()
+    ds.set_counting(False); ds.clear_film(); ds.render(); a = ds.film_accum(); st = ds.last_stats()
+    ds.clear_film(); ds.render(); b = ds.film_accum()
+    ds.close()
+    assert st["pipeline"] == 0
+    assert np.array_equal(a, twin), ("by vertex != per ray", kw, wk)
+    assert np.array_equal(a, b), ("two renders of the timed kernel differ", kw)
+    assert cnt["camera_rays"] > 0 and cnt["bad_samples"] == 0
+
+
 def test_errors_are_loud(pkg, scenes):
     need_gpu(pkg)
     ps = pkg.ParsedScene(text=scenes.cornell_scene(xres=8, yres=8))
