@@ -31,6 +31,7 @@
 #include <atomic>
 #include <memory>
 #include <thread>
+#include <sys/mman.h>
 
 #ifndef RT_KD_MAX_THREADS
 #define RT_KD_MAX_THREADS 64          // (10 M triangles on a 256-thread host: 64 threads 5.0 s, 128 threads 5.7 s)
@@ -55,6 +56,12 @@ inline int log2_int(float v) {                                                  
     return int(double(logf(v) * inv_log2) + (.5 - 1.4e-11));
 }
 
+// large, freshly allocated arrays on 2 MB pages where the kernel offers them (madvise mode): their first touch is a few thousand page faults instead of millions
+inline void huge_pages(void *p, size_t bytes) {
+    const uintptr_t a = (reinterpret_cast<uintptr_t>(p) + 4095) & ~uintptr_t(4095);
+    if (bytes > (size_t(64) << 20)) madvise(reinterpret_cast<void *>(a), bytes - (a - reinterpret_cast<uintptr_t>(p)), MADV_HUGEPAGE);
+}
+
 // LIFO scratch: a node's child lists live here while its subtree is built
 class Stack {
   public:
@@ -65,6 +72,7 @@ class Stack {
         if (cur == blocks.size()) {
             const size_t sz = std::max(bytes, std::max<size_t>(size_t(1) << 22, blocks.empty() ? 0 : blocks.back().size * 2));
             blocks.push_back(Block{std::unique_ptr<char[]>(new char[sz]), sz});
+            huge_pages(blocks.back().mem.get(), sz);
             used = 0;
         }
         void *p = blocks[cur].mem.get() + used;
@@ -96,6 +104,7 @@ void parallel_sort(Edge *a, size_t n, int threads) {
     for (int b = 1; b < K; ++b) split.push_back(sample[size_t(b) * 64]);
     std::vector<size_t> count(size_t(K) * K, 0);                // [chunk][bucket]
     std::unique_ptr<Edge[]> tmp(new Edge[n]);
+    huge_pages(tmp.get(), n * sizeof(Edge));
     auto bucket_of = [&](const Edge &e) { return int(std::upper_bound(split.begin(), split.end(), e) - split.begin()); };
     auto run = [&](auto fn) { std::vector<std::thread> th; for (int t = 0; t < K; ++t) th.emplace_back(fn, t); for (auto &x : th) x.join(); };
     run([&](int c) { const size_t lo = n * c / K, hi = n * (c + 1) / K; size_t *cnt = &count[size_t(c) * K]; for (size_t i = lo; i < hi; ++i) ++cnt[bucket_of(a[i])]; });
@@ -489,7 +498,13 @@ class Builder {
             }
         } walk{top, tk, pos, pieces, nodeAt, refAt, std::vector<uint32_t>(top.size(), 0)};
         walk.go(0);
+        const bool slog = std::getenv("PBRT_HIP_CREATE_LOG") != nullptr;
+        auto st0 = std::chrono::steady_clock::now();
+        auto stick = [&](const char *what) { if (slog) { auto t = std::chrono::steady_clock::now(); std::fprintf(stderr, "KDBUILD   stitch: %-22s %.3f s\n", what, std::chrono::duration<double>(t - st0).count()); st0 = t; } };
         tree.nodes.resize(nodeAt); tree.leaf_refs.resize(refAt);
+        // the final arrays on 2 MB pages where the kernel offers them: their first touch by the copying threads is a few thousand page faults instead of 1.5 M
+        huge_pages(tree.nodes.data(), tree.nodes.size() * sizeof(Node)); huge_pages(tree.leaf_refs.data(), tree.leaf_refs.size() * sizeof(uint32_t));
+        stick("walk + resize");
         // pass 2: the top's own nodes
         for (size_t i = 0; i < top.size(); ++i) {
             const Node nd = top[i];
@@ -524,6 +539,7 @@ class Builder {
         std::vector<std::thread> pool;
         for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
         for (auto &th : pool) th.join();
+        stick("copy + free");
     }
 };
 
