@@ -30,6 +30,7 @@ extern "C" {
 #define RT_EINVAL (-1)   /* bad argument / inconsistent description          */
 #define RT_EDEVICE (-2)  /* HIP runtime error (no device, OOM, launch failed) */
 #define RT_ESTATE (-3)   /* call out of order (e.g. render before film bind)  */
+#define RT_ENOMEM (-4)   /* host memory exhausted while building the scene    */
 
 typedef struct RtScene RtScene; /* opaque */
 

@@ -74,9 +74,7 @@ void build_grid(const float *tri_verts, uint32_t n_tris, GridAccelData &out) {
             }
         };
         if (threads == 1) { work(0); return; }
-        std::vector<std::thread> pool;
-        for (int t = 0; t < threads; ++t) pool.emplace_back(work, t);
-        for (auto &th : pool) th.join();
+        ThreadGroup pool; for (int t = 0; t < threads; ++t) pool.spawn(work, t); pool.join();
     };
     slab_pass([&](size_t o, uint32_t) { ++out.voxels[o].y; });
     uint32_t total = 0;

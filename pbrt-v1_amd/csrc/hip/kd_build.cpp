@@ -106,7 +106,7 @@ void parallel_sort(Edge *a, size_t n, int threads) {
     std::unique_ptr<Edge[]> tmp(new Edge[n]);
     huge_pages(tmp.get(), n * sizeof(Edge));
     auto bucket_of = [&](const Edge &e) { return int(std::upper_bound(split.begin(), split.end(), e) - split.begin()); };
-    auto run = [&](auto fn) { std::vector<std::thread> th; for (int t = 0; t < K; ++t) th.emplace_back(fn, t); for (auto &x : th) x.join(); };
+    auto run = [&](auto fn) { ThreadGroup g; for (int t = 0; t < K; ++t) g.spawn(fn, t); g.join(); };
     run([&](int c) { const size_t lo = n * c / K, hi = n * (c + 1) / K; size_t *cnt = &count[size_t(c) * K]; for (size_t i = lo; i < hi; ++i) ++cnt[bucket_of(a[i])]; });
     std::vector<size_t> start(size_t(K) * K), bstart(K + 1, 0);
     { size_t at = 0; for (int b = 0; b < K; ++b) { bstart[b] = at; for (int c = 0; c < K; ++c) { start[size_t(c) * K + b] = at; at += count[size_t(c) * K + b]; } } bstart[K] = at; }
@@ -198,9 +198,7 @@ class Builder {
                 sub.build_task(t);
             }
         };
-        std::vector<std::thread> pool;
-        for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
-        for (auto &th : pool) th.join();
+        { ThreadGroup pool; for (int t = 0; t < threads; ++t) pool.spawn(worker); pool.join(); }
         tick("task pool");
         if (log) {
             std::sort(idle_at.begin(), idle_at.end());
@@ -249,9 +247,9 @@ class Builder {
         };
         if (threads < 3) { for (int a = 0; a < 3; ++a) one(a, threads); }
         else {
-            std::thread t1(one, 1, threads / 3), t2(one, 2, threads / 3);
+            ThreadGroup g; g.spawn(one, 1, threads / 3); g.spawn(one, 2, threads / 3);
             one(0, threads - 2 * (threads / 3));
-            t1.join(); t2.join();
+            g.join();
         }
         return L;
     }
@@ -384,7 +382,7 @@ class Builder {
                 // the sequential pass's, whatever P is
                 const size_t N2 = size_t(2) * n;
                 auto chunk = [&](size_t total, int c) { return std::make_pair(total * size_t(c) / size_t(P), total * size_t(c + 1) / size_t(P)); };
-                auto run = [&](auto fn) { std::vector<std::thread> th; for (int c = 1; c < P; ++c) th.emplace_back(fn, c); fn(0); for (auto &x : th) x.join(); };
+                auto run = [&](auto fn) { ThreadGroup g; for (int c = 1; c < P; ++c) g.spawn(fn, c); fn(0); g.join(); };
                 std::vector<size_t> cnt0(size_t(P) * 4, 0);                 // per chunk: [classification: starts, ends] then reused per axis
                 run([&](int c) {
                     const auto r = chunk(size_t(n), c);
@@ -438,7 +436,8 @@ class Builder {
             // above child in a forked thread (own scratch, arrays and task list), below child here; then append the forked arrays behind ours
             const int levels = fork_levels - 1, cut = cutoff;
             const int par_all = par;
-            std::thread th([&, levels, cut, par_all]() {
+            ThreadGroup th;
+            th.spawn([&, levels, cut, par_all]() {
                 fb->tasks = fTasks.get(); fb->cutoff = cut; fb->fork_levels = levels; fb->par = std::max(1, par_all / 2);
                 fb->split(b1, c1, depth - 1, bad);
             });
@@ -536,9 +535,7 @@ class Builder {
                 NodeVec().swap(t.sub.nodes); RefVec().swap(t.sub.leaf_refs);
             }
         };
-        std::vector<std::thread> pool;
-        for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
-        for (auto &th : pool) th.join();
+        { ThreadGroup pool; for (int t = 0; t < threads; ++t) pool.spawn(worker); pool.join(); }
         stick("copy + free");
     }
 };

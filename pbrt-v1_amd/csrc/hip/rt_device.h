@@ -66,19 +66,20 @@ struct DevScene {
                                // the geometric normal and BSDF tangent are constants of the triangle, precomputed on the host with
                                // the reference's expressions (rt_shade.h tri_frame) instead of two normalisations per vertex
     const uint2 *nodes;
-    const uint2 *tnodes;       // trace kernel (rt_pipeline.h): the same nodes, but a leaf's word 1 is the position (in float4 units) of its
-                               // primitives in `ltris`
+    const uint2 *tnodes;       // the flat traversal round in index form: the same nodes with the leaves in ENTRY form (rt_traverse.h RT_LE_*): word 0 =
+                               // position of the first primitive's record in `ltris` << 2 | 3, word 1 = that entry's flags | the cursor
     const uint4 *tpairs;       // the same tree as sibling PAIRS for the flat traversal round: {below.x, below.y, above.x, above.y}; an interior
-                               // node's word 1 is the index of its children's pair, a leaf's word 1 its position in `ltris`.  Both children
+                               // node's word 1 is the index of its children's pair, a leaf is in entry form as in `tnodes`.  Both children
                                // arrive with ONE 16-byte gather, and because the traversal carries node CONTENTS (in registers and in the
                                // stack entries) instead of indices, a leaf and a popped subtree root need no fetch of their own: gathers per
                                // ray = interior nodes visited, not nodes visited (-44 % at 1 M triangles).  Pairs are stored depth-first.
     unsigned root_x, root_y;   // contents of the root in that encoding
-    unsigned top_pairs, pad_tp;  // the first top_pairs records of tpairs are the owner blocks of the tree's top levels, breadth-first and packed without
+    unsigned top_pairs, leaf_runs;  // leaf_runs: the leaves own runs of consecutive records (tiny scenes; rt_traverse.h RT_LE_*) instead of entries.
+                               // The first top_pairs records of tpairs are the owner blocks of the tree's top levels, breadth-first and packed without
                                // padding (pair_blocks_order; an LDS copy of them was measured and not kept: profiles/r05_lds_top_experiment.patch)
-    const float4 *ltris;       // triangle records in LEAF order: the n primitives of a leaf are n consecutive 48-byte records (p1, e1, e2 as
-                               // in DevTri, the primitive's index in q2.w), placed so that a leaf touches the fewest 128-byte lines: one
-                               // gather fetches what the mesh-order layout needs a leaf-list read plus 1.25 lines per triangle for
+    const float4 *ltris;       // ONE 48-byte record per primitive (p1, e1, e2 as in DevTri, the primitive's index in q2.w), RT_TRI_STRIDE float4 units apart,
+                               // in the order the depth-first leaf walk first meets the primitives (round 6; rounds 2-5: one copy per leaf reference)
+    const unsigned *lrefs;     // entries (position | RT_LE_* flags) of the third and later primitives of the leaves that hold three or more
     const unsigned *leaf_refs;
     const int *tri_shading_idx;      // [n_tris] index into tri_shading or -1 (EXT kernels; null when no mesh has N / S)
     const DevTriShading *tri_shading;

@@ -3,6 +3,7 @@
 #include "../../../include/pbrt_hip.h"
 #include <cstdint>
 #include <memory>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -21,6 +22,17 @@ template <class T> struct NoInitAlloc : std::allocator<T> {
 };
 typedef std::vector<Node, NoInitAlloc<Node>> NodeVec;
 typedef std::vector<uint32_t, NoInitAlloc<uint32_t>> RefVec;
+
+// Worker threads that are joined on EVERY way out of the scope that started them.  A std::thread that is still joinable when it is destroyed calls
+// std::terminate: if starting the k-th worker throws (EAGAIN under thread / ulimit pressure) or an allocation beside the workers throws bad_alloc, the
+// workers already running are joined during unwinding and the exception reaches the C boundary (rt_scene_create / rt_kdtree_build return RT_ENOMEM /
+// RT_ESTATE) instead of ending the process.
+struct ThreadGroup {
+    std::vector<std::thread> th;
+    template <class F, class... A> void spawn(F &&f, A &&...a) { th.emplace_back(std::forward<F>(f), std::forward<A>(a)...); }
+    void join() { for (auto &t : th) if (t.joinable()) t.join(); th.clear(); }
+    ~ThreadGroup() { for (auto &t : th) if (t.joinable()) t.join(); }
+};
 
 struct KdTree {
     NodeVec nodes;

@@ -650,7 +650,7 @@ struct RtScene {
     bool have_timing = false;
     bool counting = true;
     uint32_t n_tris = 0;
-    size_t n_leaf_tri_units = 0;
+    size_t n_leaf_tri_units = 0, n_leaf_entries = 0;
     // queue pipeline (rt_pipeline.h)
     PipePool pool{}; unsigned pool_cap = 0; int pool_vec = 0; PipePool *dev_pool = nullptr;
     unsigned *h_qcount = nullptr;                       // page-locked mirror of pool.q_count (termination test)
@@ -685,89 +685,136 @@ static void host_tri_frame(const float *v, bool flip, float nn[3], float sn[3]) 
     for (int a = 0; a < 3; ++a) sn[a] = dpdu[a] * inv;
 }
 
-// Triangle records in leaf order for the trace kernel (rt_device.h DevScene::ltris / tnodes).  A leaf with n primitives gets n
-// consecutive 48-byte records; its run starts at a 128-byte boundary whenever starting where the previous leaf ended would make
-// it touch more 128-byte lines than necessary (measured: one L2 miss costs the same whether 8 or 128 bytes of the line are used,
-// ~56 G misses/s for the whole chip, and the 1 M-triangle frame makes 17 triangle tests per ray).
-typedef std::vector<float4, NoInitAlloc<float4>> LeafRecords;
-
-// pass 1 (arithmetic only): where every leaf's run starts; returns the array's size in float4 units.  Round 5: the node array is cut into blocks of
-// 2^20 nodes whose runs start on a line boundary, so a block's offsets do not depend on what precedes it: the blocks are laid out by all threads and
-// shifted by a prefix sum over their sizes (the layout depends on the block size, never on the thread count; 245.7 M nodes: 1.24 -> ~0.1 s).
-static size_t leaf_order_offsets(const NodeVec &nodes, NodeVec &tnodes) {
-    tnodes.resize(nodes.size());
-    const size_t B = size_t(1) << 20, nb = (nodes.size() + B - 1) / B;
-    std::vector<size_t> size(nb + 1, 0);
-    auto block = [&](size_t b) {
-        size_t off = 0;                                   // float4 units (16 B) from the block's start; a line is 8 units
-        const size_t hi = std::min(nodes.size(), (b + 1) * B);
-        for (size_t i = b * B; i < hi; ++i) {
-            const Node n = nodes[i];
-            tnodes[i] = n;
-            if ((n.x & 3u) != 3u) continue;
-            const uint32_t np = n.x >> 2;
-            if (np == 0) { tnodes[i].y = 0u; continue; }
-            const size_t units = size_t(np) * 3;
-            const size_t lines_here = (off % 8 + units + 7) / 8, lines_min = (units + 7) / 8;
-            if (lines_here > lines_min) off = (off + 7) / 8 * 8;
-            tnodes[i].y = uint32_t(off);                 // block-local for now
-            off += units;
-        }
-        size[b + 1] = (off + 7) / 8 * 8;
-    };
+// One record per primitive for the flat traversal (rt_device.h DevScene::ltris / lrefs / tnodes; the entry encoding: rt_traverse.h RT_LE_*).
+// Rounds 2-5 kept one 48-byte copy per leaf REFERENCE, a leaf's copies side by side: 25.1 M copies of the benchmark soup's 1 M triangles (1.2 GB;
+// 12 GB at 10 M triangles) that no cache level holds.  Now a primitive has ONE record, placed where the depth-first leaf walk first meets it (so the
+// primitives of neighbouring leaves are neighbours), RT_TRI_STRIDE float4 units apart; a leaf node names its first primitive inline, a leaf of two
+// the second one in its word 1, a larger leaf the index of its remaining entries in `lrefs` (the reference's own form, kdtree.cpp:55-64).
+// `copies` (PBRT_HIP_LEAF_COPIES, measurements only): every reference gets a record of its own again -- the same kernel, the old footprint.
+// `runs`: the leaves own runs of consecutive records and word 1 is the primitive count (DevScene::leaf_runs: rounds 2-5's layout, without the line
+// alignment; what scenes of a few thousand references use -- cache resident, bound by instruction issue, where fetching entries costs 3 %).
+struct LeafLayout {
+    NodeVec tnodes;                       // the nodes with leaves in entry form
+    RefVec lrefs;                         // entries of the third and later primitives of the leaves
+    RefVec slot_prim;                     // record slot -> primitive
+    size_t n_slots = 0;
+};
+static bool leaf_cursor_layout(const NodeVec &nodes, const RefVec &leaf_refs, uint32_t n_tris, bool copies, bool runs, LeafLayout &o) {
+    copies = copies || runs;
+    const size_t N = nodes.size();
+    o.tnodes.resize(N);
+    const size_t B = size_t(1) << 18, nb = (N + B - 1) / B;
     const size_t nthreads = nb < 4 ? 1 : std::min<size_t>(nb, std::max(1u, std::min(64u, std::thread::hardware_concurrency())));
     auto run = [&](auto fn) {
         if (nthreads == 1) { for (size_t b = 0; b < nb; ++b) fn(b); return; }
         std::atomic<size_t> next(0);
-        std::vector<std::thread> pool;
-        for (size_t t = 0; t < nthreads; ++t) pool.emplace_back([&] { for (;;) { const size_t b = next.fetch_add(1); if (b >= nb) return; fn(b); } });
-        for (auto &th : pool) th.join();
+        ThreadGroup pool;
+        for (size_t t = 0; t < nthreads; ++t) pool.spawn([&] { for (;;) { const size_t b = next.fetch_add(1); if (b >= nb) return; fn(b); } });
     };
-    run(block);
-    for (size_t b = 0; b < nb; ++b) size[b + 1] += size[b];
-    if (size[nb] >= (size_t(1) << 32)) return size[nb];   // (refused by the caller; the 32-bit offsets below would wrap)
+    auto leaf_n = [&](const Node &n) -> uint32_t { return (n.x & 3u) == 3u ? n.x >> 2 : 0u; };
+    auto ref = [&](const Node &n, uint32_t np, uint32_t k) -> uint32_t { return np == 1 ? n.y : leaf_refs[n.y + k]; };
+    // pass 1: where the walk first meets every primitive (64-bit key = node << 32 | position in the leaf; minimum over its references)
+    std::unique_ptr<std::atomic<uint64_t>[]> first;
+    if (!copies) {
+        first.reset(new std::atomic<uint64_t>[size_t(n_tris) + 1]);
+        for (size_t i = 0; i <= n_tris; ++i) first[i].store(~0ull, std::memory_order_relaxed);
+        run([&](size_t b) {
+            const size_t hi = std::min(N, (b + 1) * B);
+            for (size_t i = b * B; i < hi; ++i) {
+                const Node n = nodes[i]; const uint32_t np = leaf_n(n);
+                for (uint32_t k = 0; k < np; ++k) {
+                    const uint64_t key = uint64_t(i) << 32 | k;
+                    std::atomic<uint64_t> &f = first[ref(n, np, k)];
+                    uint64_t cur = f.load(std::memory_order_relaxed);
+                    while (key < cur && !f.compare_exchange_weak(cur, key, std::memory_order_relaxed)) {}
+                }
+            }
+        });
+    }
+    // pass 2: per block of nodes, the records it opens and the list entries its leaves of three or more need
+    std::vector<size_t> slots(nb + 1, 0), lists(nb + 1, 0);
     run([&](size_t b) {
-        const size_t base = size[b], hi = std::min(nodes.size(), (b + 1) * B);
-        if (!base) return;
-        for (size_t i = b * B; i < hi; ++i) if ((tnodes[i].x & 3u) == 3u && (tnodes[i].x >> 2)) tnodes[i].y += uint32_t(base);
-    });
-    return size[nb] ? size[nb] : 8;
-}
-// pass 2 on the host (the reference form of rt::derive_leaf_records_kernel below: PBRT_HIP_VERIFY_DERIVED compares the two byte for byte)
-static void leaf_order_fill_host(const NodeVec &nodes, const NodeVec &tnodes, const RefVec &leaf_refs,
-                                 const std::vector<DevTri> &tris, LeafRecords &ltris, size_t units) {
-    ltris.resize(units);
-    std::memset((void *)ltris.data(), 0, units * sizeof(float4));
-    for (size_t i = 0; i < nodes.size(); ++i) {
-        const Node &n = nodes[i];
-        if ((n.x & 3u) != 3u) continue;
-        const uint32_t np = n.x >> 2;
-        float4 *dst = ltris.data() + tnodes[i].y;
-        for (uint32_t k = 0; k < np; ++k) {
-            const uint32_t prim = np == 1 ? n.y : leaf_refs[n.y + k];
-            float4 q2 = tris[prim].q2; std::memcpy(&q2.w, &prim, 4);
-            dst[3 * k] = tris[prim].q0; dst[3 * k + 1] = tris[prim].q1; dst[3 * k + 2] = q2;
+        const size_t hi = std::min(N, (b + 1) * B);
+        size_t ns = 0, nl = 0;
+        for (size_t i = b * B; i < hi; ++i) {
+            const Node n = nodes[i]; const uint32_t np = leaf_n(n);
+            if (np >= 3 && !runs) nl += np - 1;
+            if (copies) ns += np;
+            else for (uint32_t k = 0; k < np; ++k) ns += first[ref(n, np, k)].load(std::memory_order_relaxed) == (uint64_t(i) << 32 | k);
         }
+        slots[b + 1] = ns; lists[b + 1] = nl;
+    });
+    for (size_t b = 0; b < nb; ++b) { slots[b + 1] += slots[b]; lists[b + 1] += lists[b]; }
+    o.n_slots = slots[nb];
+    if (o.n_slots * RT_TRI_STRIDE >= RT_LE_POS || lists[nb] >= RT_LE_POS) return false;
+    o.slot_prim.resize(o.n_slots);
+    o.lrefs.resize(lists[nb] ? lists[nb] : 1);
+    // pass 3: a primitive's slot (the record it shares, or one per reference)
+    std::vector<uint32_t> slot_of;
+    if (!copies) {
+        slot_of.assign(size_t(n_tris) + 1, 0u);
+        run([&](size_t b) {
+            const size_t hi = std::min(N, (b + 1) * B);
+            size_t at = slots[b];
+            for (size_t i = b * B; i < hi; ++i) {
+                const Node n = nodes[i]; const uint32_t np = leaf_n(n);
+                for (uint32_t k = 0; k < np; ++k) {
+                    const uint32_t p = ref(n, np, k);
+                    if (first[p].load(std::memory_order_relaxed) == (uint64_t(i) << 32 | k)) { slot_of[p] = uint32_t(at); o.slot_prim[at++] = p; }
+                }
+            }
+        });
+    }
+    // pass 4: the leaves in entry form
+    run([&](size_t b) {
+        const size_t hi = std::min(N, (b + 1) * B);
+        size_t at = slots[b], lat = lists[b];
+        for (size_t i = b * B; i < hi; ++i) {
+            const Node n = nodes[i];
+            o.tnodes[i] = n;
+            if ((n.x & 3u) != 3u) continue;
+            const uint32_t np = n.x >> 2;
+            if (np == 0) { o.tnodes[i].x = RT_LE_NONE; o.tnodes[i].y = ~RT_LE_POS; continue; }       // entry RT_LE_NONE
+            auto pos = [&](uint32_t k) -> uint32_t {
+                if (copies) { o.slot_prim[at + k] = ref(n, np, k); return uint32_t(at + k) * RT_TRI_STRIDE; }
+                return slot_of[ref(n, np, k)] * RT_TRI_STRIDE;
+            };
+            const uint32_t multi = np > 1 ? RT_LE_MULTI : 0u;
+            o.tnodes[i].x = pos(0) << 2 | 3u;
+            if (runs) { for (uint32_t k = 1; k < np; ++k) pos(k); o.tnodes[i].y = multi | np; }
+            else if (np == 1) o.tnodes[i].y = 0u;
+            else if (np == 2) o.tnodes[i].y = RT_LE_MORE | multi | pos(1);
+            else {
+                o.tnodes[i].y = RT_LE_MORE | RT_LE_LIST | multi | uint32_t(lat);
+                for (uint32_t k = 1; k < np; ++k) o.lrefs[lat++] = pos(k) | (k + 1 < np ? RT_LE_MORE | RT_LE_LIST : 0u);
+            }
+            if (copies) at += np;
+        }
+    });
+    if (lists[nb] == 0) o.lrefs[0] = 0u;
+    return true;
+}
+// the records on the host (the check of rt::derive_leaf_records_kernel below: PBRT_HIP_VERIFY_DERIVED compares the two byte for byte)
+static void leaf_records_fill_host(const RefVec &slot_prim, const std::vector<DevTri> &tris, std::vector<float4> &ltris) {
+    ltris.assign(slot_prim.size() * RT_TRI_STRIDE + 4, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (size_t i = 0; i < slot_prim.size(); ++i) {
+        const uint32_t prim = slot_prim[i];
+        float4 q2 = tris[prim].q2; std::memcpy(&q2.w, &prim, 4);
+        float4 *dst = ltris.data() + i * RT_TRI_STRIDE;
+        dst[0] = tris[prim].q0; dst[1] = tris[prim].q1; dst[2] = q2;
     }
 }
-// pass 2 on the device (round 4): one thread per node copies its leaf's primitives out of the mesh-order records that are in HBM anyway.  The
-// 12 GB of leaf-ordered records of a 10 M-triangle scene were filled by 64 host threads (5.2 s) and uploaded (2.4 s) by every rank; now they
-// never exist on the host.  (The alignment padding between runs is zeroed by a memset before the launch.)
+// ... and on the device: one thread per record copies its primitive out of the mesh-order records that are in HBM anyway (the primitive's index goes
+// into the spare word; the padding was zeroed by a memset before the launch)
 namespace rt {
-__global__ void derive_leaf_records_kernel(const uint2 *__restrict__ nodes, const uint2 *__restrict__ tnodes, const unsigned *__restrict__ leaf_refs,
-                                           const DevTri *__restrict__ tris, float4 *__restrict__ ltris, size_t n_nodes) {
+__global__ void derive_leaf_records_kernel(const unsigned *__restrict__ slot_prim, const DevTri *__restrict__ tris, float4 *__restrict__ ltris, size_t n_slots) {
     const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= n_nodes) return;
-    const uint2 n = nodes[i];
-    if ((n.x & 3u) != 3u) return;
-    const unsigned np = n.x >> 2;
-    float4 *dst = ltris + tnodes[i].y;
-    for (unsigned k = 0; k < np; ++k) {
-        const unsigned prim = np == 1u ? n.y : leaf_refs[n.y + k];
-        const DevTri t = tris[prim];
-        float4 q2 = t.q2; q2.w = __uint_as_float(prim);
-        dst[3 * k] = t.q0; dst[3 * k + 1] = t.q1; dst[3 * k + 2] = q2;
-    }
+    if (i >= n_slots) return;
+    const unsigned prim = slot_prim[i];
+    const DevTri t = tris[prim];
+    float4 q2 = t.q2; q2.w = __uint_as_float(prim);
+    float4 *dst = ltris + i * RT_TRI_STRIDE;
+    dst[0] = t.q0; dst[1] = t.q1; dst[2] = q2;
 }
 }  // namespace rt
 
@@ -805,7 +852,7 @@ static void host_tri_frame_uv(const float *v, const float *uv, bool flip, float 
 // the interior grandchildren of an owner; the nodes in between are "members" of their parent's block (flags 0: when a member is reached
 // through a pop it takes a one-level step).  Blocks are emitted depth-first, the below side first, so a subtree stays contiguous.
 // Two phases: pair_blocks_order() decides where every pair goes (a sequential depth-first walk that looks at the tree's SHAPE only, so it runs
-// beside leaf_order_offsets on another thread), pair_blocks_fill() writes the records (needs the leaves' positions in ltris; 64 threads).
+// beside leaf_cursor_layout on another thread), pair_blocks_fill() writes the records (needs the leaves in entry form; 64 threads).
 // Round 5: the blocks of the tree's TOP levels come first, breadth-first (owner level by owner level, below side first) and packed without
 // padding, RT_TOP_PREFIX records at most (any prefix of the array is "the topmost blocks": what an LDS copy would want -- measured, not kept,
 // profiles/r05_lds_top_scan.txt -- and what every ray walks sits in 64 KB).  The subtrees below that frontier follow depth-first in 64-byte-aligned blocks as before.
@@ -860,9 +907,8 @@ static void pair_blocks_order(const NodeVec &tn, PairBlockOrder &o) {
     auto run = [&](auto fn) {
         if (nthreads == 1) { for (size_t k = 0; k < roots.size(); ++k) fn(k); return; }
         std::atomic<size_t> next(0);
-        std::vector<std::thread> pool;
-        for (size_t t = 0; t < nthreads; ++t) pool.emplace_back([&] { for (;;) { const size_t k = next.fetch_add(1); if (k >= roots.size()) return; fn(k); } });
-        for (auto &th : pool) th.join();
+        ThreadGroup pool;
+        for (size_t t = 0; t < nthreads; ++t) pool.spawn([&] { for (;;) { const size_t k = next.fetch_add(1); if (k >= roots.size()) return; fn(k); } });
     };
     run([&](size_t k) {
         std::vector<uint32_t> &ord = sub[k], todo{roots[k]};
@@ -879,7 +925,7 @@ static void pair_blocks_order(const NodeVec &tn, PairBlockOrder &o) {
         std::vector<uint32_t>().swap(sub[k]);
     });
 }
-// `tn`: the nodes with a leaf's word 1 = its position in ltris (interior nodes as in the tree: same shape as pair_blocks_order saw)
+// `tn`: the nodes with the leaves in entry form (LeafLayout::tnodes; interior nodes as in the tree: same shape as pair_blocks_order saw)
 static void pair_blocks_fill(const NodeVec &tn, const PairBlockOrder &o, std::vector<uint4> &pairs, uint32_t &root_x, uint32_t &root_y) {
     pairs.clear();
     if (tn.empty()) { root_x = 3u; root_y = 0u; pairs.push_back(make_uint4(3u, 0u, 3u, 0u)); return; }
@@ -889,7 +935,7 @@ static void pair_blocks_fill(const NodeVec &tn, const PairBlockOrder &o, std::ve
     if (order.size() >= (size_t(1) << 30)) return;
     auto interior = [&](uint32_t n) { return (tn[n].x & 3u) != 3u; };
     auto word1 = [&](uint32_t n) -> uint32_t {
-        if (!interior(n)) return tn[n].y;                                     // leaf: position of its primitives in ltris
+        if (!interior(n)) return tn[n].y;                                     // leaf: flags of its first entry | cursor
         uint32_t y = o.pos[n];
         if (o.owner[n]) y |= (interior(n + 1u) ? 1u << 30 : 0u) | (interior(tn[n].y) ? 1u << 31 : 0u);
         return y;
@@ -906,9 +952,8 @@ static void pair_blocks_fill(const NodeVec &tn, const PairBlockOrder &o, std::ve
     const size_t nthreads = order.size() < (size_t(1) << 20) ? 1 : std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
     if (nthreads == 1) fill(0, order.size());
     else {
-        std::vector<std::thread> pool;
-        for (size_t t = 0; t < nthreads; ++t) pool.emplace_back(fill, order.size() * t / nthreads, order.size() * (t + 1) / nthreads);
-        for (auto &th : pool) th.join();
+        ThreadGroup pool;
+        for (size_t t = 0; t < nthreads; ++t) pool.spawn(fill, order.size() * t / nthreads, order.size() * (t + 1) / nthreads);
     }
     root_y = word1(0u);
 }
@@ -1064,6 +1109,14 @@ static int render_pipeline(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, int
 static void fill_info(const KdTree &tree, const GridAccelData &g, int kind, uint32_t n_tris, RtAccelInfo *info);
 extern "C" int rt_scene_destroy(RtScene *s);
 
+// No C++ exception crosses the C boundary: the host builders allocate gigabytes and start worker threads (every group of them is joined while the
+// exception unwinds, rt_internal.h ThreadGroup), so bad_alloc / a failed thread start end in a status code, not in std::terminate.
+template <class F> static int guarded(const char *what, F &&f) {
+    try { return f(); }
+    catch (const std::bad_alloc &) { return fail(RT_ENOMEM, std::string(what) + ": out of host memory"); }
+    catch (const std::exception &e) { return fail(RT_ESTATE, std::string(what) + ": " + e.what()); }
+}
+
 extern "C" {
 
 const char *rt_last_error(void) { return g_err.c_str(); }
@@ -1120,13 +1173,13 @@ static int check_prebuilt(const RtPrebuiltAccel *a, uint32_t n_tris) {
 }
 
 static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel *pre, RtScene **out);
-int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) { return scene_create(d, device, nullptr, out); }
+int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) { return guarded("rt_scene_create", [&] { return scene_create(d, device, nullptr, out); }); }
 // The same scene with the accelerator somebody else built (rt_accel_build / rt_scene_accel_copy of another rank's scene): the ranks of one
 // node build the kd-tree ONCE (10 M triangles: 15 s on all host cores) instead of once per process.  The arrays are the canonical flattened
 // tree (pbrt_hip.h RtAccelInfo / rt_accel_copy); everything the device derives from them (leaf-ordered records, pair blocks) is rebuilt here.
 int rt_scene_create_prebuilt(const RtSceneDesc *d, int device, const RtPrebuiltAccel *pre, RtScene **out) {
     if (!pre) return fail(RT_EINVAL, "rt_scene_create_prebuilt: null accelerator");
-    return scene_create(d, device, pre, out);
+    return guarded("rt_scene_create_prebuilt", [&] { return scene_create(d, device, pre, out); });
 }
 static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel *pre, RtScene **out) {
     if (!d || !out) return fail(RT_EINVAL, "rt_scene_create: null argument");
@@ -1282,32 +1335,41 @@ static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel 
     s->dev.nodes = nodes_dev;
     s->dev.tnodes = nodes_dev;
     if (s->accel_kind == RT_ACCEL_KDTREE) {
-        NodeVec tn;
+        LeafLayout ll;
         tick("node / leaf-list upload");
-        const size_t units = leaf_order_offsets(s->tree.nodes, tn);
-        tick("leaf-order offsets");
-        if (units >= (size_t(1) << 32)) return fail(RT_EINVAL, "rt_scene_create: leaf-ordered triangle array beyond 2^32 float4 units");
+        // runs of consecutive records per leaf for scenes of a few thousand references (C2's 14 triangles: cache resident, bound by instruction issue -- the entry
+        // form costs it 2.8 %, profiles/r06_dedup_scan.txt); everything larger shares one record per primitive
+        bool runs = s->tree.leaf_refs.size() + s->tree.nodes.size() / 2 <= 32768;
+        if (const char *e = knob("PBRT_HIP_LEAF_RUNS")) runs = std::atoi(e) != 0;
+        if (!leaf_cursor_layout(s->tree.nodes, s->tree.leaf_refs, d->n_tris, knob("PBRT_HIP_LEAF_COPIES") != nullptr, runs, ll))
+            return fail(RT_EINVAL, "rt_scene_create: primitive records or leaf entries beyond 2^29");
+        s->dev.leaf_runs = runs ? 1u : 0u;
+        const NodeVec &tn = ll.tnodes;
+        tick("leaf entries");
         if ((rc = upload_nodes(tn, &s->dev.tnodes))) return rc;
+        if ((rc = upload(s, ll.lrefs.data(), ll.lrefs.size(), &s->dev.lrefs))) return rc;
         {
+            const unsigned *slot_prim_dev = nullptr;
+            if ((rc = upload(s, ll.slot_prim.data(), ll.slot_prim.size(), &slot_prim_dev))) return rc;
+            const size_t units = ll.n_slots * RT_TRI_STRIDE + 4;            // (+ one record of padding: a lane without a primitive never loads, but the array is never empty)
             void *p = nullptr;
             HIPCHK(hipMalloc(&p, units * sizeof(float4)));
             s->allocs.push_back(p);
             s->dev.ltris = (const float4 *)p;
             HIPCHK(hipMemsetAsync(p, 0, units * sizeof(float4), s->stream));
-            const size_t nn = s->tree.nodes.size();
-            if (nn) hipLaunchKernelGGL(derive_leaf_records_kernel, dim3(unsigned((nn + 255) / 256)), dim3(256), 0, s->stream, s->dev.nodes, s->dev.tnodes,
-                                       s->dev.leaf_refs, (const DevTri *)s->dev.tris, (float4 *)p, nn);
+            if (ll.n_slots) hipLaunchKernelGGL(derive_leaf_records_kernel, dim3(unsigned((ll.n_slots + 255) / 256)), dim3(256), 0, s->stream, slot_prim_dev,
+                                               (const DevTri *)s->dev.tris, (float4 *)p, ll.n_slots);
             HIPCHK(hipGetLastError());
             if (knob("PBRT_HIP_VERIFY_DERIVED")) {             // tests: the device fill against the host fill, byte for byte
-                LeafRecords lt; leaf_order_fill_host(s->tree.nodes, tn, s->tree.leaf_refs, tris, lt, units);
-                std::vector<float4> back(units);
+                std::vector<float4> lt, back(units); leaf_records_fill_host(ll.slot_prim, tris, lt);
                 HIPCHK(hipStreamSynchronize(s->stream));
                 HIPCHK(hipMemcpy(back.data(), p, units * sizeof(float4), hipMemcpyDeviceToHost));
-                if (std::memcmp(back.data(), lt.data(), units * sizeof(float4)) != 0) return fail(RT_ESTATE, "rt_scene_create: the device-built leaf-ordered records differ from the host fill");
+                if (lt.size() != units || std::memcmp(back.data(), lt.data(), units * sizeof(float4)) != 0) return fail(RT_ESTATE, "rt_scene_create: the device-built primitive records differ from the host fill");
             }
+            s->n_leaf_tri_units = units;
+            s->n_leaf_entries = ll.lrefs.size();
         }
-        s->n_leaf_tri_units = units;
-        tick("leaf-ordered records (device)");
+        tick("primitive records (device)");
         std::vector<uint4> pairs;
         order_thread.join();
         pair_blocks_fill(tn, pbo, pairs, s->dev.root_x, s->dev.root_y);
@@ -1520,14 +1582,16 @@ int rt_accel_build(const float *tri_verts, uint32_t n_tris, const RtAccelParams 
     if (!out || (n_tris && !tri_verts)) return fail(RT_EINVAL, "rt_accel_build: null argument");
     RtAccelParams p; std::memset(&p, 0, sizeof p);
     if (params) p = *params;
-    RtKdTree *t = new RtKdTree(); t->n_tris = n_tris; t->kind = p.kind;
-    if (p.kind == RT_ACCEL_GRID) {
-        build_grid(tri_verts, n_tris, t->grid);
-        t->tree.nodes = t->grid.voxels; t->tree.leaf_refs = t->grid.refs; t->tree.max_depth = 0;
-        std::memcpy(t->tree.bounds, t->grid.bounds, sizeof t->tree.bounds); t->tree.build_seconds = t->grid.build_seconds;
-    } else if (p.kind == RT_ACCEL_KDTREE) build_kdtree(tri_verts, n_tris, p, t->tree);
-    else { delete t; return fail(RT_EINVAL, "rt_accel_build: unknown accelerator kind"); }
-    *out = t; return RT_OK;
+    if (p.kind != RT_ACCEL_GRID && p.kind != RT_ACCEL_KDTREE) return fail(RT_EINVAL, "rt_accel_build: unknown accelerator kind");
+    return guarded("rt_accel_build", [&] {
+        std::unique_ptr<RtKdTree> t(new RtKdTree()); t->n_tris = n_tris; t->kind = p.kind;
+        if (p.kind == RT_ACCEL_GRID) {
+            build_grid(tri_verts, n_tris, t->grid);
+            t->tree.nodes = t->grid.voxels; t->tree.leaf_refs = t->grid.refs; t->tree.max_depth = 0;
+            std::memcpy(t->tree.bounds, t->grid.bounds, sizeof t->tree.bounds); t->tree.build_seconds = t->grid.build_seconds;
+        } else build_kdtree(tri_verts, n_tris, p, t->tree);
+        *out = t.release(); return RT_OK;
+    });
 }
 int rt_accel_info(const RtAccel *t, RtAccelInfo *info) {
     if (!t || !info) return fail(RT_EINVAL, "null argument");
@@ -1641,7 +1705,10 @@ static int make_frame(RtScene *s, const RtRenderDesc *rd, DevFrame &fr, bool nee
         if (!s->light_dims || up.size() != tab.size() || std::memcmp(up.data(), tab.data(), tab.size() * sizeof(DimReq)) != 0) {
             int rc = ensure(s, &s->light_dims, &s->light_dims_cap, tab.size()); if (rc) return rc;
             up.swap(tab);
-            HIPCHK(hipMemcpyAsync(s->light_dims, up.data(), up.size() * sizeof(DimReq), hipMemcpyHostToDevice, s->stream));
+            // rt_render is asynchronous: a frame queued earlier may still be reading the table, and the source is pageable host memory that the next make_frame
+            // may swap away -- wait for the stream, then copy synchronously (36 bytes per light; only when a frame asks for other requests than the last one)
+            HIPCHK(hipStreamSynchronize(s->stream));
+            HIPCHK(hipMemcpy(s->light_dims, up.data(), up.size() * sizeof(DimReq), hipMemcpyHostToDevice));
         }
         fr.light_dims = s->light_dims;
         d1.erase(d1.begin(), d1.begin() + nl);              // what stays in the descriptor: the volume integrator's two 1-D requests

@@ -25,6 +25,27 @@
 #ifndef RT_BLOCK
 #define RT_BLOCK 256
 #endif
+// ---- the leaf cursor of the flat traversal (round 6: ONE record per primitive) ------------------------------------------------------------
+// DevScene::ltris holds one record per distinct primitive, in the order the depth-first leaf walk first meets them (RT_TRI_STRIDE float4 units
+// apart), instead of one 48-byte copy per leaf REFERENCE (25.1 M copies of 1 M triangles = 1.2 GB on the benchmark soup, 12 GB at 10 M triangles;
+// the reference itself keeps indices, kdtree.cpp:55-64).  A leaf's primitives are walked through "entries" = position | flags:
+//   RT_LE_MORE   another primitive follows this one,
+//   RT_LE_LIST   ... and its entry is read from DevScene::lrefs at the cursor (otherwise the cursor itself is that entry: leaves of two),
+//   RT_LE_MULTI  (word 1 of the leaf node only) the leaf has more than one primitive: the reference walks its list there (the leaf_refs counter).
+// A leaf node carries its FIRST entry inline -- word 0 = position << 2 | 3, the entry's flags in the top three bits of word 1 -- and in the low
+// 29 bits of word 1 the cursor: the second entry (leaves of two: 72 % of the soup's leaf references sit in leaves of one or two and need no
+// index fetch at all) or the index of the leaf's remaining entries in `lrefs`, which are requested TOGETHER with the record of the primitive
+// before them, so no test waits for two dependent round trips.  An empty leaf has the entry RT_LE_NONE.
+// DevScene::leaf_runs (scenes of a few thousand references: everything is cache resident and the kernel is bound by instruction issue): every leaf owns a
+// run of consecutive records instead -- word 1 = the number of primitives, the cursor counts down, no entry is ever fetched.
+#ifndef RT_TRI_STRIDE
+#define RT_TRI_STRIDE 4           // float4 units between two records: 4 = a 48-byte record never straddles two 64-byte sectors / 128-byte lines
+#endif
+#define RT_LE_MORE 0x80000000u
+#define RT_LE_LIST 0x40000000u
+#define RT_LE_MULTI 0x20000000u
+#define RT_LE_POS 0x1fffffffu
+#define RT_LE_NONE 0xffffffffu
 // Per-lane 4-entry mailbox window: measured SLOWER on MI355X (C2 92.9 vs 87.8 ms, 100k-soup path 169 vs 165 ms): the
 // four compares + rotates per candidate cost more VALU than the avoided re-tests save.  Kept as a compile-time knob.
 
@@ -47,7 +68,8 @@ struct Trav {
     unsigned cx, cy;               // sibling-pair form (kdp_step): the CONTENTS of the current node instead of its index
     float tmin, tmax;
     int sp, sbase;                 // todo stack: entries [sbase, sp) live in the LDS ring, [0, sbase) in HBM
-    // leaf / voxel primitive-list cursor for the lock-step ("while-while") traversal: at_leaf => test prims [li, ln)
+    // leaf / voxel primitive-list cursor for the lock-step ("while-while") traversal: at_leaf => test prims [li, ln) of the list at ly;
+    // in the flat traversal (one record per primitive, see RT_LE_*): ly = the entry of the primitive to test next, ln_ = the cursor, li unused
     unsigned li, ln_, ly;
     bool at_leaf;
     // grid 3D-DDA cursor (grid.cpp:238-260): voxel position and the ray parameter of the next crossing per axis
@@ -470,6 +492,13 @@ RT_DEV void accel_round_pooled(Trav &tv, bool mine, const DevScene &sc, uint2 RT
 #define RT_TRACE_LEAF_MIN 24      // keep testing primitives while at least this many lanes have one left (the megakernel takes DevFrame::leaf_min: 8 on tiny trees)
 #endif
 
+// entering a leaf of the flat traversal: its first entry and the cursor from the leaf node's two words (encoding: RT_LE_* above)
+RT_DEV void leaf_cursor_enter(Trav &tv, bool enter, unsigned wx, unsigned wy) {
+    tv.ly = enter ? ((wx >> 2) | (wy & ~(RT_LE_POS | RT_LE_MULTI))) : tv.ly;
+    tv.ln_ = enter ? (wy & RT_LE_POS) : tv.ln_;
+    tv.li = enter ? (wy & RT_LE_MULTI) : tv.li;             // read by the counting twins only (the reference walks a list there: leaf_refs); dead elsewhere
+}
+
 // ---- the trace kernel's own traversal steps ------------------------------------------------------------------------------
 // Same semantics as kd_descend / leaf_test_one / kd_leaf_done of rt_traverse.h (KdTreeAccel::Intersect / IntersectP,
 // kdtree.cpp:313-488; Triangle::Intersect, trianglemesh.cpp:213-246), written as straight-line code with selects: every
@@ -500,23 +529,39 @@ RT_DEV void kd_step_flat(Trav &tv, bool desc, const DevScene &sc, uint2 RT_L *ld
     tv.tmax = both ? tplane : tv.tmax;
     const bool enter = go && leaf;
     tv.at_leaf = enter ? true : tv.at_leaf;
-    tv.li = enter ? 0u : tv.li;
-    tv.ln_ = enter ? (nd.x >> 2) : tv.ln_;
-    tv.ly = enter ? nd.y : tv.ly;
+    if (LEAF_ORDER) leaf_cursor_enter(tv, enter, nd.x, nd.y);
+    else {
+        tv.li = enter ? 0u : tv.li;
+        tv.ln_ = enter ? (nd.x >> 2) : tv.ln_;
+        tv.ly = enter ? nd.y : tv.ly;
+    }
     tv.active = dead ? false : tv.active;
 }
 template <bool COUNT>
 RT_DEV void leaf_test_flat(Trav &tv, bool leafw, const DevScene &sc, TravCounters &cnt) {
-    // leaf-ordered records (DevScene::ltris): primitive li of this leaf sits 3 * li float4s behind the leaf's first
-    const bool single = tv.ln_ == 1u;
+    // one record per primitive (DevScene::ltris) at the position the lane's current entry names
+    const unsigned cur = tv.ly;
     float4 q0, q1, q2; undef_f4(q0); undef_f4(q1); undef_f4(q2);
     if (leafw) {
-        const float4 RT_G *gt = RT_GPTR(const float4, sc.ltris) + (size_t(tv.ly) + 3u * tv.li);
+        const float4 RT_G *gt = RT_GPTR(const float4, sc.ltris) + (cur & RT_LE_POS);
         q0 = gt[0]; q1 = gt[1]; q2 = gt[2];
     }
+    if (sc.leaf_runs) {
+        // tiny scenes (scene-uniform, a scalar branch): every leaf owns a run of consecutive records, the cursor counts what is left of it
+        const unsigned nxt = tv.ln_ > 1u ? cur + RT_TRI_STRIDE : RT_LE_NONE;
+        tv.ly = leafw ? nxt : tv.ly;
+        tv.ln_ -= leafw ? 1u : 0u;
+    } else {
+        // a leaf of three or more asks for the entry of its NEXT primitive in the same batch of loads
+        const bool list = leafw && cur >= (RT_LE_MORE | RT_LE_LIST);                 // (leafw: cur is not RT_LE_NONE)
+        unsigned nx; asm("" : "=v"(nx));
+        if (list) nx = RT_GPTR(const unsigned, sc.lrefs)[tv.ln_];
+        const unsigned nxt = list ? nx : (int(cur) < 0 ? tv.ln_ : RT_LE_NONE);   // (a leaf of two: the cursor is the second entry)
+        tv.ly = leafw ? nxt : tv.ly;
+        tv.ln_ += list ? 1u : 0u;
+    }
     const unsigned prim = __float_as_uint(q2.w);
-    if (COUNT) { cnt.tris += leafw ? 1u : 0u; cnt.leaf_refs += (leafw && !single) ? 1u : 0u; }
-    tv.li += leafw ? 1u : 0u;
+    if (COUNT) { cnt.tris += leafw ? 1u : 0u; cnt.leaf_refs += (leafw && tv.li != 0u) ? 1u : 0u; }      // tv.li (counting twins only): the leaf has more than one primitive
     const V3 p1 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
     const V3 s1 = cross3(tv.d, e2);
     const float divisor = dot3(s1, e1);
@@ -626,9 +671,7 @@ RT_DEV void kdp_step(Trav &tv, bool desc, const DevScene &sc, PairStack st, unsi
     const bool enter = go && (tv.cx & 3u) == 3u;
     if (COUNT) cnt.nodes += (interior && enter) ? 1u : 0u;
     tv.at_leaf = enter ? true : tv.at_leaf;
-    tv.li = enter ? 0u : tv.li;
-    tv.ln_ = enter ? (tv.cx >> 2) : tv.ln_;
-    tv.ly = enter ? tv.cy : tv.ly;
+    leaf_cursor_enter(tv, enter, tv.cx, tv.cy);
 }
 template <bool COUNT, int NS>
 RT_DEV void kdp_pop(Trav &tv, bool done, PairStack st, unsigned n_threads, unsigned gtid, TravCounters &cnt) {
@@ -651,9 +694,7 @@ RT_DEV void kdp_pop(Trav &tv, bool done, PairStack st, unsigned n_threads, unsig
     const bool enter = pop && !dead && (ex & 3u) == 3u;
     if (COUNT) cnt.nodes += enter ? 1u : 0u;
     tv.at_leaf = done ? enter : tv.at_leaf;
-    tv.li = enter ? 0u : tv.li;
-    tv.ln_ = enter ? (ex >> 2) : tv.ln_;
-    tv.ly = enter ? ey : tv.ly;
+    leaf_cursor_enter(tv, enter, ex, ey);
     tv.active = (done && (!pop || dead)) ? false : tv.active;
 }
 
@@ -661,6 +702,7 @@ template <bool COUNT, int ACCEL, bool EXT, int NS, bool PAIRS_OK = true, int DST
 RT_DEV void trace_round(Trav &tv, bool busy, const DevScene &sc, uint2 RT_L *lds_stack, float RT_L *lds_tm, uint2 RT_G *spill, unsigned n_threads, unsigned gtid, TravCounters &cnt,
                         int leaf_min = RT_TRACE_LEAF_MIN) {
     constexpr bool PAIRS = PAIRS_OK && ACCEL != RT_ACCEL_GRID && !EXT;
+    constexpr bool CURSOR = ACCEL != RT_ACCEL_GRID && !EXT;                    // the leaf cursor walks entries (one record per primitive), not [li, ln)
     const PairStack pst = {lds_stack, lds_tm, (uint4 RT_G *)spill};
     if (ACCEL == RT_ACCEL_GRID) {
         if (busy && tv.active && !tv.at_leaf) grid_enter_voxel<COUNT>(tv, sc, cnt);
@@ -681,14 +723,14 @@ RT_DEV void trace_round(Trav &tv, bool busy, const DevScene &sc, uint2 RT_L *lds
     }
 #pragma unroll 1
     for (;;) {
-        const bool leafw = busy && tv.active && tv.at_leaf && tv.li < tv.ln_;
+        const bool leafw = busy && tv.active && tv.at_leaf && (CURSOR ? tv.ly != RT_LE_NONE : tv.li < tv.ln_);
         const int nl = __popcll(__ballot(leafw));
         if (nl == 0) break;
         if (ACCEL == RT_ACCEL_GRID || EXT) { if (leafw) leaf_test_one<COUNT, ACCEL == RT_ACCEL_GRID, EXT>(tv, sc, cnt); }
         else leaf_test_flat<COUNT>(tv, leafw, sc, cnt);
         if (nl < leaf_min) break;
     }
-    const bool done = busy && tv.active && tv.at_leaf && tv.li >= tv.ln_;
+    const bool done = busy && tv.active && tv.at_leaf && (CURSOR ? tv.ly == RT_LE_NONE : tv.li >= tv.ln_);
     if (ACCEL == RT_ACCEL_GRID) { if (done) grid_voxel_done(tv, sc); }
     else if (PAIRS) { if (__any(done)) kdp_pop<COUNT, NS>(tv, done, pst, n_threads, gtid, cnt); }
     else kd_pop_flat<NS>(tv, done, lds_stack, spill, n_threads, gtid);
