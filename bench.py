@@ -51,7 +51,7 @@ HEADLINE = "c3"
 # SAME frame on the tree these parameters give (closest hits do not depend on the tree: tests/test_gpu_configs.py::test_tuned_tree_gives_the_same_film) and their
 # reference-CPU leg runs the same text.  Chosen by tools/kd_param_scan.py on the MI355X (profiles/r06_kd_param_scan.txt).
 TUNED_ACCEL = os.environ.get("PBRT_BENCH_TUNED_ACCEL") or \
-    '"integer intersectcost" [%d] "integer traversalcost" [%d] "float emptybonus" [%s] "integer maxprims" [%d]' % (8, 1, "0.5", 2)
+    '"integer intersectcost" [%d] "integer traversalcost" [%d] "float emptybonus" [%s] "integer maxprims" [%d]' % (2, 1, "0", 4)
 
 
 def workload(name: str):
@@ -279,8 +279,13 @@ def run_workload(name, args, pkg, torch, dist, world, rank, device_index, steps,
                     break
                 except OSError as e:
                     print("bench.py: cannot publish the accelerator under %s (%s)" % (d, e), file=sys.stderr, flush=True)
-        dist.broadcast_object_list(where, src=0)                          # (one node: rank 0 is local rank 0)
-        shared = where[0]
+        # every node's local rank 0 publishes on its own (it may have chosen another directory than global rank 0, or failed): a rank takes the path of ITS
+        # node's local rank 0, never one that exists only on another host
+        import socket
+        mine = (socket.gethostname(), local_rank, where[0])
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        shared = next((p for h, lr, p in everyone if h == mine[0] and lr == 0), None)
         if local_rank != 0:
             ds = pkg.DeviceScene(ps, device=device_index, prebuilt=pkg.attach_accel(shared)) if shared else pkg.DeviceScene(ps, device=device_index)
         dist.barrier()

@@ -166,7 +166,11 @@ enum { RT_STRATEGY_ALL = 0, RT_STRATEGY_ONE = 1, RT_STRATEGY_WEIGHTED = 2 };
  * untouched then (the count pass writes neither), rt_last_render_stats / rt_samples_read report "no frame".  In a participating medium the
  * strategy needs lights that draw no random numbers at all (delta lights, single-triangle / quadric emitters): the medium makes an estimate's
  * draws depend on occlusion, and an emitter of several triangles would draw its triangle from a different place in the stream than the
- * survey did -- refused. */
+ * survey did -- refused.
+ * Cost and limit with lights of mixed RNG use: a camera sample with P shading points keeps P (1 + 2 (nLights - nD)) + nD P (P + 1) floats of survey records
+ * (nD = emitters of several triangles) -- QUADRATIC in P, i.e. in the depth of the specular recursion -- capped at 2^32 floats per frame (refused after the
+ * count pass, as above), and the recurrence itself is sequential by definition: one lane walks every shading point of the frame in program order (~0.45 us per
+ * point on MI355X; the reference pays the same dependence on one core).  High maxdepth with many such emitters is therefore slow or refused, never wrong. */
 enum { RT_VOLUME_NONE = 0, RT_VOLUME_EMISSION = 1, RT_VOLUME_SINGLE = 2 };
 enum { RT_SAMPLER_STRATIFIED = 0, RT_SAMPLER_LOWDISCREPANCY = 1, RT_SAMPLER_RANDOM = 2 };
 

@@ -738,7 +738,7 @@ static bool leaf_cursor_layout(const NodeVec &nodes, const RefVec &leaf_refs, ui
         size_t ns = 0, nl = 0;
         for (size_t i = b * B; i < hi; ++i) {
             const Node n = nodes[i]; const uint32_t np = leaf_n(n);
-            if (np >= 3 && !runs) nl += np - 1;
+            if (np >= 3 && !runs) nl += (np - 1 + 1) & ~size_t(1);            // lists start at even indices (the cursor is stored halved)
             if (copies) ns += np;
             else for (uint32_t k = 0; k < np; ++k) ns += first[ref(n, np, k)].load(std::memory_order_relaxed) == (uint64_t(i) << 32 | k);
         }
@@ -746,7 +746,7 @@ static bool leaf_cursor_layout(const NodeVec &nodes, const RefVec &leaf_refs, ui
     });
     for (size_t b = 0; b < nb; ++b) { slots[b + 1] += slots[b]; lists[b + 1] += lists[b]; }
     o.n_slots = slots[nb];
-    if (o.n_slots * RT_TRI_STRIDE >= RT_LE_POS || lists[nb] >= RT_LE_POS) return false;
+    if (o.n_slots * RT_TRI_STRIDE >= RT_LE_POS || lists[nb] / 2 >= RT_LE_POS) return false;
     o.slot_prim.resize(o.n_slots);
     o.lrefs.resize(lists[nb] ? lists[nb] : 1);
     // pass 3: a primitive's slot (the record it shares, or one per reference)
@@ -774,19 +774,19 @@ static bool leaf_cursor_layout(const NodeVec &nodes, const RefVec &leaf_refs, ui
             o.tnodes[i] = n;
             if ((n.x & 3u) != 3u) continue;
             const uint32_t np = n.x >> 2;
-            if (np == 0) { o.tnodes[i].x = RT_LE_NONE; o.tnodes[i].y = ~RT_LE_POS; continue; }       // entry RT_LE_NONE
+            if (np == 0) { o.tnodes[i].x = RT_LE_NONE; o.tnodes[i].y = ~RT_LE_POS; continue; }       // entry RT_LE_NONE (runs: + a count that is never read)
             auto pos = [&](uint32_t k) -> uint32_t {
                 if (copies) { o.slot_prim[at + k] = ref(n, np, k); return uint32_t(at + k) * RT_TRI_STRIDE; }
                 return slot_of[ref(n, np, k)] * RT_TRI_STRIDE;
             };
-            const uint32_t multi = np > 1 ? RT_LE_MULTI : 0u;
             o.tnodes[i].x = pos(0) << 2 | 3u;
-            if (runs) { for (uint32_t k = 1; k < np; ++k) pos(k); o.tnodes[i].y = multi | np; }
+            if (runs) { for (uint32_t k = 1; k < np; ++k) pos(k); o.tnodes[i].y = (np > 1 ? RT_LE_MORE : 0u) | np; }
             else if (np == 1) o.tnodes[i].y = 0u;
-            else if (np == 2) o.tnodes[i].y = RT_LE_MORE | multi | pos(1);
+            else if (np == 2) o.tnodes[i].y = RT_LE_MORE | pos(1);
             else {
-                o.tnodes[i].y = RT_LE_MORE | RT_LE_LIST | multi | uint32_t(lat);
+                o.tnodes[i].y = RT_LE_MORE | RT_LE_LIST | uint32_t(lat / 2);
                 for (uint32_t k = 1; k < np; ++k) o.lrefs[lat++] = pos(k) | (k + 1 < np ? RT_LE_MORE | RT_LE_LIST : 0u);
+                if (lat & 1) o.lrefs[lat++] = RT_LE_NONE;                          // padding, never read
             }
             if (copies) at += np;
         }
@@ -957,6 +957,68 @@ static void pair_blocks_fill(const NodeVec &tn, const PairBlockOrder &o, std::ve
     }
     root_y = word1(0u);
 }
+
+#if RT_KD3
+// Three tree levels per 64-byte block (rt_traverse.h kd3_step).  `nodes` = the tree as built (leaf sizes), `tn` = the same nodes with the leaves in entry form.
+// Blocks are numbered depth-first (a block, then the blocks behind its links, below side first), so a subtree stays contiguous.
+struct Kd3Layout { std::vector<uint32_t> blocks; std::vector<Node> ldesc; uint32_t root_x = 3u, root_y = 0u; };
+static bool kd3_layout(const NodeVec &nodes, const NodeVec &tn, Kd3Layout &o) {
+    o.blocks.clear(); o.ldesc.clear();
+    auto interior = [&](uint32_t n) { return (nodes[n].x & 3u) != 3u; };
+    bool ok = true;
+    auto leaf_code = [&](uint32_t n) -> uint32_t {
+        const uint32_t np = nodes[n].x >> 2;
+        if (np == 0) return 3u;
+        if (np == 1) { const uint32_t rec = (tn[n].x >> 2) / RT_TRI_STRIDE; if (rec >= (1u << 28)) ok = false; return 3u | rec << 2 | 1u << 30; }
+        const size_t d = o.ldesc.size(); if (d >= (size_t(1) << 28)) ok = false;
+        o.ldesc.push_back(tn[n]);
+        return 3u | uint32_t(d) << 2 | 3u << 30;
+    };
+    if (nodes.empty()) { o.blocks.assign(16, 3u); return true; }
+    if (!interior(0)) { o.root_x = leaf_code(0); o.blocks.assign(16, 3u); o.ldesc.push_back(Node{RT_LE_NONE, ~RT_LE_POS}); return ok; }
+    o.root_x = 0u; o.root_y = 0u;
+    struct Todo { uint32_t node, block; };
+    std::vector<Todo> todo;
+    o.blocks.assign(16, 3u);
+    todo.push_back(Todo{0u, 0u});
+    while (!todo.empty()) {
+        const Todo t = todo.back(); todo.pop_back();
+        uint32_t slot_node[7]; bool have[7] = {true, false, false, false, false, false, false};
+        slot_node[0] = t.node;
+        uint32_t links[8]; bool link_interior[8];
+        for (int k = 0; k < 7; ++k) {
+            if (!have[k]) continue;
+            const uint32_t n = slot_node[k];
+            uint32_t *w = &o.blocks[size_t(t.block) * 16];
+            if (!interior(n)) { w[k] = leaf_code(n); continue; }
+            w[k] = nodes[n].x;
+            const uint32_t c[2] = {n + 1u, nodes[n].y};
+            for (int j = 0; j < 2; ++j) {
+                if (k < 3) { slot_node[2 * k + 1 + j] = c[j]; have[2 * k + 1 + j] = true; }
+                else { const int li = 2 * (k - 3) + j; link_interior[li] = interior(c[j]); links[li] = link_interior[li] ? c[j] : leaf_code(c[j]); w[8 + li] = links[li]; if (link_interior[li]) w[8 + li] = ~0u; }
+            }
+        }
+        // the blocks behind the links: numbered now (below side first), filled when popped; pushed in reverse so that the first is processed next
+        std::vector<Todo> mine;
+        for (int k = 3; k < 7; ++k) {
+            if (!have[k] || !interior(slot_node[k])) continue;
+            for (int j = 0; j < 2; ++j) {
+                const int li = 2 * (k - 3) + j;
+                if (!link_interior[li]) continue;
+                const size_t b = o.blocks.size() / 16;
+                if (b >= (size_t(1) << 30)) return false;
+                o.blocks.resize(o.blocks.size() + 16, 3u);
+                o.blocks[size_t(t.block) * 16 + 8 + li] = uint32_t(b) << 2;
+                mine.push_back(Todo{links[li], uint32_t(b)});
+            }
+        }
+        for (size_t i = mine.size(); i-- > 0;) todo.push_back(mine[i]);
+    }
+    if (o.ldesc.empty()) o.ldesc.push_back(Node{RT_LE_NONE, ~RT_LE_POS});
+    o.ldesc.push_back(Node{RT_LE_NONE, ~RT_LE_POS});                         // (a step reads 16 bytes at a descriptor)
+    return ok;
+}
+#endif
 
 template <class T>
 static int upload(RtScene *s, const T *host, size_t n, const T **dev) {
@@ -1342,7 +1404,7 @@ static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel 
         bool runs = s->tree.leaf_refs.size() + s->tree.nodes.size() / 2 <= 32768;
         if (const char *e = knob("PBRT_HIP_LEAF_RUNS")) runs = std::atoi(e) != 0;
         if (!leaf_cursor_layout(s->tree.nodes, s->tree.leaf_refs, d->n_tris, knob("PBRT_HIP_LEAF_COPIES") != nullptr, runs, ll))
-            return fail(RT_EINVAL, "rt_scene_create: primitive records or leaf entries beyond 2^29");
+            return fail(RT_EINVAL, "rt_scene_create: primitive records beyond 2^30 float4 units or leaf entries beyond 2^31");
         s->dev.leaf_runs = runs ? 1u : 0u;
         const NodeVec &tn = ll.tnodes;
         tick("leaf entries");
@@ -1378,6 +1440,19 @@ static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel 
         tick("pair blocks");
         if ((rc = upload(s, pairs.data(), pairs.size(), &s->dev.tpairs))) return rc;
         tick("pair upload");
+#if RT_KD3
+        {
+            Kd3Layout k3;
+            if (!kd3_layout(s->tree.nodes, tn, k3)) return fail(RT_EINVAL, "rt_scene_create: three-level blocks beyond their index ranges");
+            s->dev.root_x = k3.root_x; s->dev.root_y = k3.root_y;
+            const uint32_t *bd = nullptr; const Node *dd = nullptr;
+            if ((rc = upload(s, k3.blocks.data(), k3.blocks.size(), &bd))) return rc;
+            if ((rc = upload(s, k3.ldesc.data(), k3.ldesc.size(), &dd))) return rc;
+            s->dev.tblocks = (const uint4 *)bd; s->dev.ldesc = (const uint2 *)dd;
+            if (tlog) std::fprintf(stderr, "CREATE kd3: %zu blocks (%.1f MB), %zu leaf descriptors (%.1f MB)\n", k3.blocks.size() / 16, k3.blocks.size() * 4 / 1e6, k3.ldesc.size(), k3.ldesc.size() * 8 / 1e6);
+            tick("three-level blocks");
+        }
+#endif
     }
     // materials (OrenNayar constants: reflection.h:268-277)
     std::vector<DevMaterial> mats(d->n_materials);
@@ -2089,6 +2164,13 @@ int rt_render(RtScene *s, const RtRenderDesc *rd) {
             size_t rec_floats = size_t(n_points) * size_t(R);
             fr.wt_mixed = mixed ? 1 : 0; fr.wt_nd = unsigned(nD); fr.wt_recbase = nullptr;
             if (mixed) {
+                // A sample with P shading points keeps P * A + nD * P * (P + 1) floats: quadratic in P, and sum P (P + 1) >= W * Pavg * (Pavg + 1) for W samples of
+                // Pavg points on average (convexity) -- a frame that cannot fit even by that lower bound is refused here, before the size scan is launched
+                {
+                    const double W = double(fr.total_work ? fr.total_work : 1), Pavg = double(n_points) / W;
+                    const double at_least = double(n_points) * double(1 + 2 * (nL - nD)) + double(nD) * W * Pavg * (Pavg + 1.0);
+                    if (at_least >= 4294967295.0) return late_fail(RT_EINVAL, "rt_render: strategy \"weighted\" with lights of mixed RNG use: the survey's records exceed 2^32 floats (quadratic in a sample's shading points)");
+                }
                 // where every sample's records start: per-sample sizes from the point counts (P * A + nD * P * (P + 1)), scanned like the counts were
                 rc = ensure(s, &s->wt_recbase, &s->wt_recbase_cap, size_t(fr.total_work) + 1); if (rc) return late_fail(rc, rt_last_error());
                 const unsigned long long nw = fr.total_work;

@@ -350,3 +350,35 @@ def test_pipeline_pool_is_sized_by_a_memory_budget(pkg, scenes):
     assert st_full["pipeline"] == 1 and st_small["pipeline"] == 1
     assert st_small["slots"] < st_full["slots"] and st_small["slots"] <= 2048 and st_small["iterations"] > st_full["iterations"]
     assert np.array_equal(full, ref) and np.array_equal(small, ref)
+
+
+# ---------------------------------------------------------------------------------------------- KdTreeAccel's build parameters ("report both")
+@pytest.mark.parametrize("integrator", ["whitted", "directlighting", "path"])
+def test_tuned_tree_gives_the_same_film(pkg, scenes, integrator):
+    """bench.py's `<workload>_tuned` sub-records render the same frame on the tree other build parameters give (accelerators/kdtree.cpp:489-498; bench.TUNED_ACCEL and
+    two more sets).  A closest hit is the smallest t over ALL primitives and an occlusion test is a yes / no: neither depends on how the tree is cut, and the keyed
+    sample stream does not depend on the traversal -- so the film must be the default tree's film BIT FOR BIT (Whitted, DirectLighting, and the path integrator too),
+    with the same rays, while the work counters differ (fewer nodes visited, more triangles tested)."""
+    need_gpu(pkg)
+    import bench
+    kw = dict(xres=96, yres=80, integrator=integrator, maxdepth=4, xsamples=2, ysamples=2, jitter=True, pixel_filter="mitchell", soup_tris=40000,
+              soup_materials=True, keyed=True)
+    base = None
+    for params in ("", bench.TUNED_ACCEL, '"integer intersectcost" [2] "integer traversalcost" [1] "float emptybonus" [0.2] "integer maxprims" [8]',
+                   '"integer intersectcost" [20] "integer traversalcost" [3] "integer maxprims" [4] "integer maxdepth" [12]'):
+        ps = pkg.ParsedScene(text=scenes.cornell_scene(accel_params=params, **kw))
+        assert ps.valid and ps.errors == 0 and ps.warnings == 0, params
+        ds = pkg.DeviceScene(ps)
+        ds.render()
+        acc, cnt, info = ds.film_accum(), ds.counters(), ds.accel_info()
+        ds.set_counting(False); ds.clear_film(); ds.render()
+        assert np.array_equal(ds.film_accum(), acc), params                      # the timed kernel on that tree
+        ds.close()
+        if base is None:
+            base = (acc, cnt, info.n_nodes)
+            continue
+        assert info.n_nodes != base[2], params                                     # really another tree
+        assert np.array_equal(acc, base[0]), params
+        for k in ("camera_rays", "closest_rays", "any_rays", "bad_samples"):
+            assert cnt[k] == base[1][k], (params, k)
+        assert cnt["nodes_visited"] != base[1]["nodes_visited"]
