@@ -79,8 +79,6 @@ struct DevScene {
                                // padding (pair_blocks_order; an LDS copy of them was measured and not kept: profiles/r05_lds_top_experiment.patch)
     const float4 *ltris;       // ONE 48-byte record per primitive (p1, e1, e2 as in DevTri, the primitive's index in q2.w), RT_TRI_STRIDE float4 units apart,
                                // in the order the depth-first leaf walk first meets the primitives (round 6; rounds 2-5: one copy per leaf reference)
-    const uint4 *tblocks;      // RT_KD3 builds: three tree levels per 64-byte block (rt_traverse.h kd3_step), and the entry-form words of the leaves of two or more
-    const uint2 *ldesc;
     const unsigned *lrefs;     // entries (position | RT_LE_* flags) of the third and later primitives of the leaves that hold three or more
     const unsigned *leaf_refs;
     const int *tri_shading_idx;      // [n_tris] index into tri_shading or -1 (EXT kernels; null when no mesh has N / S)

@@ -958,68 +958,6 @@ static void pair_blocks_fill(const NodeVec &tn, const PairBlockOrder &o, std::ve
     root_y = word1(0u);
 }
 
-#if RT_KD3
-// Three tree levels per 64-byte block (rt_traverse.h kd3_step).  `nodes` = the tree as built (leaf sizes), `tn` = the same nodes with the leaves in entry form.
-// Blocks are numbered depth-first (a block, then the blocks behind its links, below side first), so a subtree stays contiguous.
-struct Kd3Layout { std::vector<uint32_t> blocks; std::vector<Node> ldesc; uint32_t root_x = 3u, root_y = 0u; };
-static bool kd3_layout(const NodeVec &nodes, const NodeVec &tn, Kd3Layout &o) {
-    o.blocks.clear(); o.ldesc.clear();
-    auto interior = [&](uint32_t n) { return (nodes[n].x & 3u) != 3u; };
-    bool ok = true;
-    auto leaf_code = [&](uint32_t n) -> uint32_t {
-        const uint32_t np = nodes[n].x >> 2;
-        if (np == 0) return 3u;
-        if (np == 1) { const uint32_t rec = (tn[n].x >> 2) / RT_TRI_STRIDE; if (rec >= (1u << 28)) ok = false; return 3u | rec << 2 | 1u << 30; }
-        const size_t d = o.ldesc.size(); if (d >= (size_t(1) << 28)) ok = false;
-        o.ldesc.push_back(tn[n]);
-        return 3u | uint32_t(d) << 2 | 3u << 30;
-    };
-    if (nodes.empty()) { o.blocks.assign(16, 3u); return true; }
-    if (!interior(0)) { o.root_x = leaf_code(0); o.blocks.assign(16, 3u); o.ldesc.push_back(Node{RT_LE_NONE, ~RT_LE_POS}); return ok; }
-    o.root_x = 0u; o.root_y = 0u;
-    struct Todo { uint32_t node, block; };
-    std::vector<Todo> todo;
-    o.blocks.assign(16, 3u);
-    todo.push_back(Todo{0u, 0u});
-    while (!todo.empty()) {
-        const Todo t = todo.back(); todo.pop_back();
-        uint32_t slot_node[7]; bool have[7] = {true, false, false, false, false, false, false};
-        slot_node[0] = t.node;
-        uint32_t links[8]; bool link_interior[8];
-        for (int k = 0; k < 7; ++k) {
-            if (!have[k]) continue;
-            const uint32_t n = slot_node[k];
-            uint32_t *w = &o.blocks[size_t(t.block) * 16];
-            if (!interior(n)) { w[k] = leaf_code(n); continue; }
-            w[k] = nodes[n].x;
-            const uint32_t c[2] = {n + 1u, nodes[n].y};
-            for (int j = 0; j < 2; ++j) {
-                if (k < 3) { slot_node[2 * k + 1 + j] = c[j]; have[2 * k + 1 + j] = true; }
-                else { const int li = 2 * (k - 3) + j; link_interior[li] = interior(c[j]); links[li] = link_interior[li] ? c[j] : leaf_code(c[j]); w[8 + li] = links[li]; if (link_interior[li]) w[8 + li] = ~0u; }
-            }
-        }
-        // the blocks behind the links: numbered now (below side first), filled when popped; pushed in reverse so that the first is processed next
-        std::vector<Todo> mine;
-        for (int k = 3; k < 7; ++k) {
-            if (!have[k] || !interior(slot_node[k])) continue;
-            for (int j = 0; j < 2; ++j) {
-                const int li = 2 * (k - 3) + j;
-                if (!link_interior[li]) continue;
-                const size_t b = o.blocks.size() / 16;
-                if (b >= (size_t(1) << 30)) return false;
-                o.blocks.resize(o.blocks.size() + 16, 3u);
-                o.blocks[size_t(t.block) * 16 + 8 + li] = uint32_t(b) << 2;
-                mine.push_back(Todo{links[li], uint32_t(b)});
-            }
-        }
-        for (size_t i = mine.size(); i-- > 0;) todo.push_back(mine[i]);
-    }
-    if (o.ldesc.empty()) o.ldesc.push_back(Node{RT_LE_NONE, ~RT_LE_POS});
-    o.ldesc.push_back(Node{RT_LE_NONE, ~RT_LE_POS});                         // (a step reads 16 bytes at a descriptor)
-    return ok;
-}
-#endif
-
 template <class T>
 static int upload(RtScene *s, const T *host, size_t n, const T **dev) {
     void *p = nullptr;
@@ -1440,19 +1378,6 @@ static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel 
         tick("pair blocks");
         if ((rc = upload(s, pairs.data(), pairs.size(), &s->dev.tpairs))) return rc;
         tick("pair upload");
-#if RT_KD3
-        {
-            Kd3Layout k3;
-            if (!kd3_layout(s->tree.nodes, tn, k3)) return fail(RT_EINVAL, "rt_scene_create: three-level blocks beyond their index ranges");
-            s->dev.root_x = k3.root_x; s->dev.root_y = k3.root_y;
-            const uint32_t *bd = nullptr; const Node *dd = nullptr;
-            if ((rc = upload(s, k3.blocks.data(), k3.blocks.size(), &bd))) return rc;
-            if ((rc = upload(s, k3.ldesc.data(), k3.ldesc.size(), &dd))) return rc;
-            s->dev.tblocks = (const uint4 *)bd; s->dev.ldesc = (const uint2 *)dd;
-            if (tlog) std::fprintf(stderr, "CREATE kd3: %zu blocks (%.1f MB), %zu leaf descriptors (%.1f MB)\n", k3.blocks.size() / 16, k3.blocks.size() * 4 / 1e6, k3.ldesc.size(), k3.ldesc.size() * 8 / 1e6);
-            tick("three-level blocks");
-        }
-#endif
     }
     // materials (OrenNayar constants: reflection.h:268-277)
     std::vector<DevMaterial> mats(d->n_materials);

@@ -698,120 +698,6 @@ RT_DEV void kdp_pop(Trav &tv, bool done, PairStack st, unsigned n_threads, unsig
     tv.active = (done && (!pop || dead)) ? false : tv.active;
 }
 
-// ---- three tree levels per 64-byte block (RT_KD3) -------------------------------------------------------------------
-// DevScene::tblocks: a block holds the subtree of an interior node R down to three levels in heap order -- words 0..6 = R, its children, its
-// grandchildren (an interior node's word: its split with the axis in the two low bits; a leaf's word: a LEAF CODE), words 8..15 = the LINKS to the
-// eight great-grandchildren (the children of slot k = 3..6 at 8 + 2 (k - 3), + 1): block index << 2, or a leaf code.  7 splits + 8 links = 60 bytes
-// on ONE line where the pair blocks spend 48 bytes of a 64-byte slot on two levels: 9 instead of 19 bytes per interior node, one line miss per three
-// levels instead of two.  A step requests words 0..7 (two 16-byte loads), takes the reference's decisions for up to three levels from them
-// (kdtree.cpp:340-365: same comparisons, same push order), then requests the ONE pair of links it needs (8 bytes of the same line).
-// Leaf code = 3 | payload << 2 | kind << 30: kind 0 empty, 1 one primitive (payload = its record number), 3 = a leaf of two or more: payload = index
-// of its two entry-form words in DevScene::ldesc (fetched by the next step: one more round trip than the pair form, which carries them in the record).
-// The current node travels as (cx, cy) = (block << 2, slot) or (leaf code, 0); so do the stack entries: a far child inside the block is re-entered at
-// its slot (the block is requested again), a far child behind a link or a far leaf costs nothing to push.
-#ifndef RT_KD3
-#define RT_KD3 0
-#endif
-RT_DEV void kd3_enter_imm(Trav &tv, bool enter, unsigned code) {               // a leaf whose code says it all: empty, or one primitive
-    const unsigned one = ((code >> 2) & 0x0fffffffu) * RT_TRI_STRIDE;
-    tv.at_leaf = enter ? true : tv.at_leaf;
-    tv.ly = enter ? ((code >> 30) == 1u ? one : RT_LE_NONE) : tv.ly;
-    tv.ln_ = enter ? 0u : tv.ln_;
-    tv.li = enter ? 0u : tv.li;
-}
-template <bool COUNT, int NS>
-RT_DEV void kd3_step(Trav &tv, bool desc, const DevScene &sc, PairStack st, unsigned n_threads, unsigned gtid, TravCounters &cnt) {
-    const bool dead = desc && !tv.any && tv.maxt < tv.tmin;                    // kdtree.cpp:330
-    const bool go = desc && !dead;
-    tv.active = dead ? false : tv.active;
-    const bool isleaf = (tv.cx & 3u) == 3u;
-    const bool inter = go && !isleaf;
-    const bool lf_desc = go && isleaf && (tv.cx >> 30) == 3u;                  // a leaf of two or more, reached in an earlier step: its two words arrive now
-    const bool lf_imm = go && isleaf && (tv.cx >> 30) != 3u;                   // only ever a root that is a leaf
-    const unsigned blk = tv.cx >> 2, slot = tv.cy;
-    uint4 Q0, Q1; undef_u4(Q0); undef_u4(Q1);
-    if (inter | lf_desc) {
-        const char RT_G *p = inter ? (const char RT_G *)sc.tblocks + size_t(blk) * 64u : (const char RT_G *)sc.ldesc + size_t((tv.cx >> 2) & 0x0fffffffu) * 8u;
-        Q0 = *(const uint4 RT_G *)p;
-        if (inter) Q1 = *(const uint4 RT_G *)(p + 16);
-    }
-    float tplane; bool c_above, both;
-#define RT_KD3_DECIDE(WORD, TMAXC) { \
-        const unsigned ax_ = (WORD) & 3u; const float sp_ = __uint_as_float(WORD); \
-        const float oa_ = comp(tv.o, int(ax_)), da_ = comp(tv.d, int(ax_)), ia_ = comp(tv.inv, int(ax_)); \
-        tplane = (sp_ - oa_) * ia_; \
-        const bool bf_ = (oa_ < sp_) | ((oa_ == sp_) & (da_ >= 0.f)); \
-        const bool of_ = (tplane > (TMAXC)) | (tplane <= 0.f); \
-        const bool os_ = !of_ & (tplane < tv.tmin); \
-        both = !of_ & !os_; c_above = !(bf_ ^ os_); }
-    // ---- level 0: the block's root
-    const bool l0 = inter && slot == 0u;
-    RT_KD3_DECIDE(Q0.x, tv.tmax)
-    const unsigned n1w = c_above ? Q0.z : Q0.y, f1w = c_above ? Q0.y : Q0.z;
-    const unsigned near1 = c_above ? 2u : 1u, far1 = c_above ? 1u : 2u;
-    const bool both0 = l0 & both;
-    if (both0) { const bool fl = (f1w & 3u) == 3u; kdp_push<COUNT, NS>(tv, st, fl ? f1w : tv.cx, fl ? 0u : far1, tv.tmax, n_threads, gtid, cnt); }
-    const float tmax1 = both0 ? tplane : tv.tmax;
-    // ---- level 1
-    const bool l1 = inter && ((l0 && (n1w & 3u) != 3u) || slot == 1u || slot == 2u);
-    const unsigned s1 = l0 ? near1 : slot;
-    const unsigned w1 = l0 ? n1w : (slot == 1u ? Q0.y : Q0.z);
-    RT_KD3_DECIDE(w1, tmax1)
-    const unsigned cb1 = s1 == 1u ? Q0.w : Q1.y, ca1 = s1 == 1u ? Q1.x : Q1.z;
-    const unsigned n2w = c_above ? ca1 : cb1, f2w = c_above ? cb1 : ca1;
-    const unsigned near2 = 2u * s1 + (c_above ? 2u : 1u), far2 = 2u * s1 + (c_above ? 1u : 2u);
-    const bool both1 = l1 & both;
-    if (both1) { const bool fl = (f2w & 3u) == 3u; kdp_push<COUNT, NS>(tv, st, fl ? f2w : tv.cx, fl ? 0u : far2, tmax1, n_threads, gtid, cnt); }
-    const float tmax2 = both1 ? tplane : tmax1;
-    // ---- level 2: its children are behind links
-    const bool l2 = inter && ((l1 && (n2w & 3u) != 3u) || slot >= 3u);
-    const unsigned s2 = l1 ? near2 : slot;
-    const unsigned w2 = l1 ? n2w : (slot == 3u ? Q0.w : (slot == 4u ? Q1.x : (slot == 5u ? Q1.y : Q1.z)));
-    RT_KD3_DECIDE(w2, tmax2)
-    uint2 L; asm("" : "=v"(L.x), "=v"(L.y));
-    if (l2) L = *(const uint2 RT_G *)((const char RT_G *)sc.tblocks + size_t(blk) * 64u + 8u * (s2 + 1u));      // words 8 + 2 (s2 - 3), + 1
-    const unsigned nl = c_above ? L.y : L.x, fl2 = c_above ? L.x : L.y;
-    const bool both2 = l2 & both;
-    if (both2) kdp_push<COUNT, NS>(tv, st, fl2, 0u, tmax2, n_threads, gtid, cnt);
-    const float tmax3 = both2 ? tplane : tmax2;
-#undef RT_KD3_DECIDE
-    if (COUNT) cnt.nodes += (l0 ? 1u : 0u) + (l1 ? 1u : 0u) + (l2 ? 1u : 0u);
-    // ---- where the lane stands now
-    tv.cx = l2 ? nl : (l1 ? n2w : (l0 ? n1w : tv.cx));
-    tv.cy = inter ? 0u : tv.cy;
-    tv.tmax = inter ? tmax3 : tv.tmax;
-    // a leaf whose code says it all is entered in this very step (the reference's next iteration re-checks maxt < tmin with unchanged values, kdtree.cpp:330);
-    // a leaf of two or more is entered when its two words have arrived
-    const bool imm = (inter || lf_imm) && (tv.cx & 3u) == 3u && (tv.cx >> 30) != 3u;
-    kd3_enter_imm(tv, imm, tv.cx);
-    tv.at_leaf = lf_desc ? true : tv.at_leaf;
-    leaf_cursor_enter(tv, lf_desc, Q0.x, Q0.y);
-    if (COUNT) cnt.nodes += (imm || lf_desc) ? 1u : 0u;
-}
-template <bool COUNT, int NS>
-RT_DEV void kd3_pop(Trav &tv, bool done, PairStack st, unsigned n_threads, unsigned gtid, TravCounters &cnt) {
-    const bool pop = done && tv.sp > 0;
-    unsigned ex, ey; float et; asm("" : "=v"(ex), "=v"(ey), "=v"(et));
-    if (pop) {
-        --tv.sp;
-        const unsigned r = (unsigned(tv.sp) % NS) * RT_BLOCK + threadIdx.x;
-        const volatile uint2 RT_L *px = (const volatile uint2 RT_L *)st.xy + r;
-        const volatile float RT_L *pt = (const volatile float RT_L *)st.tm + r;
-        ex = px->x; ey = px->y; et = *pt;
-        if (tv.sp < tv.sbase) { const uint4 e = st.spill[size_t(tv.sp) * n_threads + gtid]; ex = e.x; ey = e.y; et = __uint_as_float(e.z); tv.sbase = tv.sp; }
-    }
-    tv.cx = pop ? ex : tv.cx;
-    tv.cy = pop ? ey : tv.cy;
-    tv.tmin = pop ? tv.tmax : tv.tmin;
-    tv.tmax = pop ? et : tv.tmax;
-    const bool dead = pop && !tv.any && tv.maxt < tv.tmin;
-    const bool imm = pop && !dead && (ex & 3u) == 3u && (ex >> 30) != 3u;
-    tv.at_leaf = done ? false : tv.at_leaf;
-    kd3_enter_imm(tv, imm, ex);
-    if (COUNT) cnt.nodes += imm ? 1u : 0u;
-    tv.active = (done && (!pop || dead)) ? false : tv.active;
-}
-
 template <bool COUNT, int ACCEL, bool EXT, int NS, bool PAIRS_OK = true, int DSTEPS = RT_TRACE_DSTEPS>
 RT_DEV void trace_round(Trav &tv, bool busy, const DevScene &sc, uint2 RT_L *lds_stack, float RT_L *lds_tm, uint2 RT_G *spill, unsigned n_threads, unsigned gtid, TravCounters &cnt,
                         int leaf_min = RT_TRACE_LEAF_MIN) {
@@ -825,8 +711,7 @@ RT_DEV void trace_round(Trav &tv, bool busy, const DevScene &sc, uint2 RT_L *lds
         for (int k = 0; k < DSTEPS; ++k) {
             const bool desc = busy && tv.active && !tv.at_leaf;
             if (!__any(desc)) break;
-            if (RT_KD3) kd3_step<COUNT, NS>(tv, desc, sc, pst, n_threads, gtid, cnt);
-            else kdp_step<COUNT, NS>(tv, desc, sc, pst, n_threads, gtid, cnt);
+            kdp_step<COUNT, NS>(tv, desc, sc, pst, n_threads, gtid, cnt);
         }
     } else {
 #pragma unroll 1
@@ -847,7 +732,7 @@ RT_DEV void trace_round(Trav &tv, bool busy, const DevScene &sc, uint2 RT_L *lds
     }
     const bool done = busy && tv.active && tv.at_leaf && (CURSOR ? tv.ly == RT_LE_NONE : tv.li >= tv.ln_);
     if (ACCEL == RT_ACCEL_GRID) { if (done) grid_voxel_done(tv, sc); }
-    else if (PAIRS) { if (__any(done)) { if (RT_KD3) kd3_pop<COUNT, NS>(tv, done, pst, n_threads, gtid, cnt); else kdp_pop<COUNT, NS>(tv, done, pst, n_threads, gtid, cnt); } }
+    else if (PAIRS) { if (__any(done)) kdp_pop<COUNT, NS>(tv, done, pst, n_threads, gtid, cnt); }
     else kd_pop_flat<NS>(tv, done, lds_stack, spill, n_threads, gtid);
 }
 
