@@ -33,7 +33,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-msse2", "-mfpmath=sse", "-fvisibility=hidden", "-fvisibility-inlines-hidden"]
 
 
-HIP_UNITS = ("rt_kernels.hip", "rt_trace.hip", "rt_mega_w.hip", "rt_mega_d.hip", "rt_mega_dw.hip", "rt_mega_p.hip", "rt_pipe_w.hip", "rt_pipe_d.hip",
+HIP_UNITS = ("rt_kernels.hip", "rt_scene.hip", "rt_film.hip", "rt_trace.hip", "rt_mega_w.hip", "rt_mega_d.hip", "rt_mega_dw.hip", "rt_mega_p.hip", "rt_pipe_w.hip", "rt_pipe_d.hip",
              "rt_pipe_p.hip", "rt_pipe_v.hip", "rt_march.hip", "kd_build.cpp", "grid_build.cpp")
 
 

@@ -3,7 +3,7 @@
 // pbrt-v1 evaluates a camera sample with recursive C++ calls (Scene::Render scene.cpp:42-84 ->
 // SurfaceIntegrator::Li -> EstimateDirect -> Scene::Intersect...).  Here each lane of a 64-wide wavefront
 // owns one camera sample at a time and runs it as an explicit state machine whose ONLY blocking
-// operation is "trace the ray I just set up"; all lanes share one traversal loop (rt_kernels.hip), and a
+// operation is "trace the ray I just set up"; all lanes share one traversal loop (rt_render_kernel.h), and a
 // lane whose sample finishes immediately fetches the next one (persistent threads + ray regeneration).
 // Whitted / DirectLighting recursion (whitted.cpp:82-137, directlighting.cpp:127-183) is flattened to
 // explicit frames that keep the reference's evaluation order, so partial sums are formed in the same

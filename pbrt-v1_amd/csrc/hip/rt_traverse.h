@@ -614,7 +614,7 @@ RT_DEV void kdp_push(Trav &tv, PairStack st, unsigned sx, unsigned sy, float tma
 }
 // One step = one gather round trip = up to TWO levels of the tree.  Everything that decides which child of the current node P the
 // traversal continues in -- P's split (in hand), the ray, [tmin, tmax] -- is known BEFORE P's children arrive, and the pair layout
-// (build_pair_blocks, rt_kernels.hip) puts the pairs of an "owner" node's interior children right behind the owner's own pair
+// (pair_blocks_order / pair_blocks_fill, rt_scene.hip) puts the pairs of an "owner" node's interior children right behind the owner's own pair
 // ({P, below(P), above(P)}: at most 48 bytes, never across a 64-byte boundary; bits 30 / 31 of the owner's word 1 say which of them
 // exist).  So the step asks for pair(P) and pair(chosen child) together, and when they arrive takes the reference's decisions for P
 // and for that child back to back (kdtree.cpp:340-365, same comparisons, same push order).  A node that is not an owner (flags 0: a

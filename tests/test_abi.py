@@ -110,7 +110,7 @@ def test_timed_kernels_stay_inside_their_occupancy_step(pkg):
     # pointer phi) puts them in scratch, 112 B per lane -- seen while writing film_march_kernel
     for frag, cap in (("film_slot_kernelILi2ELi2ELi4EE", 168), ("film_slot_kernelILi2ELi2ELi12EE", 256), ("film_slot_kernelILi1ELi1ELi4EE", 168),
                       ("film_march_kernelILi2EE", 128)):
-        v, spill = vgprs("rt_kernels", frag)
-        rep = open(os.path.join(pkg.LIB_DIR, "obj", "rt_kernels.resources.txt")).read()
+        v, spill = vgprs("rt_film", frag)
+        rep = open(os.path.join(pkg.LIB_DIR, "obj", "rt_film.resources.txt")).read()
         blk = [b for b in re.split(r"remark: Function Name: ", rep)[1:] if frag in b.splitlines()[0]][0]
         assert v <= cap and spill == 0 and int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", blk).group(1)) == 0, (frag, v, spill)

@@ -310,7 +310,7 @@ GATHER_REACH = {"mitchell_4spp": (2, 2), "gaussian_6spp": (2, 2), "triangle_1spp
 
 @pytest.mark.parametrize("name", sorted(GATHER_CASES))
 def test_the_three_film_gathers_agree_bit_for_bit(pkg, scenes, name, monkeypatch):
-    """ImageFilm::AddSample runs as one of three kernels (rt_kernels.hip): film_slot_kernel (filters reaching 1 or 2 pixels both ways: one
+    """ImageFilm::AddSample runs as one of three kernels (rt_film.hip): film_slot_kernel (filters reaching 1 or 2 pixels both ways: one
     pixel per lane, sample rows staged in LDS with the footprint tests and table indices precomputed per record), film_march_kernel (up
     to 3 rows: a lane marches down a pixel column) and the staged film_gather_kernel (anything).  All three must produce the SAME bits --
     the staged one is the kernel the reference-film fixtures were pinned with in rounds 1-2 -- whatever the strip height, on one shard
