@@ -12,7 +12,7 @@ namespace rt {
 struct Node { uint32_t x, y; };   // 8-byte flattened kd node (see kd_build.cpp header)
 
 // A vector whose resize() leaves the new elements uninitialised: multi-gigabyte arrays (2 GB of nodes and 4 GB of leaf references at 10 M triangles,
-// 12 GB of leaf-ordered records) are first touched by the threads that fill them, not zero-filled page by page by one thread beforehand.
+// 3.6 GB of leaf entries) are first touched by the threads that fill them, not zero-filled page by page by one thread beforehand.
 template <class T> struct NoInitAlloc : std::allocator<T> {
     template <class U> struct rebind { using other = NoInitAlloc<U>; };
     NoInitAlloc() = default;

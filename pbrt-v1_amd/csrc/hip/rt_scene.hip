@@ -347,7 +347,7 @@ static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel 
 int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) { return guarded("rt_scene_create", [&] { return scene_create(d, device, nullptr, out); }); }
 // The same scene with the accelerator somebody else built (rt_accel_build / rt_scene_accel_copy of another rank's scene): the ranks of one
 // node build the kd-tree ONCE (10 M triangles: 15 s on all host cores) instead of once per process.  The arrays are the canonical flattened
-// tree (pbrt_hip.h RtAccelInfo / rt_accel_copy); everything the device derives from them (leaf-ordered records, pair blocks) is rebuilt here.
+// tree (pbrt_hip.h RtAccelInfo / rt_accel_copy); everything the device derives from them (primitive records and leaf entries, pair blocks) is rebuilt here.
 int rt_scene_create_prebuilt(const RtSceneDesc *d, int device, const RtPrebuiltAccel *pre, RtScene **out) {
     if (!pre) return fail(RT_EINVAL, "rt_scene_create_prebuilt: null accelerator");
     return guarded("rt_scene_create_prebuilt", [&] { return scene_create(d, device, pre, out); });

@@ -1,5 +1,5 @@
 // rt_trace.hip -- rt::pipe_trace_kernel (the dominant kernel of the queue pipeline): k = ACCEL*4 + f, f = 0: timed, 1: counting twin with the
-// glossy / quadric code, 2: timed with that code (EXT), 3: counting twin without it (leaf-ordered triangle records, like 0)
+// glossy / quadric code, 2: timed with that code (EXT), 3: counting twin without it (per-primitive records + leaf entries, like 0)
 #include "rt_pipeline.h"
 namespace rt {
 #define RT_K(C, A, G) pipe_trace_kernel<C, A, G>
