@@ -410,6 +410,19 @@ static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel 
     std::thread order_thread;
     struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{order_thread};
     if (s->accel_kind == RT_ACCEL_KDTREE) order_thread = std::thread([&] { pair_blocks_order(s->tree.nodes, pbo); });
+    // ... and so do the leaf entries (four passes over the leaf lists by all host threads: 1.3 s at 10 M triangles) while this thread fills the per-triangle records
+    // and uploads the tree.  Scenes of a few thousand references (C2's 14 triangles: cache resident, bound by instruction issue -- the entry form costs it 2.8 %,
+    // profiles/r06_dedup_scan.txt) get runs of consecutive records per leaf; everything larger shares one record per primitive.
+    LeafLayout ll;
+    int ll_status = 0;                                  // 1 laid out, -1 index ranges exceeded, -2 out of memory
+    bool runs = s->tree.leaf_refs.size() + s->tree.nodes.size() / 2 <= 32768;
+    if (const char *e = knob("PBRT_HIP_LEAF_RUNS")) runs = std::atoi(e) != 0;
+    const bool copies = knob("PBRT_HIP_LEAF_COPIES") != nullptr;
+    std::thread layout_thread;
+    Joiner joiner2{layout_thread};
+    if (s->accel_kind == RT_ACCEL_KDTREE) layout_thread = std::thread([&] {
+        try { ll_status = leaf_cursor_layout(s->tree.nodes, s->tree.leaf_refs, d->n_tris, copies, runs, ll) ? 1 : -1; } catch (...) { ll_status = -2; }
+    });
     // triangles -> 48-byte records
     std::vector<DevTri> tris(d->n_tris);
     uint32_t n_quadric_slots = 0;
@@ -506,17 +519,13 @@ static int scene_create(const RtSceneDesc *d, int device, const RtPrebuiltAccel 
     s->dev.nodes = nodes_dev;
     s->dev.tnodes = nodes_dev;
     if (s->accel_kind == RT_ACCEL_KDTREE) {
-        LeafLayout ll;
         tick("node / leaf-list upload");
-        // runs of consecutive records per leaf for scenes of a few thousand references (C2's 14 triangles: cache resident, bound by instruction issue -- the entry
-        // form costs it 2.8 %, profiles/r06_dedup_scan.txt); everything larger shares one record per primitive
-        bool runs = s->tree.leaf_refs.size() + s->tree.nodes.size() / 2 <= 32768;
-        if (const char *e = knob("PBRT_HIP_LEAF_RUNS")) runs = std::atoi(e) != 0;
-        if (!leaf_cursor_layout(s->tree.nodes, s->tree.leaf_refs, d->n_tris, knob("PBRT_HIP_LEAF_COPIES") != nullptr, runs, ll))
-            return fail(RT_EINVAL, "rt_scene_create: primitive records beyond 2^30 float4 units or leaf entries beyond 2^31");
+        layout_thread.join();
+        if (ll_status == -2) return fail(RT_ENOMEM, "rt_scene_create: out of host memory while laying out the leaf entries");
+        if (ll_status != 1) return fail(RT_EINVAL, "rt_scene_create: primitive records beyond 2^30 float4 units or leaf entries beyond 2^31");
         s->dev.leaf_runs = runs ? 1u : 0u;
         const NodeVec &tn = ll.tnodes;
-        tick("leaf entries");
+        tick("leaf entries (rest)");
         if ((rc = upload_nodes(tn, &s->dev.tnodes))) return rc;
         if ((rc = upload(s, ll.lrefs.data(), ll.lrefs.size(), &s->dev.lrefs))) return rc;
         {

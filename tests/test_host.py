@@ -325,3 +325,24 @@ extern "C" int PbrtHipCreateSurfaceIntegrator(const PbrtHipParams *, const PbrtH
     subprocess.check_call(["g++", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"), str(tmp_path / "old.cpp"), "-o", str(old / "path.so")])
     ps6 = pkg.ParsedScene(text=('SearchPath "%s"\n' % old) + base)
     assert ps6.valid and ps6.errors == 0 and ps6.render_view()["integrator"] == 2 and ps6.warnings == 1
+
+
+def test_bench_scene_texts_for_the_tuned_tree_and_the_parity_leg(pkg):
+    """bench.py derives two more texts from a workload's scene: `<w>_tuned` appends KdTreeAccel's tuned build parameters to the Accelerator line (the host front
+    end must take them: accelerators/kdtree.cpp:489-498's names), and the oracle-side text of the cpu_baseline / parity legs adds the crop window and wraps the sampler and
+    the accelerator in the checker's helper plugins -- which scenes.for_product unwraps again, so the product parses the same frame (same crop, same tree parameters)."""
+    import bench
+    text, label, crop = bench.workload("tsmall")
+    tuned = bench.accel_with_params(text, bench.TUNED_ACCEL)
+    ps0, ps1 = pkg.ParsedScene(text=text), pkg.ParsedScene(text=tuned)
+    assert ps0.valid and ps1.valid and ps0.errors == ps1.errors == 0 and ps1.warnings == 0
+    a0, a1 = ps0.accel_params(), ps1.accel_params()
+    assert (a0["isect_cost"], a0["trav_cost"], a0["max_prims"]) == (80, 1, 1) and abs(a0["empty_bonus"] - 0.5) < 1e-7
+    assert (a1["isect_cost"], a1["trav_cost"], a1["max_prims"]) == (2, 1, 4) and a1["empty_bonus"] == 0.0
+    assert ps0.n_tris == ps1.n_tris and (ps0.width, ps0.height) == (ps1.width, ps1.height)
+    keyed = bench.oracle_side_text("tsmall", crop, keyed=True)
+    assert 'Sampler "keyed" "string inner" ["stratified"] "integer seed" [0]' in keyed and 'Accelerator "countaccel" "string inner" ["kdtree"]' in keyed and '"float cropwindow"' in keyed
+    pk = pkg.ParsedScene(text=keyed)                       # ParsedScene unwraps the helper plugins (scenes.for_product)
+    assert pk.valid and pk.errors == 0 and pk.n_tris == ps0.n_tris and pk.spp == ps0.spp
+    assert pk.width == int(np.ceil(160 * crop[1])) - int(np.ceil(160 * crop[0])) and pk.height == int(np.ceil(120 * crop[3])) - int(np.ceil(120 * crop[2]))
+    assert bench.workload("tsmall_tuned")[0] == tuned
