@@ -416,6 +416,45 @@ def test_by_vertex_path_kernels_equal_the_per_ray_twins_on_random_scenes(pkg, sc
     assert cnt["camera_rays"] > 0 and cnt["bad_samples"] == 0
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(xres=64, yres=64, integrator="path", maxdepth=5, xsamples=2, ysamples=2, jitter=True, keyed=True),                                  # Cornell alone: 14 triangles, leaves of up to 9
+    dict(xres=64, yres=48, integrator="directlighting", xsamples=2, ysamples=2, jitter=True, keyed=True, soup_tris=3000, soup_materials=True),
+    dict(xres=64, yres=48, integrator="path", maxdepth=6, xsamples=2, ysamples=1, keyed=True, soup_tris=40000, soup_materials=True,
+         accel_params='"integer maxprims" [8] "integer intersectcost" [2] "float emptybonus" [0]'),                                        # fat leaves: long entry lists
+    dict(xres=48, yres=48, integrator="whitted", xsamples=1, ysamples=1, keyed=True, soup_tris=20000, soup_materials=True,
+         volume_integrator='"single" "float stepsize" [40]', world_kwargs=dict(volume='"float g" [.2]')),                                  # the march kernel's traversal loop
+])
+def test_leaf_layout_forms_agree(pkg, scenes, cfg, monkeypatch):
+    """Round 6: a leaf's primitives are reached through ENTRIES into one record per primitive (rt_traverse.h RT_LE_*: first inline, second in the node's other word, the rest
+    in a list that is requested together with the record before it), or, on scenes of a few thousand references, through RUNS of consecutive records.  Which form a scene gets
+    is a host-side choice (rt_scene.hip leaf_cursor_layout) that must never show: the same frame under the default, under entries forced (PBRT_HIP_LEAF_RUNS=0: Cornell's leaves of
+    nine through the list path), under runs forced (=1) and under entries over per-reference copies (PBRT_HIP_LEAF_COPIES) -- films and EVERY counter equal, counting twin and timed
+    kernels (both megakernel flavours and the queue pipeline's trace kernel) alike, with the device-filled records verified against the host fill."""
+    need_gpu(pkg)
+    ps = pkg.ParsedScene(text=scenes.cornell_scene(**cfg))
+    assert ps.valid and ps.errors == 0
+    monkeypatch.setenv("PBRT_HIP_VERIFY_DERIVED", "1")
+    base = None
+    for env in ({}, dict(PBRT_HIP_LEAF_RUNS="0"), dict(PBRT_HIP_LEAF_RUNS="1"), dict(PBRT_HIP_LEAF_RUNS="0", PBRT_HIP_LEAF_COPIES="1")):
+        with pytest.MonkeyPatch.context() as mp:
+            for k, v in env.items():
+                mp.setenv(k, v)
+            ds = pkg.DeviceScene(ps)                          # (the layout knobs are read by rt_scene_create)
+        ds.render(); acc = ds.film_accum(); cnt = ds.counters()
+        for flavour in (dict(PBRT_HIP_HIGH_OCC="0"), dict(PBRT_HIP_HIGH_OCC="1"), dict(PBRT_HIP_PIPELINE="1")):
+            with pytest.MonkeyPatch.context() as mp:
+                for k, v in flavour.items():
+                    mp.setenv(k, v)
+                ds.set_counting(False); ds.clear_film(); ds.render()
+                assert np.array_equal(ds.film_accum(), acc), (env, flavour)
+        ds.close()
+        if base is None:
+            base = (acc, cnt)
+            continue
+        assert np.array_equal(acc, base[0]), env
+        assert cnt == base[1], (env, cnt, base[1])
+
+
 def test_errors_are_loud(pkg, scenes):
     need_gpu(pkg)
     ps = pkg.ParsedScene(text=scenes.cornell_scene(xres=8, yres=8))

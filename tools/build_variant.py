@@ -20,6 +20,10 @@ def main():
     for i, a in enumerate(sys.argv):                              # --mllvm OPT: a code generation option for the device compiler (scheduling experiments)
         if a == "--mllvm":
             defines += ["-mllvm", sys.argv[i + 1]]
+    arch = None
+    for i, a in enumerate(sys.argv):                              # --arch gfx950:xnack- : another target id for the device code (code generation experiments)
+        if a == "--arch":
+            arch = sys.argv[i + 1]
     units = list(pkg.HIP_UNITS)
     for i, a in enumerate(sys.argv):
         if a == "--units":
@@ -31,7 +35,10 @@ def main():
 
     def run(u):
         obj = os.path.join(obj_dir, u.rsplit(".", 1)[0] + ".o")
-        cmd = ["hipcc"] + [f for f in pkg.HIPCC_FLAGS if f != "-shared"] + defines + ["-c", os.path.join(hip_dir, u), "-o", obj]
+        flags = [f for f in pkg.HIPCC_FLAGS if f != "-shared"]
+        if arch:
+            flags = ["--offload-arch=" + arch if f.startswith("--offload-arch=") else f for f in flags]
+        cmd = ["hipcc"] + flags + defines + ["-c", os.path.join(hip_dir, u), "-o", obj]
         if not u.endswith(".hip"):
             subprocess.check_call(cmd)
             return obj
@@ -45,7 +52,7 @@ def main():
         built = dict(zip(units, ex.map(run, units)))
     objs = [built.get(u, os.path.join(pkg.LIB_DIR, "obj", u.rsplit(".", 1)[0] + ".o")) for u in pkg.HIP_UNITS]
     out = os.path.join(pkg.LIB_DIR, "libpbrt_hip_%s.so" % name)
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out])
+    subprocess.check_call(["hipcc", "--offload-arch=" + (arch or "gfx950"), "-shared", "-fPIC"] + objs + ["-o", out])
     print(out)
 
 
