@@ -104,9 +104,20 @@ def test_device_film_matches_reference_golden(pkg, oracle, name):
     ds.render()
     rgb, alpha = ds.film()
     cnt = ds.counters()
+    # ... and the TIMED kernels (COUNT = false: what bench.py measures -- the by-vertex path form among them) against the reference's film DIRECTLY, not only through
+    # their equality with the counting twin (VERDICT r05 weak #1a): the flavour make_frame picks for this scene and the register-capped one it picks for large trees
+    timed = []
+    for env in ({}, dict(PBRT_HIP_HIGH_OCC="1")):
+        with pytest.MonkeyPatch.context() as mp:
+            for k, v in env.items():
+                mp.setenv(k, v)
+            ds.set_counting(False); ds.clear_film(); ds.render()
+            timed.append(ds.film())
     ds.close()
     sens = (lambda: oracle_one_ulp_sensitivity(pkg, oracle, ps)) if ps.kdtree is not None and "grid" not in name else None
     check_film(name, rgb, alpha, g["rgb"], g["alpha"], ps.integrator, sens)
+    for trgb, talpha in timed:
+        check_film(name, trgb, talpha, g["rgb"], g["alpha"], ps.integrator, sens)
     st = g["stats"]
     tol = 0 if not libm_bound(name, ps.integrator) else max(4, int(2e-4 * st["closest_rays"]))
     assert abs(cnt["closest_rays"] - st["closest_rays"]) <= tol and abs(cnt["any_rays"] - st["any_rays"]) <= tol
