@@ -204,7 +204,7 @@ def parity_leg(pkg, name: str, crop, device_index: int):
             "ray_count_equal": bool(rays_dev == rays_ref), "rays_device": int(rays_dev), "rays_reference": int(rays_ref),
             # (path frames: a bounce direction that differs in its last bit -- device libm -- now and then changes what a later ray meets; DirectLighting frames: two
             # triangles hit at EXACTLY equal t -- the reference's per-primitive mailbox, accelerators/kdtree.cpp:376-386, and this library's re-test keep different
-            # ones when the first was already tested in an earlier leaf: 2 of 12 M camera rays on C3's crop, tools/r06_tie_probe.py, profiles/r06_tie_probe.txt)
+            # ones when the first was already tested in an earlier leaf: 2 of 12 M camera rays on C3's crop, tests/probe_equal_t_ties.py, profiles/r06_tie_probe.txt)
             "ray_count_rel_diff": float(abs(rays_dev - rays_ref) / max(rays_ref, 1)),
             "timed_kernel_film_equals_counting_twin": bool(np.array_equal(rgb, rgb_c) and np.array_equal(alpha, alpha_c)),
             "tolerance": "per-pixel L2 over rgb < 1e-4 (north star); DirectLighting / Whitted frames are expected bit-exact, path frames >= 99.5 % of pixels within 1e-4 (device libm in the cosine-sampled bounce)",

@@ -3,8 +3,9 @@
 Camera rays of the crop through rt_trace_closest on both trees and through the CPU oracle on the tuned tree: hits that differ between trees are equal-t ties
 (the kept primitive depends on leaf order, trianglemesh.cpp:245); device and oracle must agree on the SAME tree."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))      # the checker: this diagnostic lives under tests/ because only tests may use oracle/
 os.environ.setdefault("PBRT_HIP_TUNE", "1")
 import numpy as np
 import __graft_entry__ as entry
