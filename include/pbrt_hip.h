@@ -257,6 +257,14 @@ typedef struct RtKdTree RtAccel;
 int rt_accel_build(const float *tri_verts, uint32_t n_tris, const RtAccelParams *params, RtAccel **out);
 int rt_accel_info(const RtAccel *t, RtAccelInfo *info);
 int rt_accel_copy(const RtAccel *t, uint32_t *nodes, uint32_t *leaf_refs);
+/* Host only, for tests of the host logic: the leaves of a kd-tree as rt_scene_create lays them out for the flat traversal -- ONE 48-byte record per primitive, `stride` float4
+ * units apart, in the order the depth-first leaf walk first meets the primitives (`slot_prim[slot]` = primitive), and per leaf node its primitives as ENTRIES = position | flags
+ * (the reference keeps index lists, accelerators/kdtree.cpp:55-64): word 0 = position of the first primitive's record << 2 | 3, word 1 = bit 31 "more follow",
+ * bit 30 "the others' entries are a list" | the second entry (leaf of two) or HALF the index of the list in `entries`, whose items carry the same two flags; an empty leaf's first entry
+ * is 0xffffffff.  `runs` != 0: every leaf owns a run of consecutive records, word 1 = bit 31 (more than one) | the count (what scenes of a few thousand references get); `copies` != 0:
+ * one record per leaf reference (measurements).  Call with null arrays for the sizes (tnodes [n_nodes][2], slot_prim [n_slots], entries [n_entries]). */
+typedef struct RtLeafLayoutInfo { uint64_t n_nodes, n_slots, n_entries; uint32_t stride, pad; } RtLeafLayoutInfo;
+int rt_accel_leaf_layout(const RtAccel *t, int runs, int copies, uint32_t *tnodes, uint32_t *slot_prim, uint32_t *entries, RtLeafLayoutInfo *info);
 int rt_accel_destroy(RtAccel *t);
 typedef struct RtKdTree RtKdTree;
 int rt_kdtree_build(const float *tri_verts, uint32_t n_tris, const RtAccelParams *params, RtKdTree **out);

@@ -34,7 +34,7 @@ HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-msse2", "-mfpmath=sse",
 
 
 HIP_UNITS = ("rt_kernels.hip", "rt_scene.hip", "rt_film.hip", "rt_trace.hip", "rt_mega_w.hip", "rt_mega_d.hip", "rt_mega_dw.hip", "rt_mega_p.hip", "rt_pipe_w.hip", "rt_pipe_d.hip",
-             "rt_pipe_p.hip", "rt_pipe_v.hip", "rt_march.hip", "kd_build.cpp", "grid_build.cpp")
+             "rt_pipe_p.hip", "rt_pipe_v.hip", "rt_march.hip", "kd_build.cpp", "grid_build.cpp", "leaf_layout.cpp")
 
 
 def build(force: bool = False, verbose: bool = False, defines=(), jobs: int | None = None) -> None:
@@ -122,6 +122,10 @@ class RtAccelInfo(C.Structure):
                 ("grid_nvoxels", C.c_int32 * 3), ("grid_width", C.c_float * 3), ("grid_inv_width", C.c_float * 3)]
 
 
+class RtLeafLayoutInfo(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint64), ("n_slots", C.c_uint64), ("n_entries", C.c_uint64), ("stride", C.c_uint32), ("pad", C.c_uint32)]
+
+
 class RtPrebuiltAccel(C.Structure):
     _fields_ = [("kind", C.c_int32), ("n_nodes", C.c_uint32), ("n_leaf_refs", C.c_uint32), ("max_depth", C.c_uint32),
                 ("nodes", C.c_void_p), ("leaf_refs", C.c_void_p), ("bounds", C.c_float * 6),
@@ -183,7 +187,7 @@ def hip_lib():
                      "rt_counters_reset", "rt_last_render_ms", "rt_last_render_stats", "rt_samples_read", "rt_device_count", "rt_set_counting",
                      "rt_kdtree_build", "rt_kdtree_info", "rt_kdtree_copy", "rt_kdtree_destroy",
                      "rt_accel_build", "rt_accel_info", "rt_accel_copy", "rt_accel_destroy", "rt_scene_create_prebuilt", "rt_film_resolve_device",
-                     "rt_film_resolve_device_rgba", "rt_film_pack_parts"):
+                     "rt_film_resolve_device_rgba", "rt_film_pack_parts", "rt_accel_leaf_layout"):
             getattr(L, name).restype = C.c_int
         L.rt_scene_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
         L.rt_scene_create_prebuilt.argtypes = [C.c_void_p, C.c_int, C.POINTER(RtPrebuiltAccel), C.POINTER(C.c_void_p)]
@@ -218,6 +222,7 @@ def hip_lib():
         L.rt_accel_info.argtypes = [C.c_void_p, C.POINTER(RtAccelInfo)]
         L.rt_accel_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.rt_accel_destroy.argtypes = [C.c_void_p]
+        L.rt_accel_leaf_layout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(RtLeafLayoutInfo)]
         _hip = L
     return _hip
 
@@ -390,6 +395,27 @@ def build_kdtree(tri_verts: np.ndarray, accel_params_ptr=None):
     _chk(hip_lib().rt_accel_copy(t, nodes.ctypes.data, refs.ctypes.data))
     hip_lib().rt_accel_destroy(t)
     return nodes, refs[:info.n_leaf_refs], np.array(list(info.bounds), np.float32), info
+
+
+def leaf_layout(tri_verts: np.ndarray, accel_params_ptr=None, runs: bool = False, copies: bool = False):
+    """Host-only: the kd-tree of `tri_verts` and its leaves as rt_scene_create lays them out for the flat traversal (rt_accel_leaf_layout).
+    Returns (nodes[n,2], leaf_refs, tnodes[n,2], slot_prim, entries, stride)."""
+    tv = np.ascontiguousarray(tri_verts, np.float32).reshape(-1, 9)
+    t = C.c_void_p()
+    _chk(hip_lib().rt_accel_build(tv.ctypes.data, len(tv), accel_params_ptr, C.byref(t)))
+    try:
+        info = RtAccelInfo()
+        _chk(hip_lib().rt_accel_info(t, C.byref(info)))
+        nodes = np.zeros((info.n_nodes, 2), np.uint32)
+        refs = np.zeros(max(info.n_leaf_refs, 1), np.uint32)
+        _chk(hip_lib().rt_accel_copy(t, nodes.ctypes.data, refs.ctypes.data))
+        li = RtLeafLayoutInfo()
+        _chk(hip_lib().rt_accel_leaf_layout(t, int(runs), int(copies), None, None, None, C.byref(li)))
+        tn = np.zeros((li.n_nodes, 2), np.uint32); sp = np.zeros(max(li.n_slots, 1), np.uint32); en = np.zeros(max(li.n_entries, 1), np.uint32)
+        _chk(hip_lib().rt_accel_leaf_layout(t, int(runs), int(copies), tn.ctypes.data, sp.ctypes.data, en.ctypes.data, C.byref(li)))
+    finally:
+        hip_lib().rt_accel_destroy(t)
+    return nodes, refs[:info.n_leaf_refs], tn, sp[:li.n_slots], en[:li.n_entries], int(li.stride)
 
 
 def fit_tile(extent: int, size: int) -> int:

@@ -53,4 +53,13 @@ void build_grid(const float *tri_verts, uint32_t n_tris, GridAccelData &out);
 
 void build_kdtree(const float *tri_verts, uint32_t n_tris, const RtAccelParams &params, KdTree &out);
 
+// The leaves of a flattened kd-tree as the flat traversal reads them (leaf_layout.cpp; encoding: rt_leaf_entries.h)
+struct LeafLayout {
+    NodeVec tnodes;                       // the nodes with leaves in entry form
+    RefVec lrefs;                         // entries of the third and later primitives of the leaves
+    RefVec slot_prim;                     // record slot -> primitive
+    size_t n_slots = 0;
+};
+bool leaf_cursor_layout(const NodeVec &nodes, const RefVec &leaf_refs, uint32_t n_tris, bool copies, bool runs, LeafLayout &out);
+
 }  // namespace rt

@@ -96,6 +96,14 @@ RT_DEV void pipe_load(const PipePool &pl, const DevFrame &fr, unsigned slot, Lan
         ln.thr = mk3(1.f);
         return;
     }
+    if (ln.stage == ST_VERTEX) {                               // waiting for a camera / continuation / specular ray: the next vertex is made from the hit (make_vertex) and
+        const float4 a2 = st[2 * n], a3 = st[3 * n];           // every field of the direct-lighting loop is set before it is read (stage_body ST_VERTEX, ST_DIRECT_NEXT): only
+        ln.L = mk3(a2.x, a2.y, a2.z);                          // the radiance bookkeeping travels (round 6: 4 planes instead of 11 each way, a quarter of a C5 sample's state traffic)
+        { const unsigned ml = __float_as_uint(a2.w); ln.v.mat = int(ml & 0xffffu); ln.v.light = int(ml >> 16) - 1; }
+        ln.thr = mk3(a3.x, a3.y, a3.z);
+        { const unsigned lj = __float_as_uint(a3.w); ln.li = int(lj & 0xffffu); ln.lj = int(lj >> 16); }
+        return;
+    }
     const float4 a2 = st[2 * n], a3 = st[3 * n], a4 = st[4 * n], a5 = st[5 * n], a6 = st[6 * n], a7 = st[7 * n], a8 = st[8 * n], a9 = st[9 * n];
     ln.L = mk3(a2.x, a2.y, a2.z);
     { const unsigned ml = __float_as_uint(a2.w); ln.v.mat = int(ml & 0xffffu); ln.v.light = int(ml >> 16) - 1; }
@@ -126,6 +134,7 @@ RT_DEV void pipe_store(const PipePool &pl, unsigned slot, const Lane &ln) {
     st[2 * n] = make_float4(ln.L.x, ln.L.y, ln.L.z, __uint_as_float(unsigned(ln.v.mat) | (unsigned(ln.v.light + 1) << 16)));
     if (ln.stage == ST_VOL_STEP) return;                       // parked for the march kernel: the surface vertex is dead (see pipe_load)
     st[3 * n] = make_float4(ln.thr.x, ln.thr.y, ln.thr.z, __uint_as_float(unsigned(ln.li) | (unsigned(ln.lj) << 16)));
+    if (ln.stage == ST_VERTEX) return;                         // (only ever stored while the slot waits for the ray that leads to its next vertex: see pipe_load)
     st[4 * n] = make_float4(ln.v.p.x, ln.v.p.y, ln.v.p.z, __int_as_float(ln.cur_light));
     st[5 * n] = make_float4(ln.v.nn.x, ln.v.nn.y, ln.v.nn.z, ln.bs1);
     st[6 * n] = make_float4(ln.v.sn.x, ln.v.sn.y, ln.v.sn.z, ln.bs2);

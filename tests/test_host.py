@@ -346,3 +346,65 @@ def test_bench_scene_texts_for_the_tuned_tree_and_the_parity_leg(pkg):
     assert pk.valid and pk.errors == 0 and pk.n_tris == ps0.n_tris and pk.spp == ps0.spp
     assert pk.width == int(np.ceil(160 * crop[1])) - int(np.ceil(160 * crop[0])) and pk.height == int(np.ceil(120 * crop[3])) - int(np.ceil(120 * crop[2]))
     assert bench.workload("tsmall_tuned")[0] == tuned
+
+
+def _walk_leaf(tn_x, tn_y, entries, stride, runs):
+    """A leaf's record slots in test order, decoded exactly as the kernels do (rt_traverse.h leaf_cursor_enter / leaf_test_flat)."""
+    MORE, LIST, POS, NONE = 0x80000000, 0x40000000, 0x3fffffff, 0xffffffff
+    cur = (int(tn_x) >> 2) | (int(tn_y) & ~POS & 0xffffffff)
+    cursor = (int(tn_y) & POS) << ((int(tn_y) >> 30) & 1)
+    out = []
+    while cur != NONE:
+        pos = cur & POS
+        assert pos % stride == 0
+        out.append(pos // stride)
+        if runs:
+            cur = cur + stride if cursor > 1 else NONE
+            cursor -= 1
+        elif cur >= (MORE | LIST):
+            cur = int(entries[cursor]); cursor += 1
+        elif cur & MORE:
+            cur = cursor                                     # a leaf of two: the cursor is the second entry (its last)
+        else:
+            cur = NONE
+    return out
+
+
+@pytest.mark.parametrize("n_tris,runs,copies", [(0, False, False), (3000, False, False), (3000, True, False), (3000, False, True), (40000, False, False)])
+def test_leaf_entries_enumerate_the_reference_lists(pkg, scenes, n_tris, runs, copies):
+    """Round 6: the flat traversal reads ONE record per primitive and walks a leaf through entries (include/pbrt_hip.h rt_accel_leaf_layout, rt_leaf_entries.h).  On the host alone:
+    decoded the way the kernels decode them, every leaf of the tree must enumerate exactly the primitives the reference's leaf lists (kdtree.cpp:55-64) hold, in their order; the
+    records sit where the depth-first leaf walk FIRST meets each primitive (slot k = the k-th distinct primitive of that walk); lists start at even indices; the runs form gives
+    every leaf consecutive slots; the copies form one slot per reference.  40 000 triangles: > 2^20 nodes, the passes run on several threads."""
+    ps = pkg.ParsedScene(text=scenes.cornell_scene(xres=4, yres=4, integrator="whitted", soup_tris=n_tris))
+    tv = np.ascontiguousarray(ps.tri_verts(), np.float32).reshape(-1, 9)
+    nodes, refs, tn, slot_prim, entries, stride = pkg.leaf_layout(tv, runs=runs, copies=copies)
+    assert stride in (3, 4) and tn.shape == nodes.shape
+    leaf = (nodes[:, 0] & 3) == 3
+    assert np.array_equal(tn[~leaf], nodes[~leaf]) and np.all((tn[leaf, 0] & 3) == 3)          # the tree's shape is untouched
+    idx = np.nonzero(leaf)[0]
+    # the depth-first leaf walk: nodes are stored depth-first, so node order is walk order
+    def ref_list(i):
+        n = int(nodes[i, 0]) >> 2
+        return [int(nodes[i, 1])] if n == 1 else [int(r) for r in refs[int(nodes[i, 1]):int(nodes[i, 1]) + n]]
+    if not (runs or copies):
+        seen, order = set(), []
+        for i in idx:
+            for p in ref_list(i):
+                if p not in seen:
+                    seen.add(p); order.append(p)
+        assert order == [int(p) for p in slot_prim] and len(order) == len(tv)                  # first-touch order, every primitive exactly once
+    else:
+        assert len(slot_prim) == int((nodes[leaf, 0] >> 2).sum())                                # one record per reference
+    rng = np.random.default_rng(1)
+    sample = idx if len(idx) <= 30000 else np.concatenate([idx[:5000], rng.choice(idx, 20000, replace=False)])
+    for i in sample:
+        slots = _walk_leaf(tn[i, 0], tn[i, 1], entries, stride, runs)
+        assert [int(slot_prim[k]) for k in slots] == ref_list(i), (i, slots)
+        if runs and slots:
+            assert slots == list(range(slots[0], slots[0] + len(slots)))
+        ty = int(tn[i, 1])
+        if not runs and len(slots) >= 3:
+            assert ty & 0xC0000000 == 0xC0000000 and ((ty & 0x3fffffff) * 2) % 2 == 0
+        if len(slots) == 0:
+            assert int(tn[i, 0]) == 0xffffffff
