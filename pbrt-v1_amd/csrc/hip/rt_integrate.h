@@ -138,6 +138,9 @@ RT_DEV float dim_value(const DevFrame &fr, const Lane &ln, const DimReq &r, int 
 // ImageFilm::AddSample (image.cpp:103-142) per pixel in the reference's sample order.  Compared with
 // atomically splatting each sample into (2w+1)^2 pixels x 5 planes this removes ~100 L2 atomics per sample
 // (59 % of the frame time on the Cornell path-tracing config) and makes the film deterministic.
+#ifndef RT_SAMPLE_NT
+#define RT_SAMPLE_NT 1
+#endif
 RT_DEV void sample_write(const DevFrame &fr, const Lane &ln, V3 Ls, float alpha, unsigned &bad) {
     const float y = lum_y(Ls);
     if (Ls.x != Ls.x || Ls.y != Ls.y || Ls.z != Ls.z) { Ls = mk3(0.f); ++bad; }
@@ -145,8 +148,16 @@ RT_DEV void sample_write(const DevFrame &fr, const Lane &ln, V3 Ls, float alpha,
     else if (isinf(y)) { Ls = mk3(0.f); ++bad; }
     const uint32_t lp = ln.work / uint32_t(fr.spp);
     float4 RT_G *rec = RT_GPTR(float4, fr.samples) + sample_slot(lp, ln.work - lp * uint32_t(fr.spp), fr.spp);
+#if RT_SAMPLE_NT
+    // written once, read once by the film gather after the kernel: keep the records out of the way of the tree's lines in L2 (non-temporal stores)
+    typedef float nt_f4 __attribute__((ext_vector_type(4)));
+    const nt_f4 r0 = {Ls.x, Ls.y, Ls.z, alpha}, r1 = {ln.image_x, ln.image_y, 0.f, 0.f};
+    __builtin_nontemporal_store(r0, (nt_f4 RT_G *)rec);
+    __builtin_nontemporal_store(r1, (nt_f4 RT_G *)(rec + RT_SAMPLE_XY));
+#else
     rec[0] = make_float4(Ls.x, Ls.y, Ls.z, alpha);
     rec[RT_SAMPLE_XY] = make_float4(ln.image_x, ln.image_y, 0.f, 0.f);
+#endif
 }
 
 // ---- camera sample -> camera ray -----------------------------------------------------------------------
